@@ -1,0 +1,155 @@
+/* rtx.h -- C ABI of the MI355X-native tracer (librtx_hip.so).
+ *
+ * This is the drop-in boundary for the reference's GLSL fragment-shader path
+ * (assets/shaders/rt.frag dispatched by src/GLWrapper.cpp). Each entry point replaces one
+ * GLWrapper method or one GL call the reference's main loop issues; the reference file:line is
+ * cited per function. Plain pointers and sizes only -- no C++/torch types -- so that C, C++,
+ * Python (ctypes) or any FFI can bind it. include/rtx/GLWrapper.h is the header-only C++ shim
+ * with the reference's own class/method names on top of these calls.
+ *
+ * Conventions
+ *   - every call returns an rtx_status (0 = ok); rtx_last_error() gives the message of the
+ *     last failure on the calling thread. The reference prints and exit()s instead
+ *     (GLWrapper.cpp:224-227,371-375; utils.h:57-63); the C++ shim restores that behaviour.
+ *   - the library never keeps caller pointers: block and texture bytes are copied during the call
+ *     (same ownership rule as glBufferData / glTexImage2D).
+ *   - single-threaded per context, like a GL context.
+ *   - there is NO CPU fallback: rtx_create fails with RTX_ERR_DEVICE when no gfx950 device /
+ *     HIP runtime is usable.
+ *   - framebuffer row 0 is the BOTTOM row (gl_FragCoord origin, rt.frag:315).
+ */
+#ifndef RTX_H_
+#define RTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RTX_API __attribute__((visibility("default")))
+#else
+#define RTX_API
+#endif
+
+typedef struct rtx_context rtx_context;
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID = 1, /* bad argument */
+    RTX_ERR_DEVICE = 2,  /* HIP runtime / device failure (message has the hipError) */
+    RTX_ERR_ORDER = 3,   /* call made before rtx_specialize, or draw with missing blocks */
+    RTX_ERR_NAME = 4,    /* unknown uniform-block or sampler name */
+    RTX_ERR_HANDLE = 5   /* unknown block / texture handle */
+} rtx_status;
+
+/* Same 60 bytes as the reference's `rt_defines` (src/scene.h:7-20): eight array sizes, the
+ * bounce depth and two colours. It is the tracer's specialisation key. */
+typedef struct rtx_defines {
+    int32_t sphere_size, plane_size, surface_size, box_size, torus_size, ring_size;
+    int32_t light_point_size, light_direct_size;
+    int32_t iterations;
+    float ambient_color[3];
+    float shadow_ambient[3];
+} rtx_defines;
+
+typedef enum rtx_format {
+    RTX_RGBA32F = 0, /* 16 B/pixel, unclamped -- the parity buffer (FragColor before write-out) */
+    RTX_RGBA8 = 1    /* 4 B/pixel, clamp [0,1] + round-to-nearest -- what GL_RGBA8 fboColor holds
+                        (GLWrapper.cpp:127,209-222) */
+} rtx_format;
+
+typedef enum rtx_wrap { RTX_WRAP_REPEAT = 0, RTX_WRAP_CLAMP_TO_EDGE = 1 } rtx_wrap;
+
+typedef enum rtx_option {
+    RTX_OPT_CULL = 0,        /* 1 (default): conservative bounding culls in front of the torus /
+                                quadric / box / ring tests (parity-gated); 0: literal scans */
+    RTX_OPT_COUNT_RAYS = 1,  /* 1: kernel also counts closest-hit and shadow rays (rtx_stats) */
+    RTX_OPT_SCENE_LDS = 2,   /* 1: stage the scene tables into LDS per workgroup; 0: scalar (SMEM) loads */
+    RTX_OPT_TEXTURE_LOD = 3  /* 0: level-0 bilinear everywhere; 1: mip chain + quad-derivative LOD */
+} rtx_option;
+
+typedef struct rtx_stats {
+    float last_draw_ms;        /* HIP-event time of the last rtx_draw* kernel(s) on their stream */
+    uint32_t launches;         /* kernel launches since rtx_create */
+    uint64_t rays_closest;     /* valid after a draw with RTX_OPT_COUNT_RAYS = 1 */
+    uint64_t rays_shadow;      /*   (reference-defined rays: calcInter / inShadow invocations) */
+    uint64_t rays_shadow_cast; /*   shadow scans the kernel actually executed (dp > 0 only) */
+    uint64_t torus_solves;     /*   Durand-Kerner solves actually run */
+} rtx_stats;
+
+RTX_API const char* rtx_last_error(void);
+RTX_API const char* rtx_version(void);
+
+/* GLWrapper::GLWrapper(w,h,fullScreen) + init_window()  [GLWrapper.cpp:12-18,61-133]
+ * Creates the device context and the w x h colour target on HIP device `device`.
+ * The new context becomes current (see rtx_current). */
+RTX_API int rtx_create(int width, int height, int device, rtx_context** out);
+/* GLWrapper::~GLWrapper / stop()  [GLWrapper.cpp:25-44,143-147] */
+RTX_API void rtx_destroy(rtx_context* ctx);
+/* The reference's update_buffer / load_cubemap are static and act on "the current GL context";
+ * the shim uses these for the same purpose. */
+RTX_API rtx_context* rtx_current(void);
+RTX_API int rtx_make_current(rtx_context* ctx);
+RTX_API int rtx_get_size(rtx_context* ctx, int* width, int* height); /* getWidth/getHeight */
+
+/* GLWrapper::init_shaders(rt_defines&)  [GLWrapper.cpp:232-277]
+ * Fixes array sizes, bounce depth and the two colour constants. The two colours take the same
+ * "%f" text round trip as the reference's shader templating (GLWrapper.cpp:246-247,279-282).
+ * Must precede block/texture calls, like the reference (names are looked up in the program). */
+RTX_API int rtx_specialize(rtx_context* ctx, const rtx_defines* defines);
+
+/* GLWrapper::init_buffer(ubo,name,bindingPoint,size,data)  [GLWrapper.cpp:365-379]
+ * `name` is one of scene_buf, spheres_buf, planes_buf, surfaces_buf, boxes_buf, toruses_buf,
+ * rings_buf, lights_point_buf, lights_direct_buf (rt.frag:155-230). size may be 0 and data NULL.
+ * Unknown name -> RTX_ERR_NAME (the reference exits). */
+RTX_API int rtx_block_create(rtx_context* ctx, const char* name, int binding_point, size_t size,
+                             const void* data, uint32_t* handle);
+/* GLWrapper::update_buffer(ubo,size,data)  [GLWrapper.cpp:381-386] -- overwrite from offset 0. */
+RTX_API int rtx_block_update(rtx_context* ctx, uint32_t handle, size_t size, const void* data);
+
+/* GLWrapper::load_texture(path,wrap) minus the file decode  [GLWrapper.cpp:319-354]:
+ * 8-bit interleaved texels, 1/3/4 channels, row 0 = t 0 (stb_image order, no flip); builds the
+ * full mip chain (glGenerateMipmap), trilinear min / linear mag. */
+RTX_API int rtx_texture2d_create(rtx_context* ctx, int width, int height, int channels,
+                                 const uint8_t* texels, int wrap, uint32_t* handle);
+/* GLWrapper::load_cubemap(faces,genMipmap) minus the file decode  [GLWrapper.cpp:284-317]:
+ * faces in +X,-X,+Y,-Y,+Z,-Z order; a NULL face is skipped (stays black) like a face that
+ * failed to load. LINEAR, CLAMP_TO_EDGE, not seamless. */
+RTX_API int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels,
+                               const uint8_t* const faces[6], int gen_mipmap, uint32_t* handle);
+/* shader.setInt(uniformName, unit)  [GLWrapper.cpp:138,360]: sampler names skybox,
+ * texture_sphere_1..4, texture_ring, texture_box (rt.frag:136-143). */
+RTX_API int rtx_sampler_unit(rtx_context* ctx, const char* sampler_name, int unit);
+/* glActiveTexture(GL_TEXTURE0+unit); glBindTexture(target, handle)  [main.cpp:178-187,
+ * GLWrapper.cpp:139-140]. */
+RTX_API int rtx_bind_texture(rtx_context* ctx, int unit, uint32_t handle);
+RTX_API int rtx_texture_destroy(rtx_context* ctx, uint32_t handle);
+
+RTX_API int rtx_set_option(rtx_context* ctx, int option, int value);
+RTX_API int rtx_get_option(rtx_context* ctx, int option, int* value);
+
+/* GLWrapper::draw()  [GLWrapper.cpp:155-165]: trace one frame from the CURRENT block and texture
+ * contents into the context's own colour target (both formats are written). Asynchronous on the
+ * context's stream; rtx_read_pixels / rtx_finish synchronise. */
+RTX_API int rtx_draw(rtx_context* ctx);
+/* Multi-GPU / external-target form of draw(): trace only the row bands
+ * band_first, band_first+band_stride, ... (each `band_rows` rows, band b covers rows
+ * [b*band_rows, min((b+1)*band_rows, H)) ) and store them PACKED, band after band, into `dst`
+ * (a device pointer to >= rows*W pixels of `format`). `stream` is a hipStream_t (NULL = the
+ * context's stream). band_rows must be a multiple of 8. */
+RTX_API int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride,
+                           void* dst_device, int format, void* stream);
+RTX_API int rtx_finish(rtx_context* ctx);
+/* glReadPixels equivalent for tests/tools: copy the colour target to host memory. */
+RTX_API int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_bytes);
+/* Device pointer of the colour target (W*H pixels of `format`), for zero-copy consumers. */
+RTX_API int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr);
+RTX_API int rtx_get_stats(rtx_context* ctx, rtx_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H_ */

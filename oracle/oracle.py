@@ -1,0 +1,139 @@
+"""ctypes binding of the CPU oracle (oracle/rt_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product
+package (raytracing_opengl_amd/).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+TEX_SLOTS = ("texture_sphere_1", "texture_sphere_2", "texture_sphere_3", "texture_sphere_4", "texture_ring", "texture_box")
+BLOCK_FIELDS = ("scene_buf", "spheres_buf", "planes_buf", "surfaces_buf", "boxes_buf", "toruses_buf", "rings_buf",
+                "lights_point_buf", "lights_direct_buf")
+TYPE_SPHERE, TYPE_PLANE, TYPE_SURFACE, TYPE_BOX, TYPE_TORUS, TYPE_RING, TYPE_POINT_LIGHT = range(7)
+
+
+class Defines(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("sphere_size", "plane_size", "surface_size", "box_size", "torus_size", "ring_size",
+                                              "light_point_size", "light_direct_size", "iterations")] + \
+               [("ambient_color", ctypes.c_float * 3), ("shadow_ambient", ctypes.c_float * 3)]
+
+
+class Texture(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("channels", ctypes.c_int32), ("wrap", ctypes.c_int32),
+                ("texels", ctypes.c_void_p)]
+
+
+class Cubemap(ctypes.Structure):
+    _fields_ = [("face_size", ctypes.c_int32), ("channels", ctypes.c_int32), ("faces", ctypes.c_void_p * 6)]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [("fb_width", ctypes.c_int32), ("fb_height", ctypes.c_int32), ("defines", Defines)] + \
+               [(n, ctypes.c_void_p) for n in BLOCK_FIELDS] + \
+               [("skybox", Cubemap), ("tex", Texture * 6), ("texture_lod", ctypes.c_int32)]
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("rays_closest", ctypes.c_uint64), ("rays_shadow", ctypes.c_uint64), ("tests", ctypes.c_uint64 * 7),
+                ("dk_solves", ctypes.c_uint64), ("dk_sweeps", ctypes.c_uint64), ("dk_capped", ctypes.c_uint64),
+                ("t4_taken", ctypes.c_uint64), ("refract_segments", ctypes.c_uint64), ("tir_breaks", ctypes.c_uint64),
+                ("alpha_pass", ctypes.c_uint64), ("side_miss", ctypes.c_uint64), ("light_hits", ctypes.c_uint64),
+                ("box_nan_hits", ctypes.c_uint64), ("box_inside_hits", ctypes.c_uint64), ("segment_cap_hits", ctypes.c_uint64),
+                ("max_segments", ctypes.c_uint64)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "tests"}
+        d["tests"] = list(self.tests)
+        d["rays"] = self.rays_closest + self.rays_shadow
+        return d
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with oracle/Makefile (gcc, -ffp-contract=off)."""
+    src = os.path.join(_HERE, "rt_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = ctypes.CDLL(_LIB_PATH)
+        l.orc_render.restype = ctypes.c_int
+        l.orc_render.argtypes = [ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(Counters), ctypes.c_int]
+        l.orc_kat_intersect.restype = ctypes.c_int
+        l.orc_kat_intersect.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_float * 3, ctypes.c_float * 3, ctypes.c_float, ctypes.c_int,
+                                        ctypes.c_float * 5]
+        l.orc_kat_atan2.restype = ctypes.c_float
+        l.orc_kat_atan2.argtypes = [ctypes.c_float, ctypes.c_float]
+        l.orc_kat_asin.restype = ctypes.c_float
+        l.orc_kat_asin.argtypes = [ctypes.c_float]
+        l.orc_kat_rotate.argtypes = [ctypes.c_float * 4, ctypes.c_float * 3, ctypes.c_float * 3]
+        l.orc_kat_sample2d.argtypes = [ctypes.POINTER(Texture), ctypes.c_float, ctypes.c_float, ctypes.c_float * 4]
+        l.orc_kat_sample_cube.argtypes = [ctypes.POINTER(Cubemap), ctypes.c_float * 3, ctypes.c_float * 4]
+        l.orc_kat_text_round_trip.restype = ctypes.c_float
+        l.orc_kat_text_round_trip.argtypes = [ctypes.c_float]
+        _lib = l
+    return _lib
+
+
+class OracleScene:
+    """Holds one frame description (blocks + textures) alive for orc_render calls."""
+
+    def __init__(self, scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, texture_lod: int = 0):
+        """scene_blocks: object with .defines (15-tuple) and .blocks (name -> bytes);
+        textures: iterable of (sampler_uniform_name, unit, HxWxC uint8 array); cubemap: six NxNxC uint8 arrays."""
+        self._keep = []
+        fr = Frame()
+        fr.fb_width, fr.fb_height = fb_width, fb_height
+        d = scene_blocks.defines
+        for i, (n, _t) in enumerate(Defines._fields_[:9]):
+            setattr(fr.defines, n, int(d[i]))
+        fr.defines.ambient_color = (ctypes.c_float * 3)(*d[9:12])
+        fr.defines.shadow_ambient = (ctypes.c_float * 3)(*d[12:15])
+        for name in BLOCK_FIELDS:
+            raw = scene_blocks.blocks.get(name, b"")
+            buf = ctypes.create_string_buffer(raw, max(len(raw), 1))
+            self._keep.append(buf)
+            setattr(fr, name, ctypes.cast(buf, ctypes.c_void_p))
+        for uniform, _unit, img in (textures or ()):
+            slot = TEX_SLOTS.index(uniform)
+            arr = np.ascontiguousarray(img, dtype=np.uint8)
+            self._keep.append(arr)
+            h, w = arr.shape[:2]
+            c = 1 if arr.ndim == 2 else arr.shape[2]
+            fr.tex[slot] = Texture(w, h, c, 0, arr.ctypes.data)
+        if cubemap is not None:
+            faces = [None if f is None else np.ascontiguousarray(f, dtype=np.uint8) for f in cubemap]
+            self._keep.append(faces)
+            first = next(f for f in faces if f is not None)
+            fr.skybox.face_size = first.shape[0]
+            fr.skybox.channels = first.shape[2]
+            for i, f in enumerate(faces):
+                fr.skybox.faces[i] = None if f is None else f.ctypes.data
+        fr.texture_lod = texture_lod
+        self.frame = fr
+        self.width, self.height = fb_width, fb_height
+
+    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0):
+        """Returns (float32 array (rows, W, 4), counters dict). Row 0 = bottom (gl_FragCoord)."""
+        y1 = self.height if y1 is None else y1
+        out = np.empty((y1 - y0, self.width, 4), dtype=np.float32)
+        cnt = Counters()
+        rc = lib().orc_render(ctypes.byref(self.frame), y0, y1, out.ctypes.data, ctypes.byref(cnt), threads)
+        if rc != 0:
+            raise RuntimeError("orc_render failed")
+        return out, cnt.as_dict()
