@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the rt.frag path on MI355X.
+
+Metric (BASELINE.json): Mray/s (+ ms/frame) at 3840x2160, reflection depth 4, default scene.
+A "step" = one full frame traced from blocks/textures already resident in HBM. A ray = one
+closest-hit scan (calcInter) or one shadow scan (inShadow) as the REFERENCE would execute them
+(SURVEY.md section 8(d)); the per-frame count is exact (kernel counter == oracle counter, see
+tests/test_gpu_parity.py) and is measured once, untimed, with the counting kernel variant.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into
+interleaved row bands (raytracing_opengl_amd/bands.py), every rank traces its bands, and the frame
+is gathered to rank 0 over RCCL each step -> "scaling": "strong".
+
+Extra objects on the JSON line:
+  roofline     HBM-write roofline of the trace kernel: W*H*16 B of RGBA32F per launch / mean kernel
+               time from HIP events on the launch stream, against 8 TB/s.
+  cpu_baseline the oracle (scalar C restatement of the shader, all host cores) timed on one full
+               frame of the same workload, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WIDTH, HEIGHT, DEPTH, SCENE = 3840, 2160, 4, "default"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--texture-scale", type=int, default=1, help="divide the reference texture sizes (1 = reference sizes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lds", type=int, default=0)
+    ap.add_argument("--cull", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP tracer has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from raytracing_opengl_amd import bands, scenes, textures, wrapper
+
+    W, H = args.width, args.height
+    sc = scenes.build_scene(args.scene, W, H, args.depth)
+    ts = textures.default_texture_set(scale=args.texture_scale)
+    gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank)
+    gl.set_option(wrapper.RTX_OPT_CULL, args.cull)
+    gl.set_option(wrapper.RTX_OPT_SCENE_LDS, args.lds)
+
+    band_rows = ((H + 7) // 8) * 8 if world == 1 else bands.choose_band_rows(H, world)
+    gather = bands.FrameGather(H, W, 4, band_rows, torch.float32, device, dst=0)
+    bufs = [gather.new_local(torch.float32, device) for _ in range(2)]
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    # exact reference-defined ray count of this rank's bands (untimed, counting kernel variant)
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    gl.draw_bands(band_rows, rank, world, bufs[0].data_ptr(), wrapper.RTX_RGBA32F, stream)
+    torch.cuda.synchronize(device)
+    st = gl.stats()
+    rays_local = st["rays_closest"] + st["rays_shadow"]
+    rays_cast_local = st["rays_closest"] + st["rays_shadow_cast"]
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 0)
+    rays_t = torch.tensor([rays_local, rays_cast_local], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(rays_t)
+    rays_frame, rays_cast_frame = int(rays_t[0]), int(rays_t[1])
+
+    def step(k, pending):
+        buf = bufs[k & 1]
+        if pending[k & 1] is not None:          # the gather that last read this buffer must be done
+            gather.frame(pending[k & 1])
+            pending[k & 1] = None
+        gl.draw_bands(band_rows, rank, world, buf.data_ptr(), wrapper.RTX_RGBA32F, stream)
+        pending[k & 1] = gather.gather(buf)      # async; overlaps the next step's trace
+
+    def drain(pending):
+        out = None
+        for j in (0, 1):
+            if pending[j] is not None:
+                out = gather.frame(pending[j])
+                pending[j] = None
+        return out
+
+    pending = [None, None]
+    for k in range(args.warmup):
+        step(k, pending)
+    drain(pending)
+    torch.cuda.synchronize(device)
+    gl.stats()  # retire warm-up events
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, pending)
+    frame = drain(pending)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+
+    n_ev = min(args.steps, 128)
+    kernel_ms = gl.sum_recent_draw_ms(n_ev) / n_ev  # HIP events on the launch stream
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays_frame * args.steps / elapsed / 1e6
+        px_bytes_launch = gather.rows_local * W * 16  # algorithmic HBM bytes of one launch on this rank
+        achieved = px_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mray/s at 3840x2160 depth-4 default scene (reference-defined rays: closest-hit + shadow scans)",
+            "value": round(mrays, 2),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene} scene (reference main.cpp:43-132, t=0), {W}x{H}, reflection depth {args.depth}, "
+                                   f"RGBA32F target, seeded synthetic textures at reference sizes/{args.texture_scale}",
+                       "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
+                       "parallelism": "single GPU" if world == 1 else f"{world} GPUs, interleaved {band_rows}-row bands, RCCL gather to rank 0",
+                       "cull": args.cull, "scene_in_lds": args.lds},
+            "ms_per_frame": round(ms_per_step, 4),
+            "kernel_ms": round(kernel_ms, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "note": "HBM-write roofline of the RGBA32F frame (16 B/pixel); the path is ALU/divergence-bound, see DESIGN.md"},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file) and world == 1 and (W, H, args.depth, args.scene) == (WIDTH, HEIGHT, DEPTH, SCENE):
+            try:
+                out["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"])
+            cores = os.cpu_count() or 1
+            c0 = time.perf_counter()
+            ref, cnt = o.render(0, H, threads=cores)
+            cpu_s = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": round((cnt["rays_closest"] + cnt["rays_shadow"]) / cpu_s / 1e6, 3), "unit": "Mray/s",
+                                   "cores": cores, "kind": "port",
+                                   "sample": f"one full {W}x{H} depth-{args.depth} frame of the same workload, oracle/rt_oracle.c, "
+                                             f"OpenMP over rows, {cpu_s:.1f} s"}
+            # the oracle frame is there anyway: report full-size parity next to the timing
+            img = frame.cpu().numpy() if frame is not None else None
+            if img is not None:
+                d = np.abs(img - ref)
+                out["parity"] = {"max_abs_diff": float(np.nanmax(d)), "over_1e-4": int((d > 1e-4).sum()),
+                                 "nan_mismatch": int((np.isnan(img) != np.isnan(ref)).sum()),
+                                 "rays_match": bool(cnt["rays_closest"] + cnt["rays_shadow"] == rays_frame)}
+        print(json.dumps(out), flush=True)
+    gl.stop()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,14 @@ RTX_API int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t
 RTX_API int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr);
 RTX_API int rtx_get_stats(rtx_context* ctx, rtx_stats* out);
 
+/* ---- diagnostics without a reference counterpart ---- */
+/* Sum of the HIP-event durations (ms) of the n most recent draws (n <= 128): the kernel time a
+ * bench needs when it enqueues K draws back to back. A context should be driven from ONE stream. */
+RTX_API int rtx_sum_recent_draw_ms(rtx_context* ctx, int n, float* sum_ms);
+/* Device-side exhaustive check of the divide-free byte->float conversion used by the samplers
+ * (must report 0 mismatches against byte/255.0f). */
+RTX_API int rtx_selftest(rtx_context* ctx, int* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""Row-band partition of one frame over the GPUs of a node + gather of the finished frame.
+
+The reference is single-GPU; this is the multi-GPU step BASELINE.json's north_star adds
+("partition the image over the 8 GPUs of one node as tiled rows with an RCCL gather over xGMI of
+the final frame").  Pixels are independent, so the only exchange is the
+final gather.  Bands are INTERLEAVED (band b belongs to rank b % world): sky rows cost ~1 ray per
+pixel while object rows cost several, so contiguous slabs would be badly imbalanced.
+
+Every rank traces its bands packed back to back (rtx_draw_bands) and the root un-permutes after
+one gather.  Works on CPU tensors with the gloo backend too (tests/test_bands_gloo.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def num_bands(height: int, band_rows: int) -> int:
+    return (height + band_rows - 1) // band_rows
+
+
+def rank_bands(height: int, band_rows: int, rank: int, world: int) -> list[int]:
+    return list(range(rank, num_bands(height, band_rows), world))
+
+
+def band_span(height: int, band_rows: int, b: int) -> tuple[int, int]:
+    y0 = b * band_rows
+    return y0, min(y0 + band_rows, height)
+
+
+def local_rows(height: int, band_rows: int, rank: int, world: int) -> int:
+    return sum(y1 - y0 for y0, y1 in (band_span(height, band_rows, b) for b in rank_bands(height, band_rows, rank, world)))
+
+
+def max_local_rows(height: int, band_rows: int, world: int) -> int:
+    return max(local_rows(height, band_rows, r, world) for r in range(world))
+
+
+def choose_band_rows(height: int, world: int, target_bands_per_rank: int = 8) -> int:
+    """Multiple of 8 (the kernel's tile height); aims at ~target bands per rank for load balance."""
+    rows = max(8, (height // max(1, world * target_bands_per_rank)) // 8 * 8)
+    return rows
+
+
+def unpermute(gathered: list[torch.Tensor], height: int, band_rows: int, world: int) -> torch.Tensor:
+    """gathered[r]: (max_local_rows, W, C) packed bands of rank r -> (height, W, C) frame."""
+    w, c = gathered[0].shape[1], gathered[0].shape[2]
+    frame = torch.empty((height, w, c), dtype=gathered[0].dtype, device=gathered[0].device)
+    nb = num_bands(height, band_rows)
+    if height % band_rows == 0 and nb % world == 0:
+        # regular case: one strided copy
+        per = nb // world
+        src = torch.stack([g[: per * band_rows] for g in gathered], dim=0).view(world, per, band_rows, w, c)
+        frame.view(per, world, band_rows, w, c).copy_(src.permute(1, 0, 2, 3, 4))
+        return frame
+    for r in range(world):
+        off = 0
+        for b in rank_bands(height, band_rows, r, world):
+            y0, y1 = band_span(height, band_rows, b)
+            frame[y0:y1] = gathered[r][off:off + (y1 - y0)]
+            off += y1 - y0
+    return frame
+
+
+class FrameGather:
+    """Pre-allocated gather of packed row bands to rank `dst`.
+
+    gather(local) starts the collective (async) and returns a handle; frame(handle) waits and returns
+    the un-permuted (H, W, C) frame on dst (None elsewhere).  `local` must hold max_local_rows rows
+    (pad rows are ignored).  On one rank it degenerates to a view of the local buffer.
+    """
+
+    def __init__(self, height: int, width: int, channels: int, band_rows: int, dtype, device, dst: int = 0, group=None):
+        self.height, self.width, self.channels, self.band_rows = height, width, channels, band_rows
+        self.dst, self.group = dst, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rows_max = max_local_rows(height, band_rows, self.world)
+        self.rows_local = local_rows(height, band_rows, self.rank, self.world)
+        self.recv = None
+        if self.world > 1 and self.rank == dst:
+            self.recv = [torch.empty((self.rows_max, width, channels), dtype=dtype, device=device) for _ in range(self.world)]
+
+    def new_local(self, dtype, device) -> torch.Tensor:
+        return torch.empty((self.rows_max, self.width, self.channels), dtype=dtype, device=device)
+
+    def gather(self, local: torch.Tensor):
+        if self.world == 1:
+            return (None, local)
+        work = dist.gather(local, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        return (work, local)
+
+    def frame(self, handle):
+        work, local = handle
+        if self.world == 1:
+            return unpermute([local], self.height, self.band_rows, 1)
+        work.wait()
+        if self.rank != self.dst:
+            return None
+        return unpermute(self.recv, self.height, self.band_rows, self.world)

@@ -1,0 +1,969 @@
+// rt_device.h -- the per-pixel tracer (device code of the MI355X path).
+//
+// Replaces the reference's fragment shader assets/shaders/rt.frag. This is NOT a transliteration:
+// the shader's recursive-looking structure (main -> getReflectedColor -> calcShade -> inShadow,
+// each with its own copy of the primitive scans) is rebuilt as ONE wave-uniform segment loop with
+// a single closest-hit site and a single shading site; per-primitive constants are hoisted into
+// the DevScene tables (rt_scene_dev.h); ray-invariant terms of the torus quartic are hoisted out
+// of the Durand-Kerner sweeps; shadow rays whose result is provably unused are not cast;
+// conservative bounding culls sit in front of the expensive solvers.
+//
+// Numerics contract (DESIGN.md "Numerics"): every value that feeds a hit/miss decision is
+// computed with exactly the float operations, in exactly the order, that rt.frag spells out
+// (IEEE binary32, no FMA contraction: the file must be compiled with -ffp-contract=off; IEEE
+// division and sqrt). Hoisting and culling never change an operand. Citations "rt.frag:N" give
+// the shader lines whose semantics a function carries.
+//
+// The header is also compilable by a plain host C++ compiler (tests/host_harness) so that the
+// device logic can be checked against the oracle without a GPU; wave intrinsics collapse to
+// their one-lane meaning there.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_scene_dev.h"
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD static inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_ANY(x) (__any((x)) != 0)
+#else
+#define RT_ANY(x) (x)
+#endif
+
+namespace rtdev {
+
+// ------------------------------------------------------------------------------------------
+// small vector algebra (component order and association exactly as GLSL evaluates them)
+// ------------------------------------------------------------------------------------------
+RT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+RT_HD f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+RT_HD f3 xyz(const f4& v) { return mk3(v.x, v.y, v.z); }
+RT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+RT_HD float length3(f3 a) { return sqrtf(dot3(a, a)); }
+RT_HD f3 normalize3(f3 a) { return a / length3(a); }
+RT_HD float gl_min(float a, float b) { return b < a ? b : a; }   // GLSL min: NaN-asymmetric on purpose
+RT_HD float gl_max(float a, float b) { return a < b ? b : a; }
+RT_HD float gl_clamp(float x, float lo, float hi) { return gl_min(gl_max(x, lo), hi); }
+RT_HD float gl_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+RT_HD float gl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+RT_HD f3 gl_reflect(f3 I, f3 N) { return I - N * (2.0f * dot3(N, I)); }
+RT_HD f3 gl_refract(f3 I, f3 N, float eta)
+{
+    const float d = dot3(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    return I * eta - N * (eta * d + sqrtf(k));
+}
+
+// rt.frag:285-311. quat_rotate keeps every product of quat_mult, including the ones with the
+// zero w of the embedded vector: dropping them would change signed zeros / NaN propagation.
+RT_HD f4 quat_conj(f4 q) { return mk4(-q.x, -q.y, -q.z, q.w); }
+RT_HD f4 quat_inv(f4 q)
+{
+    const f4 c = quat_conj(q);
+    const float s = 1.0f / (q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return mk4(c.x * s, c.y * s, c.z * s, c.w * s);
+}
+RT_HD f3 quat_rotate(f4 q, f3 v)
+{
+    const float pw = 0.0f;
+    // q_tmp = quat_mult(q, (v,0))
+    const float tx = (q.w * v.x) + (q.x * pw) + (q.y * v.z) - (q.z * v.y);
+    const float ty = (q.w * v.y) - (q.x * v.z) + (q.y * pw) + (q.z * v.x);
+    const float tz = (q.w * v.z) + (q.x * v.y) - (q.y * v.x) + (q.z * pw);
+    const float tw = (q.w * pw) - (q.x * v.x) - (q.y * v.y) - (q.z * v.z);
+    // quat_mult(q_tmp, conj(q)).xyz
+    const float cx = -q.x, cy = -q.y, cz = -q.z, cw = q.w;
+    f3 r;
+    r.x = (tw * cx) + (tx * cw) + (ty * cz) - (tz * cy);
+    r.y = (tw * cy) - (tx * cz) + (ty * cw) + (tz * cx);
+    r.z = (tw * cz) + (tx * cy) - (ty * cx) + (tz * cw);
+    return r;
+}
+
+// atan(y,x) / asin(x) of the equirect mapping (rt.frag:323-324): fixed float64 series, only
+// + - * / sqrt, one final rounding to float -> bit-reproducible on host and device
+// (DESIGN.md "Numerics"; the oracle states the same algorithm independently).
+RT_HD double atan_unit(double a)  // 0 <= a <= 1
+{
+    double off = 0.0;
+    if (a > 0.4142135623730950488) { a = (a - 1.0) / (a + 1.0); off = 0.78539816339744830962; }
+    const double s = a * a;
+    double p = 1.0 / 25.0;
+    p = 1.0 / 23.0 - s * p;
+    p = 1.0 / 21.0 - s * p;
+    p = 1.0 / 19.0 - s * p;
+    p = 1.0 / 17.0 - s * p;
+    p = 1.0 / 15.0 - s * p;
+    p = 1.0 / 13.0 - s * p;
+    p = 1.0 / 11.0 - s * p;
+    p = 1.0 / 9.0 - s * p;
+    p = 1.0 / 7.0 - s * p;
+    p = 1.0 / 5.0 - s * p;
+    p = 1.0 / 3.0 - s * p;
+    p = 1.0 - s * p;
+    return off + a * p;
+}
+RT_HD float rt_atan2(float yf, float xf)
+{
+    const double y = (double)yf, x = (double)xf;
+    const double ay = y < 0.0 ? -y : y, ax = x < 0.0 ? -x : x;
+    const double mx = ax < ay ? ay : ax, mn = ax < ay ? ax : ay;
+    double r;
+    if (!(mx > 0.0)) r = 0.0;
+    else {
+        r = atan_unit(mn / mx);
+        if (ax < ay) r = 1.57079632679489661923 - r;
+        if (x < 0.0) r = 3.14159265358979323846 - r;
+        if (y < 0.0) r = -r;
+    }
+    return (float)r;
+}
+RT_HD float rt_asin(float xf)
+{
+    const double x = (double)xf;
+    const double c = sqrt(1.0 - x * x);
+    if (!(c == c)) return NAN;
+    const double ax = x < 0.0 ? -x : x;
+    const double mx = ax < c ? c : ax, mn = ax < c ? ax : c;
+    double r;
+    if (!(mx > 0.0)) r = 0.0;
+    else {
+        r = atan_unit(mn / mx);
+        if (c < ax) r = 1.57079632679489661923 - r;
+        if (x < 0.0) r = -r;
+    }
+    return (float)r;
+}
+
+// ------------------------------------------------------------------------------------------
+// scene view + constants
+// ------------------------------------------------------------------------------------------
+#define RT_MAXDIST 1000000.0f         /* rt.frag:145 */
+#define RT_PI_F 3.14159265358979f     /* rt.frag:5 */
+#define RT_FLT_MAX 3.402823466e+38f   /* rt.frag:4 */
+#define RT_SEGMENT_CAP 256            /* bound on main-loop trips (refraction does i--, trap T2) */
+
+struct SceneView {
+    const DevSceneHeader* h;
+    const DevSphere* spheres;
+    const DevPlane* planes;
+    const DevSurface* surfaces;
+    const DevBox* boxes;
+    const DevTorus* tori;
+    const DevRing* rings;
+    const DevLightPoint* lights_point;
+    const DevLightDirect* lights_direct;
+    const DevMaterial* mats[6];
+};
+RT_HD SceneView make_view(const char* blob)
+{
+    SceneView S;
+    const DevSceneHeader* h = reinterpret_cast<const DevSceneHeader*>(blob);
+    S.h = h;
+    S.spheres = reinterpret_cast<const DevSphere*>(blob + h->off_sphere);
+    S.planes = reinterpret_cast<const DevPlane*>(blob + h->off_plane);
+    S.surfaces = reinterpret_cast<const DevSurface*>(blob + h->off_surface);
+    S.boxes = reinterpret_cast<const DevBox*>(blob + h->off_box);
+    S.tori = reinterpret_cast<const DevTorus*>(blob + h->off_torus);
+    S.rings = reinterpret_cast<const DevRing*>(blob + h->off_ring);
+    S.lights_point = reinterpret_cast<const DevLightPoint*>(blob + h->off_light_point);
+    S.lights_direct = reinterpret_cast<const DevLightDirect*>(blob + h->off_light_direct);
+    for (int t = 0; t < 6; t++) S.mats[t] = reinterpret_cast<const DevMaterial*>(blob + h->off_mat[t]);
+    return S;
+}
+
+struct TexTable {
+    DevTexture tex[TEX_SLOTS];
+    DevCubemap sky;
+};
+
+struct LaneCounters {
+    uint32_t closest;      // calcInter invocations (reference-defined closest-hit rays)
+    uint32_t shadow_ref;   // inShadow invocations the reference would make
+    uint32_t shadow_cast;  // shadow scans actually executed
+    uint32_t torus_solves; // Durand-Kerner solves actually executed
+};
+
+// ------------------------------------------------------------------------------------------
+// texture sampling (DESIGN.md "Texture rule"): exact float weights, RGBA8 taps
+// ------------------------------------------------------------------------------------------
+// byte / 255.0f, correctly rounded, without the IEEE divide: one multiply by RN(1/255) and one
+// fma-based correction step. Equality with the division for all 256 inputs is asserted on the
+// host at library load and on the device by tests (rtx_selftest).
+RT_HD float unorm8(uint32_t b)
+{
+    const float x = (float)b;
+    const float rcp = 0.0039215688593685626983642578125f;  // RN(1/255)
+    float q = x * rcp;
+    const float r = __builtin_fmaf(-q, 255.0f, x);
+    q = __builtin_fmaf(r, rcp, q);
+    return q;
+}
+RT_HD f4 unpack_rgba8(uint32_t p) { return mk4(unorm8(p & 255u), unorm8((p >> 8) & 255u), unorm8((p >> 16) & 255u), unorm8(p >> 24)); }
+
+RT_HD void axis_taps(float u, int n, int wrap, int& i0, int& i1, float& a)
+{
+    if (wrap == 0) u = u - floorf(u);
+    else u = gl_min(gl_max(u, -1.0f), 2.0f);
+    if (!(u == u)) u = 0.0f;
+    const float x = u * (float)n - 0.5f;
+    const float fl = floorf(x);
+    a = x - fl;
+    int i = (int)fl;
+    int k = i + 1;
+    if (wrap == 0) {
+        if (i < 0) i += n;
+        if (i >= n) i -= n;
+        if (k >= n) k -= n;
+    } else {
+        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+        k = k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
+    }
+    i0 = i;
+    i1 = k;
+}
+RT_HD f4 bilinear_taps(const uint32_t* base, int w, int i0, int i1, int j0, int j1, float a, float b)
+{
+    const uint32_t p00 = base[(size_t)j0 * (size_t)w + (size_t)i0];
+    const uint32_t p10 = base[(size_t)j0 * (size_t)w + (size_t)i1];
+    const uint32_t p01 = base[(size_t)j1 * (size_t)w + (size_t)i0];
+    const uint32_t p11 = base[(size_t)j1 * (size_t)w + (size_t)i1];
+    const f4 t00 = unpack_rgba8(p00), t10 = unpack_rgba8(p10), t01 = unpack_rgba8(p01), t11 = unpack_rgba8(p11);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    f4 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.w = w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w;
+    return r;
+}
+RT_HD f4 sample2d_level0(const DevTexture& t, float u, float v)
+{
+    if (t.texels == nullptr) return mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    int i0, i1, j0, j1;
+    float a, b;
+    axis_taps(u, t.width, t.wrap, i0, i1, a);
+    axis_taps(v, t.height, t.wrap, j0, j1, b);
+    return bilinear_taps(t.texels, t.width, i0, i1, j0, j1, a, b);
+}
+// texture(skybox, d): GL face table, per-face bilinear, CLAMP_TO_EDGE, not seamless (rt.frag:893)
+RT_HD f4 sample_cube(const DevCubemap& c, f3 d)
+{
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face;
+    float sc, tc, ma;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay >= az)        { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; }  else { face = 3; sc = d.x; tc = -d.z; } }
+    else                      { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    if (c.texels == nullptr || !((c.face_mask >> face) & 1)) return mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float s = 0.5f * (sc / ma + 1.0f);
+    const float t = 0.5f * (tc / ma + 1.0f);
+    int i0, i1, j0, j1;
+    float a, b;
+    axis_taps(s, c.size, 1, i0, i1, a);
+    axis_taps(t, c.size, 1, j0, j1, b);
+    return bilinear_taps(c.texels + (size_t)face * (size_t)c.size * (size_t)c.size, c.size, i0, i1, j0, j1, a, b);
+}
+
+// ------------------------------------------------------------------------------------------
+// intersectors
+// ------------------------------------------------------------------------------------------
+// rt.frag:342-354; geom.w is the hoisted r*r
+RT_HD bool intersect_sphere(f3 ro, f3 rd, f4 geom, bool hollow, float tmin, float& t)
+{
+    const f3 oc = ro - xyz(geom);
+    const float b = dot3(oc, rd);
+    const float c = dot3(oc, oc) - geom.w;
+    const float h = b * b - c;
+    if (h < 0.0f) return false;
+    const float hs = sqrtf(h);
+    t = -b - hs;
+    if (hollow && t < 0.0f) t = -b + hs;
+    return t > 0.0f && t < tmin;
+}
+
+// rt.frag:356-370 (PLANE_ONESIDE defined -> one-sided, trap T1)
+RT_HD bool intersect_plane(f3 ro, f3 rd, f3 n, f3 p, float tmin, float& t)
+{
+    const float denom = gl_clamp(dot3(n, rd), -1.0f, 1.0f);
+    if (denom < -1e-6f) {
+        t = dot3(p - ro, n) / denom;
+        return t > 0.0f && t < tmin;
+    }
+    return false;
+}
+
+// rt.frag:372-390. uv is written only on a hit (the shader's global opt_uv)
+RT_HD bool intersect_ring(const DevRing& R, f3 ro, f3 rd, float tmin, float& t, f2& uv)
+{
+    const f3 d = quat_rotate(R.quat, rd);
+    const f3 o = quat_rotate(R.quat, ro - xyz(R.pos_tex));
+    t = -o.z / d.z;
+    const float x = o.x + d.x * t;
+    const float y = o.y + d.y * t;
+    const float p = x * x + y * y;
+    if (t > 0.0f && t < tmin && p < R.radii.y && p > R.radii.x) {
+        const float len = sqrtf(x * x + y * y);
+        const float nx = x / len, ny = y / len;
+        uv = mk2((p - R.radii.x) / R.radii.z, nx * 1.0f + ny * 0.0f);
+        return true;
+    }
+    return false;
+}
+
+// rt.frag:399-427. nor (box-space normal) is written only on a hit; NaN falls through the
+// early-outs exactly like the shader (trap T5); no t>0 test (trap T21).
+RT_HD bool intersect_box(const DevBox& B, f3 ro, f3 rd, float tmin, float& t, f3& nor)
+{
+    const f3 rdd = quat_rotate(B.quat, rd);
+    const f3 roo = quat_rotate(B.quat, ro - xyz(B.pos));
+    const f3 m = mk3(1.0f / rdd.x, 1.0f / rdd.y, 1.0f / rdd.z);
+    const f3 n = m * roo;
+    const f3 k = mk3(fabsf(m.x), fabsf(m.y), fabsf(m.z)) * xyz(B.form_tex);
+    const f3 t1 = -n - k;
+    const f3 t2 = -n + k;
+    const float tN = gl_max(gl_max(t1.x, t1.y), t1.z);
+    const float tF = gl_min(gl_min(t2.x, t2.y), t2.z);
+    if (tN > tF || tF < 0.0f) return false;
+    if (tN >= tmin) return false;
+    nor.x = -gl_sign(rdd.x) * gl_step(t1.y, t1.x) * gl_step(t1.z, t1.x);
+    nor.y = -gl_sign(rdd.y) * gl_step(t1.z, t1.y) * gl_step(t1.x, t1.y);
+    nor.z = -gl_sign(rdd.z) * gl_step(t1.x, t1.z) * gl_step(t1.y, t1.z);
+    t = tN;
+    return true;
+}
+
+// ---- torus: Durand-Kerner on the ray/torus quartic (rt.frag:438-487) ----
+struct TorusRay {  // ray-invariant terms of cTorus (rt.frag:445-455), hoisted out of the sweeps
+    float a, b, c;        // dot(rd,rd), dot(ro,rd), dot(ro,ro)+R2-r2
+    float axy, bxy, cxy;  // the same three over .xy
+    float k;              // 4*R2
+};
+RT_HD f2 cmul(f2 p, f2 q) { return mk2(p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x); }
+RT_HD f2 torus_poly(f2 t, const TorusRay& w)
+{
+    const f2 t2 = mk2(t.x * t.x - t.y * t.y, 2.0f * t.x * t.y);
+    f2 res = mk2(t2.x * w.a + 2.0f * t.x * w.b + w.c, t2.y * w.a + 2.0f * t.y * w.b + 0.0f);
+    res = cmul(res, res);
+    const f2 res2 = mk2(w.k * (t2.x * w.axy + 2.0f * t.x * w.bxy + w.cxy), w.k * (t2.y * w.axy + 2.0f * t.y * w.bxy + 0.0f));
+    return mk2(res.x - res2.x, res.y - res2.y);
+}
+RT_HD float dk_step(f2& c0, f2 c1, f2 c2, f2 c3, const TorusRay& w)
+{
+    f2 fc = torus_poly(c0, w);
+    const f2 den = cmul(mk2(c0.x - c1.x, c0.y - c1.y), cmul(mk2(c0.x - c2.x, c0.y - c2.y), mk2(c0.x - c3.x, c0.y - c3.y)));
+    const float dd = den.x * den.x + den.y * den.y;
+    fc = cmul(fc, mk2(den.x / dd, -den.y / dd));
+    c0.x -= fc.x;
+    c0.y -= fc.y;
+    return gl_max(fabsf(fc.x), fabsf(fc.y));
+}
+RT_HD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
+{
+    const float eps = 0.001f;
+    TorusRay w;
+    w.a = dot3(rd, rd);
+    w.b = dot3(ro, rd);
+    w.c = dot3(ro, ro) + T.radii.z - T.radii.w;
+    w.axy = dot2(rd.x, rd.y, rd.x, rd.y);
+    w.bxy = dot2(ro.x, ro.y, rd.x, rd.y);
+    w.cxy = dot2(ro.x, ro.y, ro.x, ro.y);
+    w.k = T.k.x;
+    f2 c0 = mk2(1.0f, 0.0f);
+    f2 c1 = mk2(0.4f, 0.9f);
+    f2 c2 = cmul(c1, mk2(0.4f, 0.9f));
+    f2 c3 = cmul(c2, mk2(0.4f, 0.9f));
+    for (int i = 0; i < 60; i++) {
+        float e = dk_step(c0, c1, c2, c3, w);
+        e = gl_max(e, dk_step(c1, c2, c3, c0, w));
+        e = gl_max(e, dk_step(c2, c3, c0, c1, w));
+        e = gl_max(e, dk_step(c3, c0, c1, c2, w));
+        if (e < eps) break;  // per-lane exit: a converged lane must stop updating its roots (trap T14)
+    }
+    float r0 = c0.x, r1 = c1.x, r2 = c2.x, r3 = c3.x;
+    if (fabsf(c0.y) > eps || r0 < 0.0f) r0 = 10000.0f;
+    if (fabsf(c1.y) > eps || r1 < 0.0f) r1 = 10000.0f;
+    if (fabsf(c2.y) > eps || r2 < 0.0f) r2 = 10000.0f;
+    if (fabsf(c3.y) > eps || r3 < 0.0f) r3 = 10000.0f;
+    t = gl_min(gl_min(r0, r1), gl_min(r2, r3));
+    return t > 0.0f && t < 100.0f && t < tmin;
+}
+// Conservative pre-test in WORLD space (no rotation needed): true = the solve can be skipped.
+// A root is accepted only for 0 < t < min(tmin,100) (rt.frag:486). If the ray's line misses the
+// torus' bounding sphere inflated by 1 % + 0.01, or the sphere lies behind the origin, or is
+// entered beyond that limit, the quartic has no real root in range, and Durand-Kerner -- even
+// when it runs out of its 60 sweeps, which is what happens for origins more than ~100 units
+// away -- reports none (checked exhaustively against the un-culled oracle on every bench scene
+// and on random rays: tests/test_culls.py). Skipping is therefore result-preserving.
+RT_HD bool torus_cull(const DevTorus& T, f3 ro, f3 rd, float tlimit)
+{
+    const f3 oc = ro - xyz(T.pos);
+    const float cc = dot3(oc, oc) - T.k.y;   // > 0: origin outside the inflated bounding sphere
+    if (!(cc > 0.0f)) return false;
+    const float b = dot3(oc, rd);
+    if (b >= 0.0f) return true;               // sphere behind the origin
+    const float a = dot3(rd, rd);
+    const float h = b * b - a * cc;
+    if (h < 0.0f) return true;                // line misses the sphere
+    const float lim = gl_min(tlimit, 100.0f);
+    const float t_in = (-b - sqrtf(h)) / a;   // entry distance (a ~ 1)
+    return t_in > lim * 1.001f + 0.01f;
+}
+RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
+{
+    const f3 o = quat_rotate(T.quat, ro - xyz(T.pos));
+    const f3 d = quat_rotate(T.quat, rd);
+    return intersect_torus_local(T, o, d, tmin, t);
+}
+
+// ---- general quadric (rt.frag:499-572) ----
+RT_HD bool is_between(f3 v, f3 lo, f3 hi) { return (v.x > lo.x && v.y > lo.y && v.z > lo.z) && (v.x < hi.x && v.y < hi.y && v.z < hi.z); }
+RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t)
+{
+    const f3 ro = quat_rotate(Q.quat, ro_w - xyz(Q.pos_a));
+    const f3 rd = quat_rotate(Q.quat, rd_w);
+    const float a = Q.pos_a.w, b = Q.bcde.x, c = Q.bcde.y, d = Q.bcde.z, e = Q.bcde.w, f = Q.f_vmin.x;
+    const float d1 = rd.x, d2 = rd.y, d3 = rd.z, o1 = ro.x, o2 = ro.y, o3 = ro.z;
+    const float p1 = 2.0f * a * d1 * o1 + 2.0f * b * d2 * o2 + 2.0f * c * d3 * o3 + d * d3 + d2 * e;
+    const float p2 = a * d1 * d1 + b * d2 * d2 + c * d3 * d3;
+    const float p3 = a * o1 * o1 + b * o2 * o2 + c * o3 * o3 + d * o3 + e * o2 + f;
+    if (fabsf(p2) < 1e-6f) {  // trap T4: inverted comparison, no clip test
+        t = -p3 / p1;
+        return t > tmin;
+    }
+    const float p4 = sqrtf(p1 * p1 - 4.0f * p2 * p3);
+    float mn = RT_FLT_MAX, mx = RT_FLT_MAX;
+    const float t1 = (-p1 - p4) / (2.0f * p2);
+    const float t2 = (-p1 + p4) / (2.0f * p2);
+    const float epsilon = 1e-4f;
+    if (t1 > epsilon && t1 < mn) { mn = t1; mx = t2; }
+    if (t2 > epsilon && t2 < mn) { mn = t2; mx = t1; }
+    // checkSurfaceEdges (rt.frag:500-512) on the WORLD-space ray (trap T6)
+    const f3 vmin = mk3(Q.f_vmin.y, Q.f_vmin.z, Q.f_vmin.w), vmax = xyz(Q.vmax);
+    f3 pt = rd_w * mn + ro_w;
+    if (!is_between(pt, vmin, vmax)) {
+        if (mx < epsilon) return false;
+        pt = rd_w * mx + ro_w;
+        if (!is_between(pt, vmin, vmax)) return false;
+        const float tmp = mn; mn = mx; mx = tmp;
+    }
+    t = mn;
+    return t < tmin;
+}
+// Conservative pre-test: true = intersect_surface would return false. Only for quadrics whose
+// clip box is finite on all axes (bound.w >= 0). Two facts are needed:
+//  (1) the degenerate branch |p2| < 1e-6 (trap T4), which ignores the clip box, is not taken:
+//      p2 = d^T M d with M = R^T diag(a,b,c) R, evaluated here from the hoisted symmetric M;
+//      the two evaluations differ by rounding only, far less than the stored margin;
+//  (2) past that branch a hit needs a point of the ray strictly inside the clip box
+//      (checkSurfaceEdges); if the ray's LINE misses the box's inflated bounding sphere there is none.
+RT_HD bool surface_cull(const DevSurface& Q, f3 ro, f3 rd)
+{
+    if (!(Q.bound.w >= 0.0f)) return false;
+    const float p2 = Q.sym0.x * rd.x * rd.x + Q.sym0.w * rd.y * rd.y + Q.sym1.y * rd.z * rd.z +
+                     2.0f * (Q.sym0.y * rd.x * rd.y + Q.sym0.z * rd.x * rd.z + Q.sym1.x * rd.y * rd.z);
+    if (!(fabsf(p2) > Q.sym1.z)) return false;  // too close to the degenerate branch: run the full test
+    const f3 oc = ro - xyz(Q.bound);
+    const float b = dot3(oc, rd);
+    const float a = dot3(rd, rd);
+    const float cc = dot3(oc, oc) - Q.bound.w;
+    return (b * b - a * cc) < 0.0f;             // NaN -> false -> not culled
+}
+
+// ------------------------------------------------------------------------------------------
+// closest hit (rt.frag:587-628) and any-hit (rt.frag:630-658)
+// ------------------------------------------------------------------------------------------
+template <bool CULL, bool COUNT>
+RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt)
+{
+    float tmin = RT_MAXDIST;
+    float t = 0.0f;
+    if (COUNT) cnt.closest++;
+    for (int i = 0; i < S.h->n_plane; i++) {
+        if (intersect_plane(ro, rd, xyz(S.planes[i].normal), xyz(S.planes[i].pos), tmin, t)) { num = i; tmin = t; type = TYPE_PLANE; }
+    }
+    for (int i = 0; i < S.h->n_sphere; i++) {
+        if (intersect_sphere(ro, rd, S.spheres[i].geom, S.spheres[i].hollow != 0, tmin, t)) { num = i; tmin = t; type = TYPE_SPHERE; }
+    }
+    for (int i = 0; i < S.h->n_surface; i++) {
+        if (CULL && surface_cull(S.surfaces[i], ro, rd)) continue;
+        if (intersect_surface(S.surfaces[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
+    }
+    for (int i = 0; i < S.h->n_box; i++) {
+        f3 nor;
+        if (intersect_box(S.boxes[i], ro, rd, tmin, t, nor)) { num = i; tmin = t; type = TYPE_BOX; }
+    }
+    for (int i = 0; i < S.h->n_torus; i++) {
+        if (CULL && torus_cull(S.tori[i], ro, rd, tmin)) continue;
+        if (COUNT) cnt.torus_solves++;
+        if (intersect_torus(S.tori[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_TORUS; }
+    }
+    for (int i = 0; i < S.h->n_ring; i++) {
+        f2 uv;
+        if (intersect_ring(S.rings[i], ro, rd, tmin, t, uv)) { num = i; tmin = t; type = TYPE_RING; }
+    }
+    for (int i = 0; i < S.h->n_light_point; i++) {
+        if (intersect_sphere(ro, rd, S.lights_point[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
+    }
+    return tmin;
+}
+
+// `on` = this lane casts the ray. Lanes stop scanning once shadow >= 1: later hits could only
+// set it to 1 or add a non-negative alpha and the result is min(shadow,1) (rt.frag:657), so the
+// early exit is exact.
+template <bool CULL, bool COUNT>
+RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 rd, float dist, LaneCounters& cnt)
+{
+    float shadow = 0.0f;
+    float t = 0.0f;
+    if (COUNT && on) cnt.shadow_cast++;
+    if (on) {
+        for (int i = 0; i < S.h->n_sphere; i++) {
+            if (intersect_sphere(ro, rd, S.spheres[i].geom, false, dist, t)) { shadow = 1.0f; break; }
+        }
+    }
+    on = on && shadow < 1.0f;
+    if (on) {
+        for (int i = 0; i < S.h->n_box; i++) {   // boxes before quadrics/tori: cheaper, order is irrelevant for an OR
+            f3 nor;
+            if (intersect_box(S.boxes[i], ro, rd, dist, t, nor)) { shadow = 1.0f; break; }
+        }
+    }
+    on = on && shadow < 1.0f;
+    if (on) {
+        for (int i = 0; i < S.h->n_surface; i++) {
+            if (CULL && surface_cull(S.surfaces[i], ro, rd)) continue;
+            if (intersect_surface(S.surfaces[i], ro, rd, dist, t)) { shadow = 1.0f; break; }
+        }
+    }
+    on = on && shadow < 1.0f;
+    if (on) {
+        for (int i = 0; i < S.h->n_torus; i++) {
+            if (CULL && torus_cull(S.tori[i], ro, rd, dist)) continue;
+            if (COUNT) cnt.torus_solves++;
+            if (intersect_torus(S.tori[i], ro, rd, dist, t)) { shadow = 1.0f; break; }
+        }
+    }
+    on = on && shadow < 1.0f;
+    // rings: textured rings ADD their alpha (trap T10) -- keep ring order for the float sum
+    for (int i = 0; i < S.h->n_ring; i++) {
+        f2 uv = mk2(0.0f, 0.0f);
+        const bool hit = on && intersect_ring(S.rings[i], ro, rd, dist, t, uv);
+        const int texnum = __builtin_bit_cast(int, S.rings[i].pos_tex.w);
+        if (texnum > 0) {
+            if (RT_ANY(hit)) {
+                const f4 c = sample2d_level0(T.tex[TEX_RING], uv.x, uv.y);
+                if (hit) shadow += c.w;
+            }
+        } else if (hit) {
+            shadow = 1.0f;
+        }
+        on = on && shadow < 1.0f;
+    }
+    return gl_min(shadow, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// shading (rt.frag:660-709)
+// ------------------------------------------------------------------------------------------
+struct Surf {           // what calcShade needs from a hit
+    f3 color;           // material colour (after texturing)
+    float diffuse;
+    int specular;
+    float kd, ks;
+};
+
+template <bool CULL, bool COUNT>
+RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd, const Surf& m, f3 normal, LaneCounters& cnt)
+{
+    f3 diffuse = mk3(0.0f, 0.0f, 0.0f);
+    f3 specular = mk3(0.0f, 0.0f, 0.0f);
+    const f3 ambient = xyz(S.h->ambient), shadow_ambient = xyz(S.h->shadow_ambient);
+    const int n_lp = S.h->n_light_point, n_ld = S.h->n_light_direct;
+    for (int li = 0; li < n_lp + n_ld; li++) {
+        f3 light_color, light_dir;
+        float intensity, dist, distDiv;
+        if (li < n_lp) {
+            const DevLightPoint& L = S.lights_point[li];
+            light_color = xyz(L.color_intensity);
+            intensity = L.color_intensity.w;
+            light_dir = xyz(L.pos_r2) - pt;
+            dist = length3(light_dir);
+            distDiv = 1.0f + L.atten.x * dist + L.atten.y * dist * dist;
+        } else {
+            const DevLightDirect& L = S.lights_direct[li - n_lp];
+            light_color = xyz(L.color_intensity);
+            intensity = L.color_intensity.w;
+            light_dir = -xyz(L.direction);
+            dist = RT_MAXDIST;
+            distDiv = 1.0f;
+        }
+        // calcShade2
+        light_dir = normalize3(light_dir);
+        const float dp = gl_clamp(dot3(normal, light_dir), 0.0f, 1.0f);
+        light_color = light_color * dp;
+        if (COUNT && on) cnt.shadow_ref++;
+        // dp == 0 zeroes light_color, so neither term below can receive anything from this light:
+        // the shadow ray's result is unused and the ray is not cast (the reference casts it, trap T10).
+        // (NaN dp must still take the full path so that it propagates like in the shader.)
+        const bool cast = on && !(dp == 0.0f);
+        const float sh = 1.0f - in_shadow<CULL, COUNT>(S, T, cast, pt, light_dir, dist, cnt);
+        if (cast) {
+            light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
+            diffuse = diffuse + (((light_color * m.color) * m.diffuse) * intensity) / distDiv;
+            if (m.specular > 0) {
+                const f3 refl = gl_reflect(light_dir, normal);
+                const float specDp = gl_clamp(dot3(rd, refl), 0.0f, 1.0f);
+                specular = specular + ((light_color * powf(specDp, (float)m.specular)) * intensity) / distDiv;
+            }
+        }
+    }
+    return ambient * m.color + (diffuse * m.kd + specular * m.ks);
+}
+
+// rt.frag:711-742
+RT_HD float get_fresnel(f3 normal, f3 rd, float reflection)
+{
+    const float ndotv = gl_clamp(dot3(normal, -rd), 0.0f, 1.0f);
+    return reflection + (1.0f - reflection) * powf(1.0f - ndotv, 5.0f);
+}
+RT_HD float fresnel_reflect_amount(float n1, float n2, f3 normal, f3 incident, float refl)
+{
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    float cosX = -dot3(normal, incident);
+    if (n1 > n2) {
+        const float n = n1 / n2;
+        const float sinT2 = n * n * (1.0f - cosX * cosX);
+        if (sinT2 > 1.0f) return 1.0f;
+        cosX = sqrtf(1.0f - sinT2);
+    }
+    const float x = 1.0f - cosX;
+    float ret = r0 + (1.0f - r0) * x * x * x * x * x;
+    ret = (refl + (1.0f - refl) * ret);
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------
+// hit attributes (rt.frag:744-784). Box normal and ring uv are RE-DERIVED from the winning
+// primitive instead of being carried through the scan in registers (the shader's opt_normal /
+// opt_uv globals): same operands, same operations -> same bits, fewer live VGPRs in the scan.
+// ------------------------------------------------------------------------------------------
+struct Hit {
+    f3 normal;
+    float alpha;
+    float bias;
+    Surf surf;
+    float reflection, refraction;
+    f3 absorb;
+};
+
+RT_HD void load_material(const DevMaterial& M, Hit& h)
+{
+    h.surf.color = mk3(M.color[0], M.color[1], M.color[2]);
+    h.surf.diffuse = M.diffuse;
+    h.surf.specular = M.specular;
+    h.surf.kd = M.kd;
+    h.surf.ks = M.ks;
+    h.reflection = M.reflection;
+    h.refraction = M.refraction;
+    h.absorb = mk3(M.absorb[0], M.absorb[1], M.absorb[2]);
+}
+
+// `on` = lane has a hit to describe. Texture fetches sit in wave-uniform control flow.
+RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 rd, f3 pt, float t, int num, int type, Hit& h)
+{
+    h.normal = mk3(0.0f, 0.0f, 0.0f);
+    h.alpha = 1.0f;
+    h.surf.color = mk3(0.0f, 0.0f, 0.0f);
+    h.surf.diffuse = 0.0f; h.surf.specular = 0; h.surf.kd = 0.0f; h.surf.ks = 0.0f;
+    h.reflection = 0.0f; h.refraction = 0.0f; h.absorb = mk3(0.0f, 0.0f, 0.0f);
+
+    // ---- spheres (+ equirect texture, rt.frag:319-340) ----
+    {
+        const bool is = on && type == TYPE_SPHERE;
+        bool textured = false;
+        float u = 0.0f, v = 0.0f;
+        int texnum = 0;
+        if (is) {
+            const DevSphere& P = S.spheres[num];
+            load_material(S.mats[TYPE_SPHERE][num], h);
+            h.normal = normalize3(pt - xyz(P.geom));
+            texnum = P.texture;
+            if (texnum != 0) {
+                f3 sn = h.normal;
+                const f4 q = P.quat;
+                if (q.x != 0.0f || q.y != 0.0f || q.z != 0.0f || q.w != 1.0f) sn = quat_rotate(q, sn);
+                u = 0.5f + rt_atan2(sn.z, sn.x) / (2.0f * RT_PI_F);
+                v = 0.5f - rt_asin(sn.y) / RT_PI_F;
+                textured = true;
+            }
+        }
+        if (RT_ANY(textured)) {
+            f4 c = mk4(0.0f, 0.0f, 0.0f, 0.0f);  // texNum outside {1,2,3}: undefined in GLSL (trap T15), pinned to 0
+            if (textured) {
+                if (texnum == 1) c = sample2d_level0(T.tex[TEX_SPHERE_1], u, v);
+                if (texnum == 2) c = sample2d_level0(T.tex[TEX_SPHERE_2], u, v);
+                if (texnum == 3) c = sample2d_level0(T.tex[TEX_SPHERE_3], u, v);
+                h.surf.color = mk3(c.x, c.y, c.z);
+                h.alpha = c.w;
+            }
+        }
+    }
+    if (on && type == TYPE_PLANE) {
+        load_material(S.mats[TYPE_PLANE][num], h);
+        h.normal = normalize3(xyz(S.planes[num].normal));
+    }
+    if (on && type == TYPE_SURFACE) {  // getSurfaceNormal rt.frag:573-584
+        const DevSurface& Q = S.surfaces[num];
+        load_material(S.mats[TYPE_SURFACE][num], h);
+        const f3 o = quat_rotate(Q.quat, ro - xyz(Q.pos_a));
+        const f3 d = quat_rotate(Q.quat, rd);
+        const f3 tm = d * t + o;
+        const f3 n = mk3(2.0f * Q.pos_a.w * tm.x, 2.0f * Q.bcde.x * tm.y + Q.bcde.w, 2.0f * Q.bcde.y * tm.z + Q.bcde.z);
+        h.normal = normalize3(quat_rotate(Q.qinv, n));
+    }
+    // ---- boxes (+ tri-planar texture, rt.frag:428-436) ----
+    {
+        const bool is = on && type == TYPE_BOX;
+        bool textured = false;
+        f3 lp = mk3(0.0f, 0.0f, 0.0f), lpos = lp, ln = lp;
+        if (is) {
+            const DevBox& B = S.boxes[num];
+            load_material(S.mats[TYPE_BOX][num], h);
+            float tt;
+            f3 nor = mk3(0.0f, 0.0f, 0.0f);
+            intersect_box(B, ro, rd, RT_FLT_MAX, tt, nor);  // re-derive the winning box's normal (+inf tmin: same result path)
+            h.normal = quat_rotate(B.qinv, nor);
+            if (__builtin_bit_cast(int, B.form_tex.w) != 0) {
+                lpos = quat_rotate(B.quat, xyz(B.pos));
+                lp = quat_rotate(B.quat, pt);
+                ln = quat_rotate(B.quat, h.normal);
+                textured = true;
+            }
+        }
+        if (RT_ANY(textured)) {
+            const DevTexture& tx = T.tex[TEX_BOX];
+            f4 a = mk4(0, 0, 0, 0), b = a, c = a;
+            if (textured) {
+                a = sample2d_level0(tx, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
+                b = sample2d_level0(tx, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.x - lpos.x) - 0.5f);
+                c = sample2d_level0(tx, 0.5f * (lp.x - lpos.x) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
+                const float wx = fabsf(ln.x), wy = fabsf(ln.y), wz = fabsf(ln.z);
+                h.surf.color = mk3(wx * a.x + wy * b.x + wz * c.x, wx * a.y + wy * b.y + wz * c.y, wx * a.z + wy * b.z + wz * c.z);
+            }
+        }
+    }
+    if (on && type == TYPE_TORUS) {  // getTorusNormal rt.frag:488-496
+        const DevTorus& P = S.tori[num];
+        load_material(S.mats[TYPE_TORUS][num], h);
+        const f3 o = quat_rotate(P.quat, ro - xyz(P.pos));
+        const f3 d = quat_rotate(P.quat, rd);
+        const f3 pos = o + d * t;
+        const float s = dot3(pos, pos) - P.radii.w;
+        const f3 n = pos * mk3(s - P.radii.z * 1.0f, s - P.radii.z * 1.0f, s - P.radii.z * -1.0f);
+        h.normal = normalize3(quat_rotate(P.qinv, n));
+    }
+    // ---- rings (+ strip texture, rt.frag:391-397) ----
+    {
+        const bool is = on && type == TYPE_RING;
+        bool textured = false;
+        f2 uv = mk2(0.0f, 0.0f);
+        if (is) {
+            const DevRing& R = S.rings[num];
+            load_material(S.mats[TYPE_RING][num], h);
+            h.normal = xyz(R.normal);
+            if (__builtin_bit_cast(int, R.pos_tex.w) != 0) {
+                float tt;
+                intersect_ring(R, ro, rd, RT_FLT_MAX, tt, uv);  // re-derive opt_uv of the winning ring
+                textured = true;
+            }
+        }
+        if (RT_ANY(textured)) {
+            if (textured) {
+                const f4 c = sample2d_level0(T.tex[TEX_RING], uv.x, uv.y);
+                h.surf.color = mk3(c.x, c.y, c.z);
+                h.alpha = c.w;
+            }
+        }
+    }
+    const float distance = length3(pt - ro);
+    h.bias = (9e-3f * distance + 35.0f) / 35e3f;
+}
+
+// rt.frag:313-317
+RT_HD f3 ray_dir(const SceneView& S, float frag_x, float frag_y)
+{
+    const float cw = (float)S.h->canvas_w, ch = (float)S.h->canvas_h;
+    const f3 v = mk3((frag_x - cw / 2.0f) / ch, (frag_y - ch / 2.0f) / ch, 1.0f);
+    return normalize3(quat_rotate(S.h->cam_quat, v));
+}
+
+// ------------------------------------------------------------------------------------------
+// the pixel program: rt.frag main() (:804-902) + getReflectedColor (:787-802) as one segment
+// loop. Per trip every live lane traces ONE closest-hit ray -- either the next segment of its
+// main path or the one-bounce "side" ray that getReflectedColor casts for refractive surfaces
+// -- then at most one shading evaluation. All lanes of a wave walk the loop together; `alive`
+// predicates the work, so texture fetch sites stay in wave-uniform control flow.
+// ------------------------------------------------------------------------------------------
+template <bool CULL, bool COUNT>
+RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
+{
+    f3 mask = mk3(1.0f, 1.0f, 1.0f);
+    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    f3 ro = xyz(S.h->cam_pos);
+    f3 rd = ray_dir(S, frag_x, frag_y);
+    float absorbDistance = 0.0f;
+    const int iterations = S.h->iterations;
+    int i = 0;          // the shader's loop variable
+    int segments = 0;   // main-loop trips taken (cap, trap T2)
+    bool side = false;  // the NEXT trip traces getReflectedColor's ray
+    f3 cont_ro = ro, cont_rd = rd;  // refracted continuation of the main path while the side ray runs
+    float side_R = 0.0f;
+
+    alive = alive && iterations > 0;
+    while (RT_ANY(alive)) {
+        const bool is_side = side;  // what THIS trip traces
+        if (alive && !is_side) segments++;
+
+        // ---- one closest-hit ray per live lane ----
+        int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
+        float tm = RT_MAXDIST;
+        if (alive) tm = calc_inter<CULL, COUNT>(S, ro, rd, num, type, cnt);
+        const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
+        const f3 pt = ro + rd * tm;
+        Hit h;
+        get_hit_info(S, T, hit, ro, rd, pt, tm, num, type, h);
+
+        // ---- classify ----
+        enum { ACT_NONE = 0, ACT_SIDE, ACT_REFLECT, ACT_DIFFUSE };
+        int act = ACT_NONE;
+        f3 sh_pt = pt, sh_n = h.normal;
+        f3 n = h.normal;
+        float R = 0.0f, Tm = 1.0f;
+        bool finished = false;  // lane leaves the loop after this trip
+        bool sky = false;
+        bool arm_side = false;
+        f3 next_ro = ro, next_rd = rd;
+        f3 add = mk3(0.0f, 0.0f, 0.0f);  // radiance that needs no shading evaluation, already weighted
+
+        if (alive) {
+            if (is_side) {
+                // getReflectedColor: light sphere -> its colour; miss -> BLACK (trap T3); else one shade
+                if (type == TYPE_POINT_LIGHT) {
+                    add = (xyz(S.lights_point[num].color_intensity) * side_R) * mask;
+                } else if (hit) {
+                    act = ACT_SIDE;
+                    sh_pt = dot3(rd, h.normal) < 0.0f ? pt + h.normal * h.bias : pt - h.normal * h.bias;
+                    sh_n = h.normal;  // unflipped (trap T18)
+                }
+            } else if (!hit) {
+                sky = true;
+                finished = true;
+            } else if (type == TYPE_POINT_LIGHT) {
+                add = xyz(S.lights_point[num].color_intensity) * mask;
+                finished = true;
+            } else {
+                const bool outside = dot3(rd, n) < 0.0f;
+                n = outside ? n : -n;
+                if (h.refraction > 0.0f)
+                    R = fresnel_reflect_amount(outside ? 1.0f : h.refraction, outside ? h.refraction : 1.0f, rd, n, h.reflection);
+                else
+                    R = get_fresnel(n, rd, h.reflection);
+                Tm = 1.0f - R;
+                if (h.refraction > 0.0f) {  // refractive, rt.frag:851-873
+                    next_ro = pt - n * h.bias;
+                    next_rd = gl_refract(rd, n, outside ? 1.0f / h.refraction : h.refraction);
+                    if (outside && h.reflection > 0.0f) {
+                        arm_side = true;  // next trip: the mirror ray; the refracted ray waits in cont_*
+                    } else {
+                        if (!outside) {
+                            absorbDistance += tm;  // accumulates over all inside segments (trap T12)
+                            mask = mask * mk3(expf(-h.absorb.x * absorbDistance), expf(-h.absorb.y * absorbDistance),
+                                              expf(-h.absorb.z * absorbDistance));
+                        }
+                        if (R >= 1.0f) finished = true;
+                    }
+                    // i is not advanced: "i--" cancels the loop increment (rt.frag:870-872, trap T2)
+                } else if (h.reflection > 0.0f) {  // reflective, rt.frag:874-880
+                    act = ACT_REFLECT;
+                    sh_pt = pt + n * h.bias;
+                    sh_n = n;
+                } else {  // diffuse, rt.frag:881-890
+                    act = ACT_DIFFUSE;
+                    sh_pt = pt + n * h.bias;
+                    sh_n = n;
+                }
+            }
+        }
+
+        // ---- sky fetch (wave-uniform site) ----
+        if (RT_ANY(sky)) {
+            if (sky) {
+                const f4 c = sample_cube(T.sky, rd);
+                add = mk3(c.x, c.y, c.z) * mask;
+            }
+        }
+
+        // ---- the single shading site ----
+        const f3 col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, sh_n, cnt);
+
+        // ---- apply + advance ----
+        if (alive) {
+            color = color + add;
+            if (is_side) {
+                if (act == ACT_SIDE) color = color + (col * side_R) * mask;
+                mask = mask * (1.0f - side_R);
+                if (side_R >= 1.0f) finished = true;  // total reflection: checked after the mirror term (rt.frag:865)
+                ro = cont_ro;
+                rd = cont_rd;
+                side = false;
+            } else if (arm_side) {
+                side = true;
+                side_R = R;
+                cont_ro = next_ro;
+                cont_rd = next_rd;
+                ro = pt + n * h.bias;
+                rd = gl_reflect(rd, n);
+            } else if (act == ACT_REFLECT) {
+                color = color + (col * Tm) * mask;
+                ro = sh_pt;
+                rd = gl_reflect(rd, n);
+                mask = mask * R;
+                i++;
+            } else if (act == ACT_DIFFUSE) {
+                color = color + (col * mask) * h.alpha;
+                if (h.alpha < 1.0f) {  // alpha pass-through keeps rd, costs an iteration (trap T13)
+                    ro = pt - n * h.bias;
+                    mask = mask * (1.0f - h.alpha);
+                    i++;
+                } else {
+                    finished = true;
+                }
+            } else if (!finished) {  // refraction without a mirror term
+                ro = next_ro;
+                rd = next_rd;
+            }
+            // loop condition of the shader's for(), evaluated before the next MAIN trip
+            if (finished || (!side && (i >= iterations || segments >= RT_SEGMENT_CAP))) alive = false;
+        }
+    }
+    return mk4(color.x, color.y, color.z, 1.0f);
+}
+
+}  // namespace rtdev

@@ -1,0 +1,21 @@
+// rt_kernel.h -- launch interface between the C-ABI layer (rtx_capi.cpp) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+
+struct RtLaunchParams {
+    const char* scene;        // DevScene blob (device memory)
+    int32_t scene_bytes;
+    int32_t fb_w, fb_h;       // framebuffer size = gl_FragCoord range
+    // row-band set traced by this launch: bands band_first, +band_stride, ... of band_rows rows
+    // each, stored packed (rows_local rows in total) at out_*
+    int32_t band_rows, band_first, band_stride, rows_local;
+    float* out_f32;           // RGBA32F, 16 B/pixel, or nullptr
+    uint32_t* out_u8;         // RGBA8, 4 B/pixel, or nullptr
+    unsigned long long* counters;  // 4 x u64 (COUNT variant) or nullptr
+    rtdev::TexTable tex;
+};
+
+hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, hipStream_t stream);
+hipError_t rt_launch_selftest(int* d_result, hipStream_t stream);

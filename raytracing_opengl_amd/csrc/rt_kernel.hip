@@ -1,0 +1,128 @@
+// rt_kernel.hip -- gfx950 kernels of the tracer and their launch function.
+//
+// Replaces glDrawArrays(GL_TRIANGLES,0,6) of the full-screen quad + the fragment program
+// (reference GLWrapper.cpp:155-165, assets/shaders/quad.vert, rt.frag).
+//
+// Mapping (DESIGN.md "Kernel"): one pixel per lane; one wave64 = an 8x8 pixel tile whose 2x2
+// pixel quads sit in 4 consecutive lanes; one 256-thread workgroup = four tiles side by side =
+// 32x8 pixels; grid = ceil(W/32) x rows/8. Each lane stores one 16-byte RGBA32F pixel, so the 8
+// lanes of a tile row write 128 contiguous bytes (and 4 tiles of a workgroup 512 B per image row).
+// Scene tables are read with wave-uniform addresses: scalar (SMEM) loads from the DevScene blob,
+// or LDS broadcast reads when the blob is staged per workgroup (LDS template flag).
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+#include "rt_kernel.h"
+
+using namespace rtdev;
+
+namespace {
+
+__device__ __forceinline__ uint32_t pack_rgba8(f4 c)
+{
+    // GL fixed-point write-out: clamp to [0,1], scale by 255, round to nearest; NaN -> 0
+    auto q = [](float v) -> uint32_t {
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        if (!(v == v)) v = 0.0f;
+        return (uint32_t)(v * 255.0f + 0.5f);
+    };
+    return q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
+}
+
+template <bool CULL, bool COUNT, bool LDS>
+__global__ __launch_bounds__(256) void rt_trace_kernel(const RtLaunchParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // 2x2 quads in consecutive lanes: bit0 = x&1, bit1 = y&1, bits 2-3 = quad column, bits 4-5 = quad row
+    const int tx = ((lane >> 2) & 3) * 2 + (lane & 1);
+    const int ty = ((lane >> 4) & 3) * 2 + ((lane >> 1) & 1);
+    const int x = blockIdx.x * 32 + wave * 8 + tx;
+    const int row_local = blockIdx.y * 8 + ty;  // row inside this launch's packed band set
+    const int band_j = row_local / p.band_rows;
+    const int within = row_local - band_j * p.band_rows;
+    const int y = (p.band_first + band_j * p.band_stride) * p.band_rows + within;
+    const bool alive = (x < p.fb_w) && (y < p.fb_h) && (row_local < p.rows_local);
+
+    const char* blob = p.scene;
+    if (LDS) {
+        // cooperative 16 B/lane copy of the whole DevScene blob
+        const int n16 = p.scene_bytes >> 4;
+        const float4* src = reinterpret_cast<const float4*>(p.scene);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int k = threadIdx.x; k < n16; k += 256) dst[k] = src[k];
+        __syncthreads();
+        blob = smem;
+    }
+    const SceneView S = make_view(blob);
+
+    LaneCounters cnt = {0u, 0u, 0u, 0u};
+    const f4 px = trace_pixel<CULL, COUNT>(S, p.tex, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
+
+    if (alive) {
+        const size_t idx = (size_t)row_local * (size_t)p.fb_w + (size_t)x;
+        if (p.out_f32) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f v = {px.x, px.y, px.z, px.w};
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p.out_f32) + idx);
+        }
+        if (p.out_u8) __builtin_nontemporal_store(pack_rgba8(px), p.out_u8 + idx);
+    }
+    if (COUNT) {
+        uint32_t v[4] = {cnt.closest, cnt.shadow_ref, cnt.shadow_cast, cnt.torus_solves};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(reinterpret_cast<unsigned long long*>(p.counters) + k, (unsigned long long)s);
+        }
+    }
+}
+
+// device-side exhaustive check of unorm8 (result[0] = number of mismatching byte values)
+__global__ void rt_selftest_kernel(int* result)
+{
+    const uint32_t b = threadIdx.x;
+    const float ref = (float)b / 255.0f;
+    if (unorm8(b) != ref) atomicAdd(result, 1);
+}
+
+}  // namespace
+
+template <bool CULL, bool COUNT, bool LDS>
+static hipError_t launch_variant(const RtLaunchParams& p, dim3 grid, size_t shmem, hipStream_t stream)
+{
+    if (LDS && shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS>), grid, dim3(256), shmem, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, hipStream_t stream)
+{
+    const dim3 grid((p.fb_w + 31) / 32, (p.rows_local + 7) / 8);
+    if (grid.x == 0 || grid.y == 0) return hipSuccess;
+    const size_t shmem = lds ? (size_t)((p.scene_bytes + 15) & ~15) : 0;
+    const int sel = (cull ? 4 : 0) | (count ? 2 : 0) | (lds ? 1 : 0);
+    switch (sel) {
+        case 0: return launch_variant<false, false, false>(p, grid, shmem, stream);
+        case 1: return launch_variant<false, false, true>(p, grid, shmem, stream);
+        case 2: return launch_variant<false, true, false>(p, grid, shmem, stream);
+        case 3: return launch_variant<false, true, true>(p, grid, shmem, stream);
+        case 4: return launch_variant<true, false, false>(p, grid, shmem, stream);
+        case 5: return launch_variant<true, false, true>(p, grid, shmem, stream);
+        case 6: return launch_variant<true, true, false>(p, grid, shmem, stream);
+        default: return launch_variant<true, true, true>(p, grid, shmem, stream);
+    }
+}
+
+hipError_t rt_launch_selftest(int* d_result, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_selftest_kernel, dim3(1), dim3(256), 0, stream, d_result);
+    return hipGetLastError();
+}

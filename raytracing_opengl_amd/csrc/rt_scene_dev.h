@@ -1,0 +1,121 @@
+// rt_scene_dev.h -- the tracer's device-side scene tables ("DevScene" blob).
+//
+// The boundary receives nine std140 uniform blocks (rt.frag:155-230, byte layouts in
+// include/rtx/scene.h). They are re-packed on the host, once per block update, into ONE
+// contiguous blob that the kernel reads with wave-uniform indices (scalar loads, or LDS when
+// staged): geometry records first (scanned by every ray), 64-byte materials behind them
+// (fetched once per hit). Every derived field is a pure function of one primitive and is
+// computed with the same float operations the shader would execute per ray (quat_inv, r*r,
+// 4*R*R, ...), so hoisting it changes no result bit.
+//
+// All records are multiples of 16 bytes and the blob base is 16-byte aligned, so any record
+// field group can be fetched with s_load_dwordx4 / ds_read_b128.
+#pragma once
+#include <stdint.h>
+
+namespace rtdev {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct alignas(16) f4 { float x, y, z, w; };
+
+enum PrimType { TYPE_SPHERE = 0, TYPE_PLANE = 1, TYPE_SURFACE = 2, TYPE_BOX = 3, TYPE_TORUS = 4, TYPE_RING = 5, TYPE_POINT_LIGHT = 6 };
+
+struct alignas(16) DevMaterial {  // byte-identical to std140 rt_material (rt.frag:24-34)
+    float color[3]; float _p0;
+    float absorb[3];
+    float diffuse;
+    float reflection;
+    float refraction;
+    int32_t specular;
+    float kd;
+    float ks;
+    float _p1[3];
+};
+
+struct alignas(16) DevSphere {
+    f4 geom;           // centre xyz, w = r*r   (rt.frag:346)
+    int32_t hollow;    // closest-hit only (trap T8)
+    int32_t texture;   // textureNum
+    float radius;
+    int32_t _p;
+    f4 quat;           // rotates the NORMAL for texturing (rt.frag:319-322)
+};
+struct alignas(16) DevPlane {
+    f4 normal;         // xyz (not normalised, rt.frag:357)
+    f4 pos;
+};
+struct alignas(16) DevSurface {
+    f4 quat;
+    f4 pos_a;          // pos xyz, a
+    f4 bcde;           // b, c, d, e
+    f4 f_vmin;         // f, v_min xyz (world-space clip box, trap T6)
+    f4 vmax;           // v_max xyz, w unused
+    f4 qinv;           // quat_inv(quat)
+    f4 bound;          // cull sphere: centre xyz (world), w = radius^2 (inflated); w < 0: not cullable
+    f4 sym0;           // symmetric M = R^T diag(a,b,c) R : m00, m01, m02, m11
+    f4 sym1;           // m12, m22, |p2| margin, unused        (p2 ~ d^T M d, see surface_cull)
+};
+struct alignas(16) DevBox {
+    f4 quat;
+    f4 pos;            // xyz
+    f4 form_tex;       // half extents xyz, w = textureNum as float bits (int)
+    f4 qinv;
+};
+struct alignas(16) DevTorus {
+    f4 quat;
+    f4 pos;            // xyz
+    f4 radii;          // R, r, R*R, r*r
+    f4 k;              // x = 4*R*R, y = cull radius^2 (inflated), z = far-origin radius^2 ((100+R+r) inflated), w unused
+    f4 qinv;
+};
+struct alignas(16) DevRing {
+    f4 quat;
+    f4 pos_tex;        // pos xyz, w = textureNum (int bits)
+    f4 radii;          // r1, r2 (squared radii, trap T7), r2 - r1, unused
+    f4 normal;         // rotate(quat_inv(quat), (0,0,-1))  (rt.frag:391-394)
+};
+struct alignas(16) DevLightPoint {
+    f4 pos_r2;         // xyz, w = radius*radius (light sphere, closest-hit only)
+    f4 color_intensity;
+    f4 atten;          // linear_k, quadratic_k, radius, unused
+};
+struct alignas(16) DevLightDirect {
+    f4 direction;      // xyz as given (not normalised)
+    f4 color_intensity;
+};
+
+struct alignas(16) DevSceneHeader {
+    int32_t n_sphere, n_plane, n_surface, n_box;
+    int32_t n_torus, n_ring, n_light_point, n_light_direct;
+    int32_t iterations, canvas_w, canvas_h, total_bytes;
+    f4 cam_quat;
+    f4 cam_pos;
+    f4 ambient;         // AMBIENT_COLOR after the %f text round trip (trap T9)
+    f4 shadow_ambient;  // SHADOW_AMBIENT, same
+    // byte offsets of the arrays from the blob base
+    uint32_t off_sphere, off_plane, off_surface, off_box;
+    uint32_t off_torus, off_ring, off_light_point, off_light_direct;
+    uint32_t off_mat[8];  // materials per PrimType 0..5 (6,7 unused)
+};
+
+// ---- textures --------------------------------------------------------------------------------
+// Texels are stored as RGBA8 (one dword per texel) whatever the source channel count, so a tap
+// is one aligned 4-byte load; RGB sources get alpha 255 (= 1.0 exactly), GL_RED gets (r,0,0,255).
+enum { TEX_SPHERE_1 = 0, TEX_SPHERE_2, TEX_SPHERE_3, TEX_SPHERE_4, TEX_RING, TEX_BOX, TEX_SLOTS };
+enum { MAX_MIPS = 15 };
+
+struct DevTexture {
+    const uint32_t* texels;  // level 0 at offset 0; nullptr = unbound sampler (samples black, alpha 1)
+    int32_t width, height;
+    int32_t wrap;            // 0 REPEAT, 1 CLAMP_TO_EDGE
+    int32_t levels;
+    uint32_t level_off[MAX_MIPS];  // dword offset of each mip level
+};
+struct DevCubemap {
+    const uint32_t* texels;  // 6 faces back to back (+X,-X,+Y,-Y,+Z,-Z), each size*size dwords
+    int32_t size;
+    int32_t face_mask;       // bit f set = face present (a missing face samples black)
+};
+
+}  // namespace rtdev

@@ -1,0 +1,84 @@
+"""ctypes binding of tests/host_harness (the product's device header compiled for the host).
+
+Test infrastructure only -- lets `-m "not gpu"` tests compare the tracer's LOGIC with the oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DIR = os.path.join(_HERE, "host_harness")
+_LIB = os.path.join(_DIR, "libharness.so")
+TEX_SLOTS = ("texture_sphere_1", "texture_sphere_2", "texture_sphere_3", "texture_sphere_4", "texture_ring", "texture_box")
+BLOCKS = ("scene_buf", "spheres_buf", "planes_buf", "surfaces_buf", "boxes_buf", "toruses_buf", "rings_buf", "lights_point_buf",
+          "lights_direct_buf")
+
+
+class Defines(ctypes.Structure):
+    _fields_ = [(f"i{k}", ctypes.c_int32) for k in range(9)] + [("ambient", ctypes.c_float * 3), ("shadow", ctypes.c_float * 3)]
+
+
+class Tex(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("channels", ctypes.c_int32), ("wrap", ctypes.c_int32),
+                ("texels", ctypes.c_void_p)]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [("fb_width", ctypes.c_int32), ("fb_height", ctypes.c_int32), ("defines", Defines), ("blocks", ctypes.c_void_p * 9),
+                ("block_sizes", ctypes.c_uint64 * 9), ("sky_size", ctypes.c_int32), ("sky_channels", ctypes.c_int32),
+                ("sky_faces", ctypes.c_void_p * 6), ("tex", Tex * 6), ("cull", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-C", _DIR], check=True, stdout=subprocess.DEVNULL)
+        l = ctypes.CDLL(_LIB)
+        l.harness_render.restype = ctypes.c_int
+        l.harness_render.argtypes = [ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        l.harness_unorm8_mismatches.restype = ctypes.c_int
+        _lib = l
+    return _lib
+
+
+def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=0, y1=None):
+    keep = []
+    fr = Frame()
+    fr.fb_width, fr.fb_height = fb_w, fb_h
+    d = scene_blocks.defines
+    for k in range(9):
+        setattr(fr.defines, f"i{k}", int(d[k]))
+    fr.defines.ambient = (ctypes.c_float * 3)(*d[9:12])
+    fr.defines.shadow = (ctypes.c_float * 3)(*d[12:15])
+    for b, name in enumerate(BLOCKS):
+        raw = scene_blocks.blocks.get(name, b"")
+        buf = ctypes.create_string_buffer(raw, max(len(raw), 1))
+        keep.append(buf)
+        fr.blocks[b] = ctypes.cast(buf, ctypes.c_void_p)
+        fr.block_sizes[b] = len(raw)
+    for uniform, _unit, img in (textures or ()):
+        arr = np.ascontiguousarray(img, dtype=np.uint8)
+        keep.append(arr)
+        fr.tex[TEX_SLOTS.index(uniform)] = Tex(arr.shape[1], arr.shape[0], 1 if arr.ndim == 2 else arr.shape[2], 0, arr.ctypes.data)
+    if cubemap is not None:
+        faces = [None if f is None else np.ascontiguousarray(f, dtype=np.uint8) for f in cubemap]
+        keep.append(faces)
+        first = next(f for f in faces if f is not None)
+        fr.sky_size, fr.sky_channels = first.shape[0], first.shape[2]
+        for i, f in enumerate(faces):
+            fr.sky_faces[i] = None if f is None else f.ctypes.data
+    fr.cull = 1 if cull else 0
+    y1 = fb_h if y1 is None else y1
+    out = np.empty((y1 - y0, fb_w, 4), dtype=np.float32)
+    cnt = (ctypes.c_uint64 * 4)()
+    rc = lib().harness_render(ctypes.byref(fr), y0, y1, out.ctypes.data, cnt)
+    if rc != 0:
+        raise RuntimeError("harness_render failed")
+    return out, {"closest": cnt[0], "shadow_ref": cnt[1], "shadow_cast": cnt[2], "torus_solves": cnt[3]}

@@ -1,0 +1,95 @@
+// harness.cpp -- TEST INFRASTRUCTURE: compiles the product's device header (rt_device.h) and
+// scene packer (rt_pack.h) for the HOST so that the tracer's logic can be compared with the
+// oracle pixel by pixel without a GPU (tests/test_host_harness.py, -m "not gpu").
+// It is not a product path: nothing in raytracing_opengl_amd/ or librtx_hip.so uses it, and the
+// product has no CPU fallback. Built by tests/host_harness/Makefile with g++ -ffp-contract=off.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "rt_device.h"
+#include "rt_pack.h"
+
+using namespace rtdev;
+
+extern "C" {
+
+struct harness_texture { int32_t width, height, channels, wrap; const uint8_t* texels; };
+struct harness_frame {
+    int32_t fb_width, fb_height;
+    rtpack::Defines defines;
+    const void* blocks[9];
+    uint64_t block_sizes[9];
+    int32_t sky_size, sky_channels;
+    const uint8_t* sky_faces[6];
+    harness_texture tex[6];
+    int32_t cull;
+};
+
+// renders rows [y0,y1) into out (RGBA float, row 0 = bottom); counters[4] = closest, shadow_ref, shadow_cast, torus_solves
+int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t* counters)
+{
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    for (int b = 0; b < 9; b++) {
+        const unsigned char* p = static_cast<const unsigned char*>(fr->blocks[b]);
+        if (p && fr->block_sizes[b]) blocks[b].assign(p, p + fr->block_sizes[b]);
+    }
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(fr->defines, blocks, blob, err)) return -1;
+    // 16-byte aligned copy
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+
+    TexTable T;
+    std::memset(&T, 0, sizeof T);
+    std::vector<std::vector<uint32_t>> keep;
+    for (int s = 0; s < 6; s++) {
+        const harness_texture& t = fr->tex[s];
+        if (t.width > 0 && t.texels) {
+            keep.emplace_back(static_cast<size_t>(t.width) * t.height);
+            rtpack::to_rgba8(t.texels, t.width, t.height, t.channels, keep.back().data());
+            T.tex[s].texels = keep.back().data();
+            T.tex[s].width = t.width; T.tex[s].height = t.height; T.tex[s].wrap = t.wrap; T.tex[s].levels = 1;
+        }
+    }
+    if (fr->sky_size > 0) {
+        const size_t fsz = static_cast<size_t>(fr->sky_size) * fr->sky_size;
+        keep.emplace_back(fsz * 6, 0u);
+        int mask = 0;
+        for (int f = 0; f < 6; f++)
+            if (fr->sky_faces[f]) { rtpack::to_rgba8(fr->sky_faces[f], fr->sky_size, fr->sky_size, fr->sky_channels, keep.back().data() + fsz * f); mask |= 1 << f; }
+        T.sky.texels = keep.back().data();
+        T.sky.size = fr->sky_size;
+        T.sky.face_mask = mask;
+    }
+    uint64_t tot[4] = {0, 0, 0, 0};
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tot[:4])
+    for (int y = y0; y < y1; y++) {
+        for (int x = 0; x < fr->fb_width; x++) {
+            LaneCounters c = {0, 0, 0, 0};
+            f4 px;
+            if (fr->cull) px = trace_pixel<true, true>(S, T, true, (float)x + 0.5f, (float)y + 0.5f, c);
+            else px = trace_pixel<false, true>(S, T, true, (float)x + 0.5f, (float)y + 0.5f, c);
+            float* o = out + (static_cast<size_t>(y - y0) * fr->fb_width + x) * 4;
+            o[0] = px.x; o[1] = px.y; o[2] = px.z; o[3] = px.w;
+            tot[0] += c.closest; tot[1] += c.shadow_ref; tot[2] += c.shadow_cast; tot[3] += c.torus_solves;
+        }
+    }
+    if (counters) std::memcpy(counters, tot, sizeof tot);
+    return 0;
+}
+
+// exhaustive check of the divide-free unorm8 against byte/255.0f
+int harness_unorm8_mismatches()
+{
+    int bad = 0;
+    for (uint32_t b = 0; b < 256; b++) {
+        volatile float ref = (float)b / 255.0f;
+        if (unorm8(b) != ref) bad++;
+    }
+    return bad;
+}
+
+}  // extern "C"
