@@ -49,6 +49,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP tracer is not built. Run `python -c \"import __graft_entry__ as g; g.build()\"` "
             "or `make -C raytracing_opengl_amd`. There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so, and the host layer
+    # shares device memory and streams with torch (bench.py, bands.py). Let torch load its runtime
+    # FIRST so that this library's libamdhip64.so.7 dependency binds to the same copy; loading
+    # /opt/rocm's runtime first leaves torch unable to see the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure-ctypes users without torch: /opt/rocm's runtime is used
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     c, P = ctypes, ctypes.POINTER
     vp, u32, i = c.c_void_p, c.c_uint32, c.c_int
