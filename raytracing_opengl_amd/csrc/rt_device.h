@@ -95,6 +95,24 @@ RT_HD f3 quat_rotate(f4 q, f3 v)
     return r;
 }
 
+// Exact shortcut for rotations by the identity quaternion (floor slabs, un-rotated crates, ...):
+// with q = (+-0,+-0,+-0,1) every product in quat_rotate other than 1*v_i is a signed zero, so the
+// result equals v bit for bit PROVIDED every component of v is finite and non-zero (a zero
+// component could change sign, an infinite one would turn 0*inf into NaN). `plain3` is that
+// proviso; when it fails the full formula runs.
+RT_HD bool quat_is_identity(f4 q) { return q.x == 0.0f && q.y == 0.0f && q.z == 0.0f && q.w == 1.0f; }
+RT_HD bool plain3(f3 v)
+{
+    const float z = v.x * 0.0f + v.y * 0.0f + v.z * 0.0f;  // NaN iff some component is inf/NaN
+    return z == 0.0f && v.x != 0.0f && v.y != 0.0f && v.z != 0.0f;
+}
+RT_HD f3 quat_rotate_id(f4 q, bool identity, f3 v)
+{
+    f3 r = v;
+    if (!(identity && plain3(v))) r = quat_rotate(q, v);
+    return r;
+}
+
 // atan(y,x) / asin(x) of the equirect mapping (rt.frag:323-324): fixed float64 series, only
 // + - * / sqrt, one final rounding to float -> bit-reproducible on host and device
 // (DESIGN.md "Numerics"; the oracle states the same algorithm independently).
@@ -311,8 +329,9 @@ RT_HD bool intersect_plane(f3 ro, f3 rd, f3 n, f3 p, float tmin, float& t)
 // rt.frag:372-390. uv is written only on a hit (the shader's global opt_uv)
 RT_HD bool intersect_ring(const DevRing& R, f3 ro, f3 rd, float tmin, float& t, f2& uv)
 {
-    const f3 d = quat_rotate(R.quat, rd);
-    const f3 o = quat_rotate(R.quat, ro - xyz(R.pos_tex));
+    const bool ident = quat_is_identity(R.quat);
+    const f3 d = quat_rotate_id(R.quat, ident, rd);
+    const f3 o = quat_rotate_id(R.quat, ident, ro - xyz(R.pos_tex));
     t = -o.z / d.z;
     const float x = o.x + d.x * t;
     const float y = o.y + d.y * t;
@@ -330,8 +349,9 @@ RT_HD bool intersect_ring(const DevRing& R, f3 ro, f3 rd, float tmin, float& t, 
 // early-outs exactly like the shader (trap T5); no t>0 test (trap T21).
 RT_HD bool intersect_box(const DevBox& B, f3 ro, f3 rd, float tmin, float& t, f3& nor)
 {
-    const f3 rdd = quat_rotate(B.quat, rd);
-    const f3 roo = quat_rotate(B.quat, ro - xyz(B.pos));
+    const bool ident = quat_is_identity(B.quat);
+    const f3 rdd = quat_rotate_id(B.quat, ident, rd);
+    const f3 roo = quat_rotate_id(B.quat, ident, ro - xyz(B.pos));
     const f3 m = mk3(1.0f / rdd.x, 1.0f / rdd.y, 1.0f / rdd.z);
     const f3 n = m * roo;
     const f3 k = mk3(fabsf(m.x), fabsf(m.y), fabsf(m.z)) * xyz(B.form_tex);
@@ -410,24 +430,43 @@ RT_HD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, fl
 // when it runs out of its 60 sweeps, which is what happens for origins more than ~100 units
 // away -- reports none (checked exhaustively against the un-culled oracle on every bench scene
 // and on random rays: tests/test_culls.py). Skipping is therefore result-preserving.
-RT_HD bool torus_cull(const DevTorus& T, f3 ro, f3 rd, float tlimit)
+// true = PROVABLY no point of the ray with 0 < t <= tlimit (plus slack) lies inside the sphere
+// (centre c, squared radius r2, already inflated by the caller).
+// The discriminant b*b - a*cc cancels catastrophically when the origin is far from the sphere
+// (|oc| >> r): its rounding error is bounded by ~1e-6 * a * |oc|^2 (three-term dot products,
+// 2^-24 per operation), so "misses" is only concluded when h is below minus ten times that.
+// NaNs compare false -> "not culled".
+RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
 {
-    const f3 oc = ro - xyz(T.pos);
-    const float cc = dot3(oc, oc) - T.k.y;   // > 0: origin outside the inflated bounding sphere
+    const f3 oc = ro - c;
+    const float d2 = dot3(oc, oc);
+    const float cc = d2 - r2;                 // > 0: origin outside
     if (!(cc > 0.0f)) return false;
     const float b = dot3(oc, rd);
     if (b >= 0.0f) return true;               // sphere behind the origin
     const float a = dot3(rd, rd);
     const float h = b * b - a * cc;
-    if (h < 0.0f) return true;                // line misses the sphere
-    const float lim = gl_min(tlimit, 100.0f);
-    const float t_in = (-b - sqrtf(h)) / a;   // entry distance (a ~ 1)
-    return t_in > lim * 1.001f + 0.01f;
+    const float err = 1e-5f * a * d2;
+    if (h < -err) return true;                // line misses the sphere, beyond rounding doubt
+    const float t_in = (-b - sqrtf(gl_max(h + err, 0.0f))) / a;   // earliest possible entry (a ~ 1)
+    return t_in > tlimit * 1.001f + 0.01f + 1e-5f * sqrtf(d2);
+}
+RT_HD bool torus_cull(const DevTorus& T, f3 ro, f3 rd, float tlimit)
+{
+    return sphere_cull(xyz(T.pos), T.k.y, ro, rd, gl_min(tlimit, 100.0f));
+}
+// A ring hit lies within sqrt(r2) of the ring centre (p < r2, rt.frag:384) and needs 0 < t < tmin;
+// intersect_ring has no NaN-accepting path (all four comparisons must hold), so missing the
+// inflated sphere means "false".
+RT_HD bool ring_cull(const DevRing& R, f3 ro, f3 rd, float tlimit)
+{
+    return sphere_cull(xyz(R.pos_tex), R.radii.w, ro, rd, tlimit);
 }
 RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
 {
-    const f3 o = quat_rotate(T.quat, ro - xyz(T.pos));
-    const f3 d = quat_rotate(T.quat, rd);
+    const bool ident = quat_is_identity(T.quat);
+    const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos));
+    const f3 d = quat_rotate_id(T.quat, ident, rd);
     return intersect_torus_local(T, o, d, tmin, t);
 }
 
@@ -435,8 +474,9 @@ RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t
 RT_HD bool is_between(f3 v, f3 lo, f3 hi) { return (v.x > lo.x && v.y > lo.y && v.z > lo.z) && (v.x < hi.x && v.y < hi.y && v.z < hi.z); }
 RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t)
 {
-    const f3 ro = quat_rotate(Q.quat, ro_w - xyz(Q.pos_a));
-    const f3 rd = quat_rotate(Q.quat, rd_w);
+    const bool ident = quat_is_identity(Q.quat);
+    const f3 ro = quat_rotate_id(Q.quat, ident, ro_w - xyz(Q.pos_a));
+    const f3 rd = quat_rotate_id(Q.quat, ident, rd_w);
     const float a = Q.pos_a.w, b = Q.bcde.x, c = Q.bcde.y, d = Q.bcde.z, e = Q.bcde.w, f = Q.f_vmin.x;
     const float d1 = rd.x, d2 = rd.y, d3 = rd.z, o1 = ro.x, o2 = ro.y, o3 = ro.z;
     const float p1 = 2.0f * a * d1 * o1 + 2.0f * b * d2 * o2 + 2.0f * c * d3 * o3 + d * d3 + d2 * e;
@@ -481,8 +521,9 @@ RT_HD bool surface_cull(const DevSurface& Q, f3 ro, f3 rd)
     const f3 oc = ro - xyz(Q.bound);
     const float b = dot3(oc, rd);
     const float a = dot3(rd, rd);
-    const float cc = dot3(oc, oc) - Q.bound.w;
-    return (b * b - a * cc) < 0.0f;             // NaN -> false -> not culled
+    const float d2 = dot3(oc, oc);
+    const float cc = d2 - Q.bound.w;
+    return (b * b - a * cc) < -1e-5f * a * d2;  // rounding-safe (see sphere_cull); NaN -> false -> not culled
 }
 
 // ------------------------------------------------------------------------------------------
@@ -515,6 +556,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
     }
     for (int i = 0; i < S.h->n_ring; i++) {
         f2 uv;
+        if (CULL && ring_cull(S.rings[i], ro, rd, tmin)) continue;
         if (intersect_ring(S.rings[i], ro, rd, tmin, t, uv)) { num = i; tmin = t; type = TYPE_RING; }
     }
     for (int i = 0; i < S.h->n_light_point; i++) {
@@ -563,7 +605,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 
     // rings: textured rings ADD their alpha (trap T10) -- keep ring order for the float sum
     for (int i = 0; i < S.h->n_ring; i++) {
         f2 uv = mk2(0.0f, 0.0f);
-        const bool hit = on && intersect_ring(S.rings[i], ro, rd, dist, t, uv);
+        const bool hit = on && !(CULL && ring_cull(S.rings[i], ro, rd, dist)) && intersect_ring(S.rings[i], ro, rd, dist, t, uv);
         const int texnum = __builtin_bit_cast(int, S.rings[i].pos_tex.w);
         if (texnum > 0) {
             if (RT_ANY(hit)) {
@@ -732,8 +774,9 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
     if (on && type == TYPE_SURFACE) {  // getSurfaceNormal rt.frag:573-584
         const DevSurface& Q = S.surfaces[num];
         load_material(S.mats[TYPE_SURFACE][num], h);
-        const f3 o = quat_rotate(Q.quat, ro - xyz(Q.pos_a));
-        const f3 d = quat_rotate(Q.quat, rd);
+        const bool ident = quat_is_identity(Q.quat);
+        const f3 o = quat_rotate_id(Q.quat, ident, ro - xyz(Q.pos_a));
+        const f3 d = quat_rotate_id(Q.quat, ident, rd);
         const f3 tm = d * t + o;
         const f3 n = mk3(2.0f * Q.pos_a.w * tm.x, 2.0f * Q.bcde.x * tm.y + Q.bcde.w, 2.0f * Q.bcde.y * tm.z + Q.bcde.z);
         h.normal = normalize3(quat_rotate(Q.qinv, n));
@@ -772,8 +815,9 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
     if (on && type == TYPE_TORUS) {  // getTorusNormal rt.frag:488-496
         const DevTorus& P = S.tori[num];
         load_material(S.mats[TYPE_TORUS][num], h);
-        const f3 o = quat_rotate(P.quat, ro - xyz(P.pos));
-        const f3 d = quat_rotate(P.quat, rd);
+        const bool ident = quat_is_identity(P.quat);
+        const f3 o = quat_rotate_id(P.quat, ident, ro - xyz(P.pos));
+        const f3 d = quat_rotate_id(P.quat, ident, rd);
         const f3 pos = o + d * t;
         const float s = dot3(pos, pos) - P.radii.w;
         const f3 n = pos * mk3(s - P.radii.z * 1.0f, s - P.radii.z * 1.0f, s - P.radii.z * -1.0f);

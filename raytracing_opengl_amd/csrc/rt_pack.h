@@ -48,6 +48,135 @@ inline float text_round_trip(float v)
 
 inline size_t align16(size_t n) { return (n + 15) & ~static_cast<size_t>(15); }
 
+
+// ---- bounding box of a quadric clipped by the reference's world-space clip box ------------------
+// World form of the surface:  x^T A x + B^T x + C = 0  with A = R^T diag(a,b,c) R,
+// B = w - 2 A p, C = p^T A p - w.p + f  (w = R^T (0,e,d), p = surface.pos).
+// Clip box axes are either finite (set F) or +-FLT_MAX (set U). For every point v of the F-box the
+// equation in the U coordinates u is  (u-u0(v))^T A_UU (u-u0(v)) = g(v); if A_UU is definite the
+// solutions lie within sqrt(|g|/lambda_min) of u0(v). u0 is linear and g quadratic in v, so both
+// are bounded over the box by centre value + first/second-order terms (rigorous, slightly loose).
+// Returns false when the clipped surface is unbounded (A_UU indefinite/singular) -> no cull.
+inline void sym_eig_minmax_abs(const double* M, int n, double& min_abs, bool& definite)
+{
+    // Jacobi rotations on a copy (n <= 3)
+    double a[3][3] = {{0}};
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) a[i][j] = M[i * n + j];
+    for (int sweep = 0; sweep < 50; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += a[i][j] * a[i][j];
+        if (off < 1e-300) break;
+        for (int pi = 0; pi < n; pi++)
+            for (int qi = pi + 1; qi < n; qi++) {
+                if (std::fabs(a[pi][qi]) < 1e-300) continue;
+                const double theta = (a[qi][qi] - a[pi][pi]) / (2.0 * a[pi][qi]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; k++) { const double akp = a[k][pi], akq = a[k][qi]; a[k][pi] = cs * akp - sn * akq; a[k][qi] = sn * akp + cs * akq; }
+                for (int k = 0; k < n; k++) { const double apk = a[pi][k], aqk = a[qi][k]; a[pi][k] = cs * apk - sn * aqk; a[qi][k] = sn * apk + cs * aqk; }
+            }
+    }
+    int pos = 0, neg = 0;
+    min_abs = 1e300;
+    for (int i = 0; i < n; i++) {
+        if (a[i][i] > 0) pos++; else if (a[i][i] < 0) neg++;
+        min_abs = std::fmin(min_abs, std::fabs(a[i][i]));
+    }
+    definite = (pos == n || neg == n) && min_abs > 1e-12;
+}
+inline bool solve_sym(const double* M, int n, const double* rhs, double* x)  // M x = rhs, n <= 3, Gaussian elimination with pivoting
+{
+    double a[3][4];
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) a[i][j] = M[i * n + j]; a[i][n] = rhs[i]; }
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int r = c + 1; r < n; r++) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (std::fabs(a[piv][c]) < 1e-300) return false;
+        if (piv != c) for (int k = 0; k <= n; k++) std::swap(a[piv][k], a[c][k]);
+        for (int r = 0; r < n; r++) if (r != c) { const double fct = a[r][c] / a[c][c]; for (int k = c; k <= n; k++) a[r][k] -= fct * a[c][k]; }
+    }
+    for (int i = 0; i < n; i++) x[i] = a[i][n] / a[i][i];
+    return true;
+}
+inline bool quadric_clip_bounds(const double A[3][3], const double w[3], const double p[3], double f, const double lo[3], const double hi[3],
+                                double out_lo[3], double out_hi[3])
+{
+    const double big = 1.0e30;
+    int U[3], F[3], nu = 0, nf = 0;
+    for (int k = 0; k < 3; k++) {
+        if (!(lo[k] == lo[k]) || !(hi[k] == hi[k]) || !(lo[k] < hi[k])) return false;
+        if (std::fabs(lo[k]) < big && std::fabs(hi[k]) < big) F[nf++] = k; else U[nu++] = k;
+    }
+    for (int k = 0; k < nf; k++) { out_lo[F[k]] = lo[F[k]]; out_hi[F[k]] = hi[F[k]]; }
+    if (nu == 0) return true;
+    for (int k = 0; k < nu; k++) if (std::fabs(lo[U[k]]) < big || std::fabs(hi[U[k]]) < big) return false;  // half-bounded axis: treat as unbounded
+    double B[3], C = f;
+    for (int r = 0; r < 3; r++) {
+        double Ap = 0.0;
+        for (int q = 0; q < 3; q++) Ap += A[r][q] * p[q];
+        B[r] = w[r] - 2.0 * Ap;
+        C += p[r] * Ap - w[r] * p[r];
+    }
+    double Auu[9], minabs;
+    bool definite;
+    for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) Auu[i * nu + j] = A[U[i]][U[j]];
+    sym_eig_minmax_abs(Auu, nu, minabs, definite);
+    if (!definite) return false;
+    const double sgn = Auu[0] > 0 ? 1.0 : -1.0;  // definite: sign of any diagonal entry
+    // box centre / half widths of the finite axes
+    double vc[3] = {0, 0, 0}, hv[3] = {0, 0, 0};
+    for (int k = 0; k < nf; k++) { vc[k] = 0.5 * (lo[F[k]] + hi[F[k]]); hv[k] = 0.5 * (hi[F[k]] - lo[F[k]]); }
+    // u0(v) = Mm v + m0 :  A_UU u0 = -(A_UF v + B_U/2)
+    double Mm[3][3] = {{0}}, m0[3] = {0, 0, 0}, rhs[3], col[3];
+    for (int i = 0; i < nu; i++) rhs[i] = -0.5 * B[U[i]];
+    if (!solve_sym(Auu, nu, rhs, m0)) return false;
+    for (int j = 0; j < nf; j++) {
+        for (int i = 0; i < nu; i++) rhs[i] = -A[U[i]][F[j]];
+        if (!solve_sym(Auu, nu, rhs, col)) return false;
+        for (int i = 0; i < nu; i++) Mm[i][j] = col[i];
+    }
+    // g(v) = u0^T A_UU u0 - (v^T A_FF v + B_F^T v + C) = v^T Q v + L^T v + K
+    double Q[3][3] = {{0}}, L[3] = {0, 0, 0}, K = -C;
+    double Am0[3] = {0, 0, 0};
+    for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) Am0[i] += Auu[i * nu + j] * m0[j];
+    for (int i = 0; i < nu; i++) K += m0[i] * Am0[i];
+    for (int a_ = 0; a_ < nf; a_++) {
+        double AMa[3] = {0, 0, 0};
+        for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) AMa[i] += Auu[i * nu + j] * Mm[j][a_];
+        for (int b_ = 0; b_ < nf; b_++) {
+            double acc = 0.0;
+            for (int i = 0; i < nu; i++) acc += Mm[i][b_] * AMa[i];
+            Q[b_][a_] = acc - A[F[b_]][F[a_]];
+        }
+        double l = 0.0;
+        for (int i = 0; i < nu; i++) l += 2.0 * Mm[i][a_] * Am0[i];
+        L[a_] = l - B[F[a_]];
+    }
+    // G = sgn * g ; bound max over the box: value at centre + |gradient| h + second-order terms
+    double gc = K, grad[3] = {0, 0, 0};
+    for (int a_ = 0; a_ < nf; a_++) {
+        gc += L[a_] * vc[a_];
+        grad[a_] = L[a_];
+        for (int b_ = 0; b_ < nf; b_++) { gc += vc[a_] * Q[a_][b_] * vc[b_]; grad[a_] += (Q[a_][b_] + Q[b_][a_]) * vc[b_]; }
+    }
+    double Gmax = sgn * gc;
+    for (int a_ = 0; a_ < nf; a_++) {
+        Gmax += std::fabs(grad[a_]) * hv[a_];
+        for (int b_ = 0; b_ < nf; b_++) {
+            const double qs = sgn * 0.5 * (Q[a_][b_] + Q[b_][a_]);
+            Gmax += (a_ == b_ ? std::fmax(0.0, qs) : std::fabs(qs)) * hv[a_] * hv[b_];
+        }
+    }
+    const double rad = Gmax > 0.0 ? std::sqrt(Gmax / minabs) : 0.0;  // Gmax <= 0: the surface misses the slab entirely
+    for (int i = 0; i < nu; i++) {
+        double c0 = m0[i], spread = 0.0;
+        for (int j = 0; j < nf; j++) { c0 += Mm[i][j] * vc[j]; spread += std::fabs(Mm[i][j]) * hv[j]; }
+        out_lo[U[i]] = c0 - spread - rad;
+        out_hi[U[i]] = c0 + spread + rad;
+    }
+    return true;
+}
+
 // blocks[b] may be shorter than count*record (or empty): returns false and sets err.
 inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks[BLK_COUNT], std::vector<unsigned char>& blob, std::string& err)
 {
@@ -125,33 +254,35 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.f_vmin = mk4(f, vmin.x, vmin.y, vmin.z);
         s.vmax = mk4(vmax.x, vmax.y, vmax.z, 0.0f);
         s.qinv = quat_inv(s.quat);
-        // cull data (surface_cull in rt_device.h)
-        const float big = 1.0e30f;
-        const bool finite_box = std::fabs(vmin.x) < big && std::fabs(vmin.y) < big && std::fabs(vmin.z) < big && std::fabs(vmax.x) < big &&
-                                std::fabs(vmax.y) < big && std::fabs(vmax.z) < big;
-        if (finite_box) {
-            const double cx = 0.5 * (static_cast<double>(vmin.x) + vmax.x), cy = 0.5 * (static_cast<double>(vmin.y) + vmax.y),
-                         cz = 0.5 * (static_cast<double>(vmin.z) + vmax.z);
-            const double hx = 0.5 * (static_cast<double>(vmax.x) - vmin.x), hy = 0.5 * (static_cast<double>(vmax.y) - vmin.y),
-                         hz = 0.5 * (static_cast<double>(vmax.z) - vmin.z);
-            const double rad = std::sqrt(hx * hx + hy * hy + hz * hz) * 1.01 + 0.01;
-            s.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
-            // columns of the world->local rotation, then M = R^T diag(a,b,c) R in double
+        // cull data (surface_cull in rt_device.h): symmetric M for the p2 pre-check + a bounding
+        // sphere of the part of the surface inside the world-space clip box (may not exist)
+        {
             const f3 ex = quat_rotate(s.quat, mk3(1, 0, 0)), ey = quat_rotate(s.quat, mk3(0, 1, 0)), ez = quat_rotate(s.quat, mk3(0, 0, 1));
             const double Rm[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};  // Rm[k][j]: local k <- world j
             const double dg[3] = {a, b, c};
-            double M[3][3];
-            for (int r = 0; r < 3; r++)
+            const double ql[3] = {0.0, e, dd};  // linear local coefficients (x: none, y: e, z: d)
+            const double pw[3] = {rdf(p, 112), rdf(p, 116), rdf(p, 120)};
+            double A[3][3], wv[3];
+            for (int r = 0; r < 3; r++) {
                 for (int q = 0; q < 3; q++) {
                     double acc = 0.0;
                     for (int k = 0; k < 3; k++) acc += Rm[k][r] * dg[k] * Rm[k][q];
-                    M[r][q] = acc;
+                    A[r][q] = acc;
                 }
-            s.sym0 = mk4(static_cast<float>(M[0][0]), static_cast<float>(M[0][1]), static_cast<float>(M[0][2]), static_cast<float>(M[1][1]));
+                wv[r] = Rm[0][r] * ql[0] + Rm[1][r] * ql[1] + Rm[2][r] * ql[2];
+            }
+            s.sym0 = mk4(static_cast<float>(A[0][0]), static_cast<float>(A[0][1]), static_cast<float>(A[0][2]), static_cast<float>(A[1][1]));
             const float margin = 1e-6f + 1e-5f * (std::fabs(a) + std::fabs(b) + std::fabs(c));
-            s.sym1 = mk4(static_cast<float>(M[1][2]), static_cast<float>(M[2][2]), margin, 0.0f);
-        } else {
+            s.sym1 = mk4(static_cast<float>(A[1][2]), static_cast<float>(A[2][2]), margin, 0.0f);
+            const double lo[3] = {vmin.x, vmin.y, vmin.z}, hi[3] = {vmax.x, vmax.y, vmax.z};
+            double clo[3], chi[3];
             s.bound = mk4(0.0f, 0.0f, 0.0f, -1.0f);
+            if (quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi)) {
+                const double cx = 0.5 * (clo[0] + chi[0]), cy = 0.5 * (clo[1] + chi[1]), cz = 0.5 * (clo[2] + chi[2]);
+                const double hx = 0.5 * (chi[0] - clo[0]), hy = 0.5 * (chi[1] - clo[1]), hz = 0.5 * (chi[2] - clo[2]);
+                const double rad = std::sqrt(hx * hx + hy * hy + hz * hz) * 1.01 + 0.01;
+                if (rad == rad && rad < 1.0e15) s.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
+            }
         }
         std::memcpy(reinterpret_cast<DevSurface*>(blob.data() + h.off_surface) + i, &s, sizeof s);
         std::memcpy(mat_at(TYPE_SURFACE, i), p, 64);
@@ -187,7 +318,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.quat = rd4(p, 64);
         s.pos_tex = rd3(p, 80, int_bits(rdi(p, 92)));
         const float r1 = rdf(p, 96), r2 = rdf(p, 100);
-        s.radii = mk4(r1, r2, r2 - r1, 0.0f);
+        const double ring_rb = std::sqrt(static_cast<double>(r2)) * 1.001 + 0.01;  // NaN for a negative r2: never culled
+        s.radii = mk4(r1, r2, r2 - r1, static_cast<float>(ring_rb * ring_rb));
         const f3 nrm = quat_rotate(quat_inv(s.quat), mk3(0.0f, 0.0f, -1.0f));
         s.normal = mk4(nrm.x, nrm.y, nrm.z, 0.0f);
         std::memcpy(reinterpret_cast<DevRing*>(blob.data() + h.off_ring) + i, &s, sizeof s);

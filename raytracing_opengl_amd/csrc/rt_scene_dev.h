@@ -52,7 +52,7 @@ struct alignas(16) DevSurface {
     f4 f_vmin;         // f, v_min xyz (world-space clip box, trap T6)
     f4 vmax;           // v_max xyz, w unused
     f4 qinv;           // quat_inv(quat)
-    f4 bound;          // cull sphere: centre xyz (world), w = radius^2 (inflated); w < 0: not cullable
+    f4 bound;          // cull sphere of the CLIPPED surface: centre xyz (world), w = radius^2 (inflated); w < 0: unbounded
     f4 sym0;           // symmetric M = R^T diag(a,b,c) R : m00, m01, m02, m11
     f4 sym1;           // m12, m22, |p2| margin, unused        (p2 ~ d^T M d, see surface_cull)
 };
@@ -72,7 +72,7 @@ struct alignas(16) DevTorus {
 struct alignas(16) DevRing {
     f4 quat;
     f4 pos_tex;        // pos xyz, w = textureNum (int bits)
-    f4 radii;          // r1, r2 (squared radii, trap T7), r2 - r1, unused
+    f4 radii;          // r1, r2 (squared radii, trap T7), r2 - r1, w = cull radius^2 (r2 inflated)
     f4 normal;         // rotate(quat_inv(quat), (0,0,-1))  (rt.frag:391-394)
 };
 struct alignas(16) DevLightPoint {

@@ -44,6 +44,8 @@ def lib():
         l.harness_render.restype = ctypes.c_int
         l.harness_render.argtypes = [ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         l.harness_unorm8_mismatches.restype = ctypes.c_int
+        l.harness_kat.restype = ctypes.c_int
+        l.harness_kat.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_float * 3, ctypes.c_float * 3, ctypes.c_float, ctypes.c_float * 3]
         _lib = l
     return _lib
 
@@ -82,3 +84,13 @@ def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=
     if rc != 0:
         raise RuntimeError("harness_render failed")
     return out, {"closest": cnt[0], "shadow_ref": cnt[1], "shadow_cast": cnt[2], "torus_solves": cnt[3]}
+
+
+def kat(type_, record: bytes, ro, rd, tmin=1e6):
+    """(hit, t, culled) from the DEVICE intersector + its cull predicate for one std140 record."""
+    out = (ctypes.c_float * 3)()
+    buf = ctypes.create_string_buffer(record, len(record))
+    rc = lib().harness_kat(type_, buf, (ctypes.c_float * 3)(*ro), (ctypes.c_float * 3)(*rd), tmin, out)
+    if rc != 0:
+        raise RuntimeError(f"harness_kat failed ({rc})")
+    return bool(out[0]), out[1], bool(out[2])

@@ -81,6 +81,43 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
     return 0;
 }
 
+// Single-primitive entry points on the DEVICE functions (packed through rt_pack.h like the product does).
+// type: PrimType; record: one std140 record of that type. out[0]=hit, out[1]=t, out[2]=cull decision (1 = skipped).
+int harness_kat(int type, const void* record, const float ro[3], const float rd[3], float tmin, float out[3])
+{
+    rtpack::Defines d;
+    std::memset(&d, 0, sizeof d);
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    blocks[rtpack::BLK_SCENE].assign(64, 0);
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    int blk = -1;
+    if (type == TYPE_SURFACE) { d.surface_size = 1; blk = rtpack::BLK_SURFACES; }
+    if (type == TYPE_BOX) { d.box_size = 1; blk = rtpack::BLK_BOXES; }
+    if (type == TYPE_TORUS) { d.torus_size = 1; blk = rtpack::BLK_TORUSES; }
+    if (type == TYPE_RING) { d.ring_size = 1; blk = rtpack::BLK_RINGS; }
+    if (blk < 0) return -1;
+    blocks[blk].assign(p, p + rtpack::kRecordSize[blk]);
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(d, blocks, blob, err)) return -2;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    const f3 o = mk3(ro[0], ro[1], ro[2]), dd = mk3(rd[0], rd[1], rd[2]);
+    float t = 0.0f;
+    bool hit = false, cull = false;
+    f3 nor = mk3(0, 0, 0);
+    f2 uv = mk2(0, 0);
+    if (type == TYPE_SURFACE) { cull = surface_cull(S.surfaces[0], o, dd); hit = intersect_surface(S.surfaces[0], o, dd, tmin, t); }
+    if (type == TYPE_BOX) { hit = intersect_box(S.boxes[0], o, dd, tmin, t, nor); }
+    if (type == TYPE_TORUS) { cull = torus_cull(S.tori[0], o, dd, tmin); hit = intersect_torus(S.tori[0], o, dd, tmin, t); }
+    if (type == TYPE_RING) { cull = ring_cull(S.rings[0], o, dd, tmin); hit = intersect_ring(S.rings[0], o, dd, tmin, t, uv); }
+    out[0] = hit ? 1.0f : 0.0f;
+    out[1] = t;
+    out[2] = cull ? 1.0f : 0.0f;
+    return 0;
+}
+
 // exhaustive check of the divide-free unorm8 against byte/255.0f
 int harness_unorm8_mismatches()
 {

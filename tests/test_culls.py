@@ -1,0 +1,134 @@
+"""The conservative culls must be RESULT-PRESERVING: whenever a cull predicate says "skip", the
+reference intersector (oracle) must report a miss for that ray. Checked on random rays around
+random primitives, with origins from touching distance out to 1e5 units (where the discriminant
+of a naive sphere test cancels catastrophically) and with every tmin regime.
+Also: the device intersectors agree bit for bit with the oracle's on the same rays."""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+import harness
+from oracle import oracle
+from test_oracle_kat import _isect, _mat, _quat, _surface
+
+
+def _rand_quat(rng):
+    if rng.random() < 0.25:
+        return struct.pack("<4f", 0, 0, 0, 1)  # identity: exercises the exact shortcut
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return struct.pack("<4f", *q)
+
+
+def _rays(rng, centre, extent, n):
+    """Rays aimed near the primitive from a wide range of distances, plus some that miss widely."""
+    for _ in range(n):
+        dist = 10 ** rng.uniform(-1, 5) * (1 if rng.random() < 0.8 else 0.01)
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        ro = np.asarray(centre) + direction * dist + rng.normal(size=3) * extent * 0.3
+        target = np.asarray(centre) + rng.normal(size=3) * extent * (0.6 if rng.random() < 0.7 else 4.0)
+        rd = target - ro
+        rd = (rd / np.linalg.norm(rd)).astype(np.float32)
+        if rng.random() < 0.1:
+            rd = -rd
+        if rng.random() < 0.05:  # exact zero direction components (NaN traps)
+            rd[rng.integers(3)] = 0.0
+            rd = rd / max(1e-30, np.linalg.norm(rd))
+        tmin = 1e6 if rng.random() < 0.5 else float(10 ** rng.uniform(-1, 4))
+        yield ro.astype(np.float32), rd.astype(np.float32), tmin
+
+
+def _check(type_, record, rng, centre, extent, n):
+    culled = hits = 0
+    for ro, rd, tmin in _rays(rng, centre, extent, n):
+        ohit, ot, _ = _isect(type_, record, ro, rd, tmin)
+        dhit, dt, dcull = harness.kat(type_, record, ro, rd, tmin)
+        assert dhit == ohit, (ro, rd, tmin)
+        if ohit:
+            assert (dt == ot) or (math.isnan(dt) and math.isnan(ot)), (ro, rd, dt, ot)
+            hits += 1
+        if dcull:
+            assert not ohit, f"cull skipped a ray the reference hits: ro={ro} rd={rd} tmin={tmin} t={ot}"
+            culled += 1
+    return culled, hits
+
+
+def test_torus_cull_and_solver(built):
+    rng = np.random.default_rng(11)
+    total_c = total_h = 0
+    for _ in range(12):
+        R, r = rng.uniform(0.5, 3.0), rng.uniform(0.1, 0.9)
+        pos = rng.uniform(-20, 20, 3)
+        rec = _mat() + _rand_quat(rng) + struct.pack("<3f f 2f 2f", *pos, 0, R, r, 0, 0)
+        c, h = _check(oracle.TYPE_TORUS, rec, rng, pos, R + r, 150)
+        total_c += c
+        total_h += h
+    assert total_c > 200 and total_h > 100
+
+
+def test_ring_cull(built):
+    rng = np.random.default_rng(12)
+    total_c = total_h = 0
+    for _ in range(12):
+        r_in, r_out = sorted(rng.uniform(0.5, 50.0, 2))
+        pos = rng.uniform(-100, 100, 3)
+        rec = _mat() + _rand_quat(rng) + struct.pack("<3fi2f2f", *pos, 4, r_in ** 2, r_out ** 2, 0, 0)
+        c, h = _check(oracle.TYPE_RING, rec, rng, pos, r_out, 150)
+        total_c += c
+        total_h += h
+    assert total_c > 200 and total_h > 100
+
+
+SHAPES = [dict(a=1, b=1, c=1, f=-1), dict(a=9, b=9, c=-1), dict(a=4, b=4, f=-1), dict(a=1.5, b=1.5, d=-1), dict(a=1.5, b=-1.5, d=-1),
+          dict(a=4, b=4, c=-1, f=-1), dict(a=4, b=4, c=-1, f=1), dict(a=1, e=0.6), dict(a=2, b=-3, f=-1)]
+
+
+@pytest.mark.parametrize("clip", ["all", "y_only", "xz_only", "none"])
+def test_quadric_cull(built, clip):
+    rng = np.random.default_rng(13)
+    total_c = total_h = 0
+    big = 3.402823466e38
+    for shape in SHAPES:
+        for _ in range(3):
+            pos = rng.uniform(-15, 15, 3)
+            ext = rng.uniform(0.5, 3.0, 3)
+            lo, hi = pos - ext, pos + ext
+            if clip == "y_only":
+                lo[[0, 2]], hi[[0, 2]] = -big, big
+            elif clip == "xz_only":
+                lo[1], hi[1] = -big, big
+            elif clip == "none":
+                lo[:], hi[:] = -big, big
+            rec = _surface(pos=tuple(pos), quat=_rand_quat(rng), vmin=tuple(lo), vmax=tuple(hi), **shape)
+            c, h = _check(oracle.TYPE_SURFACE, rec, rng, pos, float(ext.max()) * 1.5, 120)
+            total_c += c
+            total_h += h
+    assert total_h > 100
+    if clip == "all":
+        assert total_c > 300
+
+
+def test_box_matches_oracle_including_nan_paths(built):
+    rng = np.random.default_rng(14)
+    for _ in range(10):
+        pos = rng.uniform(-10, 10, 3)
+        form = rng.uniform(0.2, 4.0, 3)
+        rec = _mat() + _rand_quat(rng) + struct.pack("<3f f 3f i", *pos, 0, *form, 0)
+        _check(oracle.TYPE_BOX, rec, rng, pos, float(form.max()), 150)
+
+
+def test_default_scene_quadrics_get_a_bound(built):
+    """The cone and the cylinder of the default scene are clipped in world y only; the analytic
+    clip bound must still find a finite bounding sphere for both (DESIGN.md 'Culls')."""
+    from raytracing_opengl_amd import scenes
+    sc = scenes.build_scene("default", 640, 480, 1)
+    blk = sc.blocks["surfaces_buf"]
+    rng = np.random.default_rng(15)
+    for i in range(2):
+        rec = blk[i * 160:(i + 1) * 160]
+        pos = struct.unpack_from("<3f", rec, 112)
+        c, h = _check(oracle.TYPE_SURFACE, rec, rng, pos, 3.0, 400)
+        assert c > 100 and h > 20, (i, c, h)
