@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(_HERE, "librtx_hip.so")  # RTX_HIP_LIB: A/B builds of the same library
 
 RTX_OK = 0
 RTX_RGBA32F, RTX_RGBA8 = 0, 1

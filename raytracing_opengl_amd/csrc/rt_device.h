@@ -26,8 +26,10 @@
 
 #if defined(__HIPCC__)
 #define RT_HD __host__ __device__ __forceinline__
+#define RT_HDM __host__ __device__ __forceinline__
 #else
 #define RT_HD static inline
+#define RT_HDM inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -176,45 +178,82 @@ RT_HD float rt_asin(float xf)
 #define RT_FLT_MAX 3.402823466e+38f   /* rt.frag:4 */
 #define RT_SEGMENT_CAP 256            /* bound on main-loop trips (refraction does i--, trap T2) */
 
+// Typed access to the DevScene blob. Array addresses are re-derived from the header offsets at
+// each use (two scalar ops) instead of being kept in 30 SGPRs for the whole kernel.
 struct SceneView {
-    const DevSceneHeader* h;
-    const DevSphere* spheres;
-    const DevPlane* planes;
-    const DevSurface* surfaces;
-    const DevBox* boxes;
-    const DevTorus* tori;
-    const DevRing* rings;
-    const DevLightPoint* lights_point;
-    const DevLightDirect* lights_direct;
-    const DevMaterial* mats[6];
+    const DevSceneHeader* h;   // counts, camera, offsets (kernel arguments on the device)
+    const char* blob;
+    template <class T> RT_HDM const T* at(uint32_t off) const { return reinterpret_cast<const T*>(blob + off); }
+    RT_HDM const DevSphere* spheres() const { return at<DevSphere>(h->off_sphere); }
+    RT_HDM const DevPlane* planes() const { return at<DevPlane>(h->off_plane); }
+    RT_HDM const DevSurface* surfaces() const { return at<DevSurface>(h->off_surface); }
+    RT_HDM const DevBox* boxes() const { return at<DevBox>(h->off_box); }
+    RT_HDM const DevTorus* tori() const { return at<DevTorus>(h->off_torus); }
+    RT_HDM const DevRing* rings() const { return at<DevRing>(h->off_ring); }
+    RT_HDM const DevLightPoint* lights_point() const { return at<DevLightPoint>(h->off_light_point); }
+    RT_HDM const DevLightDirect* lights_direct() const { return at<DevLightDirect>(h->off_light_direct); }
+    RT_HDM const DevMaterial* mats(int type) const { return at<DevMaterial>(h->off_mat[type]); }
+    RT_HDM const f4* sph_geom() const { return at<f4>(h->off_sph_geom); }
+    RT_HDM const uint32_t* sph_hollow() const { return at<uint32_t>(h->off_sph_hollow); }
+    RT_HDM const DevSurfaceCull* surf_cull() const { return at<DevSurfaceCull>(h->off_surf_cull); }
+    RT_HDM const f4* torus_bound() const { return at<f4>(h->off_torus_bound); }
+    RT_HDM const f4* ring_bound() const { return at<f4>(h->off_ring_bound); }
 };
-RT_HD SceneView make_view(const char* blob)
+// `hdr` may live somewhere faster than the blob (the kernel passes a copy in its kernel arguments,
+// so counts, camera and array offsets do not sit behind a dependent load of the blob).
+RT_HD SceneView make_view(const char* blob, const DevSceneHeader* hdr)
 {
     SceneView S;
-    const DevSceneHeader* h = reinterpret_cast<const DevSceneHeader*>(blob);
-    S.h = h;
-    S.spheres = reinterpret_cast<const DevSphere*>(blob + h->off_sphere);
-    S.planes = reinterpret_cast<const DevPlane*>(blob + h->off_plane);
-    S.surfaces = reinterpret_cast<const DevSurface*>(blob + h->off_surface);
-    S.boxes = reinterpret_cast<const DevBox*>(blob + h->off_box);
-    S.tori = reinterpret_cast<const DevTorus*>(blob + h->off_torus);
-    S.rings = reinterpret_cast<const DevRing*>(blob + h->off_ring);
-    S.lights_point = reinterpret_cast<const DevLightPoint*>(blob + h->off_light_point);
-    S.lights_direct = reinterpret_cast<const DevLightDirect*>(blob + h->off_light_direct);
-    for (int t = 0; t < 6; t++) S.mats[t] = reinterpret_cast<const DevMaterial*>(blob + h->off_mat[t]);
+    S.h = hdr;
+    S.blob = blob;
     return S;
 }
+RT_HD SceneView make_view(const char* blob) { return make_view(blob, reinterpret_cast<const DevSceneHeader*>(blob)); }
 
 struct TexTable {
     DevTexture tex[TEX_SLOTS];
     DevCubemap sky;
 };
 
+// Optional per-wave phase timers (profiling builds only, -DRT_PHASE_TIMERS): wave-cycles spent in
+// each phase of the segment loop, read with s_memtime. Nested: DK time is also inside SCAN/SHADE.
+enum { PH_SETUP = 0, PH_SCAN, PH_HITINFO, PH_CLASSIFY, PH_SKY, PH_SHADE, PH_DK, PH_APPLY, PH_SHADOW, PH_TRIPS, PH_C_SPH, PH_C_SURF, PH_C_BOX, PH_C_TORUS, PH_C_RING, PH_C_LIGHT, PH_COUNT = 18 };
+#if defined(RT_PHASE_TIMERS)
+struct PhaseClock { unsigned long long acc[PH_COUNT]; };
+#endif
+#if defined(RT_PHASE_TIMERS) && defined(__HIP_DEVICE_COMPILE__)
+// s_memtime has no data dependence on the VALU work around it, so it is fenced with scheduling
+// barriers (nothing may be moved across) and an explicit wait for its own result.
+__device__ __forceinline__ unsigned long long rt_ph_now()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define RT_PH_DECL unsigned long long _ph_t0 = rt_ph_now()
+#define RT_PH_LAP(cnt, id) { const unsigned long long _now = rt_ph_now(); (cnt).pc.acc[id] += _now - _ph_t0; _ph_t0 = _now; }
+#define RT_PH_BEGIN(name) const unsigned long long name = rt_ph_now()
+#define RT_PH_END(cnt, id, name) (cnt).pc.acc[id] += rt_ph_now() - (name)
+#define RT_PH_ADD(cnt, id, v) (cnt).pc.acc[id] += (v)
+#else
+#if !defined(RT_PHASE_TIMERS)
+struct PhaseClock {};
+#endif
+#define RT_PH_DECL
+#define RT_PH_LAP(cnt, id)
+#define RT_PH_BEGIN(name)
+#define RT_PH_END(cnt, id, name)
+#define RT_PH_ADD(cnt, id, v)
+#endif
+
 struct LaneCounters {
     uint32_t closest;      // calcInter invocations (reference-defined closest-hit rays)
     uint32_t shadow_ref;   // inShadow invocations the reference would make
     uint32_t shadow_cast;  // shadow scans actually executed
     uint32_t torus_solves; // Durand-Kerner solves actually executed
+    PhaseClock pc;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -234,12 +273,12 @@ RT_HD float unorm8(uint32_t b)
 }
 RT_HD f4 unpack_rgba8(uint32_t p) { return mk4(unorm8(p & 255u), unorm8((p >> 8) & 255u), unorm8((p >> 16) & 255u), unorm8(p >> 24)); }
 
-RT_HD void axis_taps(float u, int n, int wrap, int& i0, int& i1, float& a)
+RT_HD void axis_taps(float u, int n, float fn, int wrap, int& i0, int& i1, float& a)
 {
     if (wrap == 0) u = u - floorf(u);
     else u = gl_min(gl_max(u, -1.0f), 2.0f);
     if (!(u == u)) u = 0.0f;
-    const float x = u * (float)n - 0.5f;
+    const float x = u * fn - 0.5f;  // fn == (float)n
     const float fl = floorf(x);
     a = x - fl;
     int i = (int)fl;
@@ -275,8 +314,8 @@ RT_HD f4 sample2d_level0(const DevTexture& t, float u, float v)
     if (t.texels == nullptr) return mk4(0.0f, 0.0f, 0.0f, 1.0f);
     int i0, i1, j0, j1;
     float a, b;
-    axis_taps(u, t.width, t.wrap, i0, i1, a);
-    axis_taps(v, t.height, t.wrap, j0, j1, b);
+    axis_taps(u, t.width, t.fwidth, t.wrap, i0, i1, a);
+    axis_taps(v, t.height, t.fheight, t.wrap, j0, j1, b);
     return bilinear_taps(t.texels, t.width, i0, i1, j0, j1, a, b);
 }
 // texture(skybox, d): GL face table, per-face bilinear, CLAMP_TO_EDGE, not seamless (rt.frag:893)
@@ -293,9 +332,37 @@ RT_HD f4 sample_cube(const DevCubemap& c, f3 d)
     const float t = 0.5f * (tc / ma + 1.0f);
     int i0, i1, j0, j1;
     float a, b;
-    axis_taps(s, c.size, 1, i0, i1, a);
-    axis_taps(t, c.size, 1, j0, j1, b);
+    axis_taps(s, c.size, c.fsize, 1, i0, i1, a);
+    axis_taps(t, c.size, c.fsize, 1, j0, j1, b);
     return bilinear_taps(c.texels + (size_t)face * (size_t)c.size * (size_t)c.size, c.size, i0, i1, j0, j1, a, b);
+}
+
+// The single 2-D texture fetch site. Each lane may request a fetch from a different sampler slot;
+// the wave serves one slot per pass (wave-uniform slot -> the sampler state is read with scalar
+// loads at a computed address, nothing is hoisted into long-lived registers), lanes of other slots
+// wait their turn. One inlined copy of the sampler instead of one per call site.
+RT_HD int rt_first_slot(bool pending, int slot)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m = __ballot(pending);
+    const int src = __ffsll((long long)m) - 1;
+    return __builtin_amdgcn_readlane(slot, src);
+#else
+    (void)pending;
+    return slot;
+#endif
+}
+RT_HD f4 fetch2d(const TexTable& T, bool want, int slot, float u, float v)
+{
+    f4 out = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool pending = want;
+    while (RT_ANY(pending)) {
+        const int s = rt_first_slot(pending, slot);
+        const bool mine = pending && slot == s;
+        if (mine) out = sample2d_level0(T.tex[s], u, v);
+        pending = pending && !mine;
+    }
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -347,12 +414,29 @@ RT_HD bool intersect_ring(const DevRing& R, f3 ro, f3 rd, float tmin, float& t, 
 
 // rt.frag:399-427. nor (box-space normal) is written only on a hit; NaN falls through the
 // early-outs exactly like the shader (trap T5); no t>0 test (trap T21).
-RT_HD bool intersect_box(const DevBox& B, f3 ro, f3 rd, float tmin, float& t, f3& nor)
+// Per-ray values shared by all identity-rotated boxes: for those rdd == rd bit for bit when rd is
+// "plain" (quat_rotate_id), so m = 1/rdd is the same three IEEE divisions for every such box and
+// is computed once per ray, lazily (wave-uniform flag).
+struct RayBoxCtx {
+    bool have = false;   // wave-uniform
+    bool rd_plain = false;
+    f3 inv_rd;
+};
+RT_HD bool intersect_box(const DevBox& B, f3 ro, f3 rd, float tmin, float& t, f3& nor, RayBoxCtx& ctx)
 {
     const bool ident = quat_is_identity(B.quat);
-    const f3 rdd = quat_rotate_id(B.quat, ident, rd);
+    if (ident && !ctx.have) {
+        ctx.have = true;
+        ctx.rd_plain = plain3(rd);
+        ctx.inv_rd = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    }
+    f3 rdd = rd;
+    f3 m = ctx.inv_rd;
+    if (!(ident && ctx.rd_plain)) {
+        rdd = quat_rotate(B.quat, rd);
+        m = mk3(1.0f / rdd.x, 1.0f / rdd.y, 1.0f / rdd.z);
+    }
     const f3 roo = quat_rotate_id(B.quat, ident, ro - xyz(B.pos));
-    const f3 m = mk3(1.0f / rdd.x, 1.0f / rdd.y, 1.0f / rdd.z);
     const f3 n = m * roo;
     const f3 k = mk3(fabsf(m.x), fabsf(m.y), fabsf(m.z)) * xyz(B.form_tex);
     const f3 t1 = -n - k;
@@ -451,23 +535,74 @@ RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
     const float t_in = (-b - sqrtf(gl_max(h + err, 0.0f))) / a;   // earliest possible entry (a ~ 1)
     return t_in > tlimit * 1.001f + 0.01f + 1e-5f * sqrtf(d2);
 }
-RT_HD bool torus_cull(const DevTorus& T, f3 ro, f3 rd, float tlimit)
+RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd, float tlimit)
 {
-    return sphere_cull(xyz(T.pos), T.k.y, ro, rd, gl_min(tlimit, 100.0f));
+    return sphere_cull(xyz(bound), bound.w, ro, rd, gl_min(tlimit, 100.0f));
 }
 // A ring hit lies within sqrt(r2) of the ring centre (p < r2, rt.frag:384) and needs 0 < t < tmin;
 // intersect_ring has no NaN-accepting path (all four comparisons must hold), so missing the
 // inflated sphere means "false".
-RT_HD bool ring_cull(const DevRing& R, f3 ro, f3 rd, float tlimit)
+RT_HD bool ring_cull(f4 bound, f3 ro, f3 rd, float tlimit)
 {
-    return sphere_cull(xyz(R.pos_tex), R.radii.w, ro, rd, tlimit);
+    return sphere_cull(xyz(bound), bound.w, ro, rd, tlimit);
 }
-RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
+// Second, tighter pre-test in the torus' own frame (axis = local z), after the rotation the solver
+// needs anyway. The torus lies inside the "puck" |z| <= r, x^2+y^2 <= (R+r)^2 and outside the
+// hole x^2+y^2 < (R-r)^2. true = the part of the ray with 0 < t <= tlimit never meets the
+// (1 %-inflated) puck, or crosses the puck's slab entirely inside the (deflated) hole. Margins as
+// in sphere_cull. Same premise as torus_cull: Durand-Kerner reports no root for a geometric miss.
+RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
+{
+    float t0 = 0.0f, t1 = gl_min(tlimit, 100.0f) * 1.001f + 0.01f;
+    // slab |z| <= hz
+    const float hz = T.cull.x;
+    if (d.z != 0.0f) {
+        const float ta = (-hz - o.z) / d.z, tb = (hz - o.z) / d.z;
+        t0 = gl_max(t0, gl_min(ta, tb));
+        t1 = gl_min(t1, gl_max(ta, tb));
+    } else if (fabsf(o.z) > hz) {
+        return true;
+    }
+    if (t0 > t1) return true;
+    // outer cylinder x^2 + y^2 <= Ro2
+    const float a = d.x * d.x + d.y * d.y;
+    const float b = o.x * d.x + o.y * d.y;
+    const float q = o.x * o.x + o.y * o.y;
+    const float c = q - T.k.z;
+    const float err = 1e-5f * (a * q + b * b);
+    if (a > 0.0f) {
+        const float h = b * b - a * c;
+        if (h < -err) return true;
+        const float sh = sqrtf(gl_max(h + err, 0.0f));
+        t0 = gl_max(t0, (-b - sh) / a);
+        t1 = gl_min(t1, (-b + sh) / a);
+        if (t0 > t1) return true;
+    } else if (c > 0.0f) {
+        return true;
+    }
+    // hole: radial distance^2 is convex in t, so its maximum over [t0,t1] is at an end point
+    const float hole = T.k.w;
+    if (hole > 0.0f) {
+        const float x0 = o.x + d.x * t0, y0 = o.y + d.y * t0, x1 = o.x + d.x * t1, y1 = o.y + d.y * t1;
+        if (x0 * x0 + y0 * y0 < hole && x1 * x1 + y1 * y1 < hole) return true;
+    }
+    return false;
+}
+template <bool CULL>
+RT_HD bool intersect_torus_c(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t, bool& solved)
 {
     const bool ident = quat_is_identity(T.quat);
     const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos));
     const f3 d = quat_rotate_id(T.quat, ident, rd);
+    solved = false;
+    if (CULL && torus_local_cull(T, o, d, tmin)) return false;
+    solved = true;
     return intersect_torus_local(T, o, d, tmin, t);
+}
+RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
+{
+    bool solved;
+    return intersect_torus_c<false>(T, ro, rd, tmin, t, solved);
 }
 
 // ---- general quadric (rt.frag:499-572) ----
@@ -512,7 +647,7 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
 //      the two evaluations differ by rounding only, far less than the stored margin;
 //  (2) past that branch a hit needs a point of the ray strictly inside the clip box
 //      (checkSurfaceEdges); if the ray's LINE misses the box's inflated bounding sphere there is none.
-RT_HD bool surface_cull(const DevSurface& Q, f3 ro, f3 rd)
+RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
 {
     if (!(Q.bound.w >= 0.0f)) return false;
     const float p2 = Q.sym0.x * rd.x * rd.x + Q.sym0.w * rd.y * rd.y + Q.sym1.y * rd.z * rd.z +
@@ -529,93 +664,206 @@ RT_HD bool surface_cull(const DevSurface& Q, f3 ro, f3 rd)
 // ------------------------------------------------------------------------------------------
 // closest hit (rt.frag:587-628) and any-hit (rt.frag:630-658)
 // ------------------------------------------------------------------------------------------
+// Two-level scans. Level 1 walks compact 16-byte records four at a time (ONE batched scalar load
+// per four primitives): for spheres the record is the test itself, for tori / rings / quadrics it
+// is the conservative cull predicate. Level 2 -- the exact test on the full record -- runs only
+// for primitives that at least one lane of the wave still needs (wave ballot), with the other
+// lanes masked. Order and strict-< tie breaking of rt.frag:587-628 are kept: a cull evaluated
+// with an earlier (larger) tmin only culls less.
+#define RT_UNROLL4(BODY) { { constexpr int k = 0; BODY } { constexpr int k = 1; BODY } { constexpr int k = 2; BODY } { constexpr int k = 3; BODY } }
+
 template <bool CULL, bool COUNT>
 RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt)
 {
     float tmin = RT_MAXDIST;
     float t = 0.0f;
     if (COUNT) cnt.closest++;
+    RT_PH_DECL;
     for (int i = 0; i < S.h->n_plane; i++) {
-        if (intersect_plane(ro, rd, xyz(S.planes[i].normal), xyz(S.planes[i].pos), tmin, t)) { num = i; tmin = t; type = TYPE_PLANE; }
+        if (intersect_plane(ro, rd, xyz(S.planes()[i].normal), xyz(S.planes()[i].pos), tmin, t)) { num = i; tmin = t; type = TYPE_PLANE; }
     }
-    for (int i = 0; i < S.h->n_sphere; i++) {
-        if (intersect_sphere(ro, rd, S.spheres[i].geom, S.spheres[i].hollow != 0, tmin, t)) { num = i; tmin = t; type = TYPE_SPHERE; }
+    {
+        const int n = S.h->n_sphere;
+        const f4* geom = S.sph_geom();
+        for (int i = 0; i < n; i += 4) {
+            const f4 g[4] = {geom[i], geom[i + 1], geom[i + 2], geom[i + 3]};
+            const uint32_t hb = S.sph_hollow()[i >> 5] >> (i & 31);
+            RT_UNROLL4(if (i + k < n && intersect_sphere(ro, rd, g[k], ((hb >> k) & 1u) != 0, tmin, t)) { num = i + k; tmin = t; type = TYPE_SPHERE; })
+        }
     }
-    for (int i = 0; i < S.h->n_surface; i++) {
-        if (CULL && surface_cull(S.surfaces[i], ro, rd)) continue;
-        if (intersect_surface(S.surfaces[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
+    RT_PH_LAP(cnt, PH_C_SPH);
+    {
+        const int n = S.h->n_surface;
+        const DevSurfaceCull* cullrec = S.surf_cull();
+        for (int i = 0; i < n; i += 2) {
+            bool need[2] = {true, i + 1 < n};
+            if (CULL) {
+                const DevSurfaceCull c0 = cullrec[i], c1 = cullrec[i + 1];
+                need[0] = !surface_cull(c0, ro, rd);
+                need[1] = need[1] && !surface_cull(c1, ro, rd);
+            }
+            for (int k = 0; k < 2; k++) {
+                if (RT_ANY(need[k])) {
+                    if (need[k] && intersect_surface(S.surfaces()[i + k], ro, rd, tmin, t)) { num = i + k; tmin = t; type = TYPE_SURFACE; }
+                }
+            }
+        }
     }
-    for (int i = 0; i < S.h->n_box; i++) {
-        f3 nor;
-        if (intersect_box(S.boxes[i], ro, rd, tmin, t, nor)) { num = i; tmin = t; type = TYPE_BOX; }
+    RT_PH_LAP(cnt, PH_C_SURF);
+    {
+        RayBoxCtx bctx;
+        for (int i = 0; i < S.h->n_box; i++) {
+            f3 nor;
+            if (intersect_box(S.boxes()[i], ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
+        }
     }
-    for (int i = 0; i < S.h->n_torus; i++) {
-        if (CULL && torus_cull(S.tori[i], ro, rd, tmin)) continue;
-        if (COUNT) cnt.torus_solves++;
-        if (intersect_torus(S.tori[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_TORUS; }
+    RT_PH_LAP(cnt, PH_C_BOX);
+    {
+        const int n = S.h->n_torus;
+        const f4* bound = S.torus_bound();
+        for (int i = 0; i < n; i += 4) {
+            bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
+            if (CULL) {
+                const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
+                RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd, tmin);)
+            }
+            for (int k = 0; k < 4; k++) {
+                if (RT_ANY(need[k])) {
+                    if (need[k]) {
+                        bool solved;
+                        RT_PH_BEGIN(_dk0);
+                        const bool th = intersect_torus_c<CULL>(S.tori()[i + k], ro, rd, tmin, t, solved);
+                        RT_PH_END(cnt, PH_DK, _dk0);
+                        if (COUNT && solved) cnt.torus_solves++;
+                        if (th) { num = i + k; tmin = t; type = TYPE_TORUS; }
+                    }
+                }
+            }
+        }
     }
-    for (int i = 0; i < S.h->n_ring; i++) {
-        f2 uv;
-        if (CULL && ring_cull(S.rings[i], ro, rd, tmin)) continue;
-        if (intersect_ring(S.rings[i], ro, rd, tmin, t, uv)) { num = i; tmin = t; type = TYPE_RING; }
+    RT_PH_LAP(cnt, PH_C_TORUS);
+    {
+        const int n = S.h->n_ring;
+        const f4* bound = S.ring_bound();
+        for (int i = 0; i < n; i += 4) {
+            bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
+            if (CULL) {
+                const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
+                RT_UNROLL4(need[k] = need[k] && !ring_cull(b[k], ro, rd, tmin);)
+            }
+            for (int k = 0; k < 4; k++) {
+                if (RT_ANY(need[k])) {
+                    f2 uv;
+                    if (need[k] && intersect_ring(S.rings()[i + k], ro, rd, tmin, t, uv)) { num = i + k; tmin = t; type = TYPE_RING; }
+                }
+            }
+        }
     }
+    RT_PH_LAP(cnt, PH_C_RING);
     for (int i = 0; i < S.h->n_light_point; i++) {
-        if (intersect_sphere(ro, rd, S.lights_point[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
+        if (intersect_sphere(ro, rd, S.lights_point()[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
     }
+    RT_PH_LAP(cnt, PH_C_LIGHT);
     return tmin;
 }
 
 // `on` = this lane casts the ray. Lanes stop scanning once shadow >= 1: later hits could only
 // set it to 1 or add a non-negative alpha and the result is min(shadow,1) (rt.frag:657), so the
-// early exit is exact.
+// early exit is exact. The any-hit scan is an OR (a float sum for textured rings only), so the
+// cheap classes go first; ring order is kept for the sum.
 template <bool CULL, bool COUNT>
 RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 rd, float dist, LaneCounters& cnt)
 {
     float shadow = 0.0f;
     float t = 0.0f;
     if (COUNT && on) cnt.shadow_cast++;
-    if (on) {
-        for (int i = 0; i < S.h->n_sphere; i++) {
-            if (intersect_sphere(ro, rd, S.spheres[i].geom, false, dist, t)) { shadow = 1.0f; break; }
+    if (RT_ANY(on)) {
+        const int n = S.h->n_sphere;
+        const f4* geom = S.sph_geom();
+        for (int i = 0; i < n; i += 4) {
+            const f4 g[4] = {geom[i], geom[i + 1], geom[i + 2], geom[i + 3]};
+            RT_UNROLL4(if (on && i + k < n && intersect_sphere(ro, rd, g[k], false, dist, t)) { shadow = 1.0f; on = false; })
+            if (!RT_ANY(on)) break;
         }
     }
-    on = on && shadow < 1.0f;
-    if (on) {
-        for (int i = 0; i < S.h->n_box; i++) {   // boxes before quadrics/tori: cheaper, order is irrelevant for an OR
+    if (RT_ANY(on)) {
+        RayBoxCtx bctx;
+        for (int i = 0; i < S.h->n_box; i++) {
             f3 nor;
-            if (intersect_box(S.boxes[i], ro, rd, dist, t, nor)) { shadow = 1.0f; break; }
+            if (on && intersect_box(S.boxes()[i], ro, rd, dist, t, nor, bctx)) { shadow = 1.0f; on = false; }
+            if (!RT_ANY(on)) break;
         }
     }
-    on = on && shadow < 1.0f;
-    if (on) {
-        for (int i = 0; i < S.h->n_surface; i++) {
-            if (CULL && surface_cull(S.surfaces[i], ro, rd)) continue;
-            if (intersect_surface(S.surfaces[i], ro, rd, dist, t)) { shadow = 1.0f; break; }
-        }
-    }
-    on = on && shadow < 1.0f;
-    if (on) {
-        for (int i = 0; i < S.h->n_torus; i++) {
-            if (CULL && torus_cull(S.tori[i], ro, rd, dist)) continue;
-            if (COUNT) cnt.torus_solves++;
-            if (intersect_torus(S.tori[i], ro, rd, dist, t)) { shadow = 1.0f; break; }
-        }
-    }
-    on = on && shadow < 1.0f;
-    // rings: textured rings ADD their alpha (trap T10) -- keep ring order for the float sum
-    for (int i = 0; i < S.h->n_ring; i++) {
-        f2 uv = mk2(0.0f, 0.0f);
-        const bool hit = on && !(CULL && ring_cull(S.rings[i], ro, rd, dist)) && intersect_ring(S.rings[i], ro, rd, dist, t, uv);
-        const int texnum = __builtin_bit_cast(int, S.rings[i].pos_tex.w);
-        if (texnum > 0) {
-            if (RT_ANY(hit)) {
-                const f4 c = sample2d_level0(T.tex[TEX_RING], uv.x, uv.y);
-                if (hit) shadow += c.w;
+    if (RT_ANY(on)) {
+        const int n = S.h->n_surface;
+        const DevSurfaceCull* cullrec = S.surf_cull();
+        for (int i = 0; i < n; i += 2) {
+            bool need[2] = {on, on && i + 1 < n};
+            if (CULL) {
+                const DevSurfaceCull c0 = cullrec[i], c1 = cullrec[i + 1];
+                need[0] = need[0] && !surface_cull(c0, ro, rd);
+                need[1] = need[1] && !surface_cull(c1, ro, rd);
             }
-        } else if (hit) {
-            shadow = 1.0f;
+            for (int k = 0; k < 2; k++) {
+                if (RT_ANY(need[k])) {
+                    if (need[k] && on && intersect_surface(S.surfaces()[i + k], ro, rd, dist, t)) { shadow = 1.0f; on = false; }
+                }
+            }
+            if (!RT_ANY(on)) break;
         }
-        on = on && shadow < 1.0f;
+    }
+    if (RT_ANY(on)) {
+        const int n = S.h->n_torus;
+        const f4* bound = S.torus_bound();
+        for (int i = 0; i < n; i += 4) {
+            bool need[4] = {on, on && i + 1 < n, on && i + 2 < n, on && i + 3 < n};
+            if (CULL) {
+                const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
+                RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd, dist);)
+            }
+            for (int k = 0; k < 4; k++) {
+                if (RT_ANY(need[k])) {
+                    if (need[k] && on) {
+                        bool solved;
+                        RT_PH_BEGIN(_dk0);
+                        const bool th = intersect_torus_c<CULL>(S.tori()[i + k], ro, rd, dist, t, solved);
+                        RT_PH_END(cnt, PH_DK, _dk0);
+                        if (COUNT && solved) cnt.torus_solves++;
+                        if (th) { shadow = 1.0f; on = false; }
+                    }
+                }
+            }
+            if (!RT_ANY(on)) break;
+        }
+    }
+    // rings: textured rings ADD their alpha (trap T10) -- ring order is kept for the float sum
+    if (RT_ANY(on)) {
+        const int n = S.h->n_ring;
+        const f4* bound = S.ring_bound();
+        for (int i = 0; i < n; i += 4) {
+            bool need[4] = {on, on && i + 1 < n, on && i + 2 < n, on && i + 3 < n};
+            if (CULL) {
+                const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
+                RT_UNROLL4(need[k] = need[k] && !ring_cull(b[k], ro, rd, dist);)
+            }
+            for (int k = 0; k < 4; k++) {
+                if (RT_ANY(need[k])) {
+                    f2 uv = mk2(0.0f, 0.0f);
+                    const bool hit = need[k] && on && intersect_ring(S.rings()[i + k], ro, rd, dist, t, uv);
+                    const int texnum = __builtin_bit_cast(int, S.rings()[i + k].pos_tex.w);
+                    if (texnum > 0) {
+                        if (RT_ANY(hit)) {
+                            const f4 c = sample2d_level0(T.tex[TEX_RING], uv.x, uv.y);
+                            if (hit) shadow += c.w;
+                        }
+                    } else if (hit) {
+                        shadow = 1.0f;
+                    }
+                    on = on && shadow < 1.0f;
+                }
+            }
+            if (!RT_ANY(on)) break;
+        }
     }
     return gl_min(shadow, 1.0f);
 }
@@ -641,14 +889,14 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         f3 light_color, light_dir;
         float intensity, dist, distDiv;
         if (li < n_lp) {
-            const DevLightPoint& L = S.lights_point[li];
+            const DevLightPoint& L = S.lights_point()[li];
             light_color = xyz(L.color_intensity);
             intensity = L.color_intensity.w;
             light_dir = xyz(L.pos_r2) - pt;
             dist = length3(light_dir);
             distDiv = 1.0f + L.atten.x * dist + L.atten.y * dist * dist;
         } else {
-            const DevLightDirect& L = S.lights_direct[li - n_lp];
+            const DevLightDirect& L = S.lights_direct()[li - n_lp];
             light_color = xyz(L.color_intensity);
             intensity = L.color_intensity.w;
             light_dir = -xyz(L.direction);
@@ -664,7 +912,9 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         // the shadow ray's result is unused and the ray is not cast (the reference casts it, trap T10).
         // (NaN dp must still take the full path so that it propagates like in the shader.)
         const bool cast = on && !(dp == 0.0f);
+        RT_PH_BEGIN(_sh0);
         const float sh = 1.0f - in_shadow<CULL, COUNT>(S, T, cast, pt, light_dir, dist, cnt);
+        RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
             diffuse = diffuse + (((light_color * m.color) * m.diffuse) * intensity) / distDiv;
@@ -736,44 +986,35 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
     h.surf.diffuse = 0.0f; h.surf.specular = 0; h.surf.kd = 0.0f; h.surf.ks = 0.0f;
     h.reflection = 0.0f; h.refraction = 0.0f; h.absorb = mk3(0.0f, 0.0f, 0.0f);
 
-    // ---- spheres (+ equirect texture, rt.frag:319-340) ----
-    {
-        const bool is = on && type == TYPE_SPHERE;
-        bool textured = false;
-        float u = 0.0f, v = 0.0f;
-        int texnum = 0;
-        if (is) {
-            const DevSphere& P = S.spheres[num];
-            load_material(S.mats[TYPE_SPHERE][num], h);
-            h.normal = normalize3(pt - xyz(P.geom));
-            texnum = P.texture;
-            if (texnum != 0) {
-                f3 sn = h.normal;
-                const f4 q = P.quat;
-                if (q.x != 0.0f || q.y != 0.0f || q.z != 0.0f || q.w != 1.0f) sn = quat_rotate(q, sn);
-                u = 0.5f + rt_atan2(sn.z, sn.x) / (2.0f * RT_PI_F);
-                v = 0.5f - rt_asin(sn.y) / RT_PI_F;
-                textured = true;
-            }
-        }
-        if (RT_ANY(textured)) {
-            f4 c = mk4(0.0f, 0.0f, 0.0f, 0.0f);  // texNum outside {1,2,3}: undefined in GLSL (trap T15), pinned to 0
-            if (textured) {
-                if (texnum == 1) c = sample2d_level0(T.tex[TEX_SPHERE_1], u, v);
-                if (texnum == 2) c = sample2d_level0(T.tex[TEX_SPHERE_2], u, v);
-                if (texnum == 3) c = sample2d_level0(T.tex[TEX_SPHERE_3], u, v);
-                h.surf.color = mk3(c.x, c.y, c.z);
-                h.alpha = c.w;
-            }
+    // texture request of this lane: slot < 0 = none. Boxes need three taps (tri-planar).
+    int slot = -1;
+    float u = 0.0f, v = 0.0f;
+    bool box_tex = false;
+    f3 lp = mk3(0.0f, 0.0f, 0.0f), lpos = lp, ln = lp;
+
+    if (on && type == TYPE_SPHERE) {  // + equirect texture, rt.frag:319-340
+        const DevSphere& P = S.spheres()[num];
+        load_material(S.mats(TYPE_SPHERE)[num], h);
+        h.normal = normalize3(pt - xyz(P.geom));
+        const int texnum = P.texture;
+        if (texnum != 0) {
+            f3 sn = h.normal;
+            const f4 q = P.quat;
+            if (q.x != 0.0f || q.y != 0.0f || q.z != 0.0f || q.w != 1.0f) sn = quat_rotate(q, sn);
+            u = 0.5f + rt_atan2(sn.z, sn.x) / (2.0f * RT_PI_F);
+            v = 0.5f - rt_asin(sn.y) / RT_PI_F;
+            // texNum outside {1,2,3}: `color` stays undefined in GLSL (trap T15) -- pinned to 0 here
+            if (texnum >= 1 && texnum <= 3) slot = TEX_SPHERE_1 + (texnum - 1);
+            else { h.surf.color = mk3(0.0f, 0.0f, 0.0f); h.alpha = 0.0f; }
         }
     }
     if (on && type == TYPE_PLANE) {
-        load_material(S.mats[TYPE_PLANE][num], h);
-        h.normal = normalize3(xyz(S.planes[num].normal));
+        load_material(S.mats(TYPE_PLANE)[num], h);
+        h.normal = normalize3(xyz(S.planes()[num].normal));
     }
     if (on && type == TYPE_SURFACE) {  // getSurfaceNormal rt.frag:573-584
-        const DevSurface& Q = S.surfaces[num];
-        load_material(S.mats[TYPE_SURFACE][num], h);
+        const DevSurface& Q = S.surfaces()[num];
+        load_material(S.mats(TYPE_SURFACE)[num], h);
         const bool ident = quat_is_identity(Q.quat);
         const f3 o = quat_rotate_id(Q.quat, ident, ro - xyz(Q.pos_a));
         const f3 d = quat_rotate_id(Q.quat, ident, rd);
@@ -781,40 +1022,27 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
         const f3 n = mk3(2.0f * Q.pos_a.w * tm.x, 2.0f * Q.bcde.x * tm.y + Q.bcde.w, 2.0f * Q.bcde.y * tm.z + Q.bcde.z);
         h.normal = normalize3(quat_rotate(Q.qinv, n));
     }
-    // ---- boxes (+ tri-planar texture, rt.frag:428-436) ----
-    {
-        const bool is = on && type == TYPE_BOX;
-        bool textured = false;
-        f3 lp = mk3(0.0f, 0.0f, 0.0f), lpos = lp, ln = lp;
-        if (is) {
-            const DevBox& B = S.boxes[num];
-            load_material(S.mats[TYPE_BOX][num], h);
-            float tt;
-            f3 nor = mk3(0.0f, 0.0f, 0.0f);
-            intersect_box(B, ro, rd, RT_FLT_MAX, tt, nor);  // re-derive the winning box's normal (+inf tmin: same result path)
-            h.normal = quat_rotate(B.qinv, nor);
-            if (__builtin_bit_cast(int, B.form_tex.w) != 0) {
-                lpos = quat_rotate(B.quat, xyz(B.pos));
-                lp = quat_rotate(B.quat, pt);
-                ln = quat_rotate(B.quat, h.normal);
-                textured = true;
-            }
-        }
-        if (RT_ANY(textured)) {
-            const DevTexture& tx = T.tex[TEX_BOX];
-            f4 a = mk4(0, 0, 0, 0), b = a, c = a;
-            if (textured) {
-                a = sample2d_level0(tx, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
-                b = sample2d_level0(tx, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.x - lpos.x) - 0.5f);
-                c = sample2d_level0(tx, 0.5f * (lp.x - lpos.x) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
-                const float wx = fabsf(ln.x), wy = fabsf(ln.y), wz = fabsf(ln.z);
-                h.surf.color = mk3(wx * a.x + wy * b.x + wz * c.x, wx * a.y + wy * b.y + wz * c.y, wx * a.z + wy * b.z + wz * c.z);
-            }
+    if (on && type == TYPE_BOX) {  // + tri-planar texture, rt.frag:428-436
+        const DevBox& B = S.boxes()[num];
+        load_material(S.mats(TYPE_BOX)[num], h);
+        float tt;
+        f3 nor = mk3(0.0f, 0.0f, 0.0f);
+        RayBoxCtx bctx;
+        intersect_box(B, ro, rd, RT_FLT_MAX, tt, nor, bctx);  // re-derive the winning box's normal (+inf tmin: same result path)
+        h.normal = quat_rotate(B.qinv, nor);
+        if (__builtin_bit_cast(int, B.form_tex.w) != 0) {
+            lpos = quat_rotate(B.quat, xyz(B.pos));
+            lp = quat_rotate(B.quat, pt);
+            ln = quat_rotate(B.quat, h.normal);
+            box_tex = true;
+            slot = TEX_BOX;
+            u = 0.5f * (lp.z - lpos.z) - 0.5f;
+            v = 0.5f * (lp.y - lpos.y) - 0.5f;
         }
     }
     if (on && type == TYPE_TORUS) {  // getTorusNormal rt.frag:488-496
-        const DevTorus& P = S.tori[num];
-        load_material(S.mats[TYPE_TORUS][num], h);
+        const DevTorus& P = S.tori()[num];
+        load_material(S.mats(TYPE_TORUS)[num], h);
         const bool ident = quat_is_identity(P.quat);
         const f3 o = quat_rotate_id(P.quat, ident, ro - xyz(P.pos));
         const f3 d = quat_rotate_id(P.quat, ident, rd);
@@ -823,26 +1051,33 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
         const f3 n = pos * mk3(s - P.radii.z * 1.0f, s - P.radii.z * 1.0f, s - P.radii.z * -1.0f);
         h.normal = normalize3(quat_rotate(P.qinv, n));
     }
-    // ---- rings (+ strip texture, rt.frag:391-397) ----
-    {
-        const bool is = on && type == TYPE_RING;
-        bool textured = false;
-        f2 uv = mk2(0.0f, 0.0f);
-        if (is) {
-            const DevRing& R = S.rings[num];
-            load_material(S.mats[TYPE_RING][num], h);
-            h.normal = xyz(R.normal);
-            if (__builtin_bit_cast(int, R.pos_tex.w) != 0) {
-                float tt;
-                intersect_ring(R, ro, rd, RT_FLT_MAX, tt, uv);  // re-derive opt_uv of the winning ring
-                textured = true;
-            }
+    if (on && type == TYPE_RING) {  // + strip texture, rt.frag:391-397
+        const DevRing& R = S.rings()[num];
+        load_material(S.mats(TYPE_RING)[num], h);
+        h.normal = xyz(R.normal);
+        if (__builtin_bit_cast(int, R.pos_tex.w) != 0) {
+            float tt;
+            f2 uv = mk2(0.0f, 0.0f);
+            intersect_ring(R, ro, rd, RT_FLT_MAX, tt, uv);  // re-derive opt_uv of the winning ring
+            slot = TEX_RING;
+            u = uv.x;
+            v = uv.y;
         }
-        if (RT_ANY(textured)) {
-            if (textured) {
-                const f4 c = sample2d_level0(T.tex[TEX_RING], uv.x, uv.y);
-                h.surf.color = mk3(c.x, c.y, c.z);
-                h.alpha = c.w;
+    }
+
+    // ---- texture taps (wave-uniform sites) ----
+    if (RT_ANY(slot >= 0)) {
+        const f4 c0 = fetch2d(T, slot >= 0, slot, u, v);
+        if (slot >= 0 && !box_tex) {
+            h.surf.color = mk3(c0.x, c0.y, c0.z);
+            h.alpha = c0.w;
+        }
+        if (RT_ANY(box_tex)) {
+            const f4 c1 = fetch2d(T, box_tex, TEX_BOX, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.x - lpos.x) - 0.5f);
+            const f4 c2 = fetch2d(T, box_tex, TEX_BOX, 0.5f * (lp.x - lpos.x) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
+            if (box_tex) {
+                const float wx = fabsf(ln.x), wy = fabsf(ln.y), wz = fabsf(ln.z);
+                h.surf.color = mk3(wx * c0.x + wy * c1.x + wz * c2.x, wx * c0.y + wy * c1.y + wz * c2.y, wx * c0.z + wy * c1.z + wz * c2.z);
             }
         }
     }
@@ -881,7 +1116,10 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
     float side_R = 0.0f;
 
     alive = alive && iterations > 0;
+    RT_PH_DECL;
+    RT_PH_LAP(cnt, PH_SETUP);
     while (RT_ANY(alive)) {
+        RT_PH_ADD(cnt, PH_TRIPS, 1);
         const bool is_side = side;  // what THIS trip traces
         if (alive && !is_side) segments++;
 
@@ -890,9 +1128,11 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         float tm = RT_MAXDIST;
         if (alive) tm = calc_inter<CULL, COUNT>(S, ro, rd, num, type, cnt);
         const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
+        RT_PH_LAP(cnt, PH_SCAN);
         const f3 pt = ro + rd * tm;
         Hit h;
         get_hit_info(S, T, hit, ro, rd, pt, tm, num, type, h);
+        RT_PH_LAP(cnt, PH_HITINFO);
 
         // ---- classify ----
         enum { ACT_NONE = 0, ACT_SIDE, ACT_REFLECT, ACT_DIFFUSE };
@@ -910,7 +1150,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
             if (is_side) {
                 // getReflectedColor: light sphere -> its colour; miss -> BLACK (trap T3); else one shade
                 if (type == TYPE_POINT_LIGHT) {
-                    add = (xyz(S.lights_point[num].color_intensity) * side_R) * mask;
+                    add = (xyz(S.lights_point()[num].color_intensity) * side_R) * mask;
                 } else if (hit) {
                     act = ACT_SIDE;
                     sh_pt = dot3(rd, h.normal) < 0.0f ? pt + h.normal * h.bias : pt - h.normal * h.bias;
@@ -920,7 +1160,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
                 sky = true;
                 finished = true;
             } else if (type == TYPE_POINT_LIGHT) {
-                add = xyz(S.lights_point[num].color_intensity) * mask;
+                add = xyz(S.lights_point()[num].color_intensity) * mask;
                 finished = true;
             } else {
                 const bool outside = dot3(rd, n) < 0.0f;
@@ -956,6 +1196,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
             }
         }
 
+        RT_PH_LAP(cnt, PH_CLASSIFY);
         // ---- sky fetch (wave-uniform site) ----
         if (RT_ANY(sky)) {
             if (sky) {
@@ -964,8 +1205,10 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
             }
         }
 
+        RT_PH_LAP(cnt, PH_SKY);
         // ---- the single shading site ----
         const f3 col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, sh_n, cnt);
+        RT_PH_LAP(cnt, PH_SHADE);
 
         // ---- apply + advance ----
         if (alive) {
@@ -1006,6 +1249,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
             // loop condition of the shader's for(), evaluated before the next MAIN trip
             if (finished || (!side && (i >= iterations || segments >= RT_SEGMENT_CAP))) alive = false;
         }
+        RT_PH_LAP(cnt, PH_APPLY);
     }
     return mk4(color.x, color.y, color.z, 1.0f);
 }

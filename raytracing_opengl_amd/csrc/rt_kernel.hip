@@ -16,6 +16,19 @@
 
 using namespace rtdev;
 
+#ifdef RT_PHASE_TIMERS
+__device__ unsigned long long g_phase[PH_COUNT];
+extern "C" __attribute__((visibility("default"))) int rtx_debug_phase_counters(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * PH_COUNT) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[PH_COUNT] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 namespace {
 
 __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
@@ -29,8 +42,14 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
     return q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
 }
 
+#ifndef RT_WAVES_PER_EU
+#define RT_LAUNCH_BOUNDS __launch_bounds__(256)
+#else
+#define RT_LAUNCH_BOUNDS __launch_bounds__(256, RT_WAVES_PER_EU)
+#endif
+
 template <bool CULL, bool COUNT, bool LDS>
-__global__ __launch_bounds__(256) void rt_trace_kernel(const RtLaunchParams p)
+__global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -56,9 +75,12 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(const RtLaunchParams p)
         __syncthreads();
         blob = smem;
     }
-    const SceneView S = make_view(blob);
+    const SceneView S = make_view(blob, &p.hdr);
 
-    LaneCounters cnt = {0u, 0u, 0u, 0u};
+    LaneCounters cnt = {};
+#ifdef RT_PHASE_TIMERS
+    const unsigned long long _k0 = clock64();
+#endif
     const f4 px = trace_pixel<CULL, COUNT>(S, p.tex, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
 
     if (alive) {
@@ -70,6 +92,13 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(const RtLaunchParams p)
         }
         if (p.out_u8) __builtin_nontemporal_store(pack_rgba8(px), p.out_u8 + idx);
     }
+#ifdef RT_PHASE_TIMERS
+    if (lane == 0) {
+        for (int k = 0; k < PH_COUNT - 2; k++) atomicAdd(&g_phase[k], cnt.pc.acc[k]);
+        atomicAdd(&g_phase[PH_COUNT - 2], (unsigned long long)clock64() - _k0);  // whole wave
+        atomicAdd(&g_phase[PH_COUNT - 1], 1ull);                                // waves
+    }
+#endif
     if (COUNT) {
         uint32_t v[4] = {cnt.closest, cnt.shadow_ref, cnt.shadow_cast, cnt.torus_solves};
 #pragma unroll

@@ -214,6 +214,12 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     h.off_light_direct = reserve(sizeof(DevLightDirect) * d.light_direct_size);
     const int mat_counts[6] = {d.sphere_size, d.plane_size, d.surface_size, d.box_size, d.torus_size, d.ring_size};
     for (int t = 0; t < 6; t++) h.off_mat[t] = reserve(sizeof(DevMaterial) * mat_counts[t]);
+    auto pad = [](int n, int m) { return static_cast<size_t>((n + m - 1) / m * m) + m; };  // one spare group: batched loads may run past n
+    h.off_sph_geom = reserve(sizeof(f4) * pad(d.sphere_size, 4));
+    h.off_sph_hollow = reserve(sizeof(uint32_t) * (static_cast<size_t>(d.sphere_size) / 32 + 2));
+    h.off_surf_cull = reserve(sizeof(DevSurfaceCull) * pad(d.surface_size, 2));
+    h.off_torus_bound = reserve(sizeof(f4) * pad(d.torus_size, 4));
+    h.off_ring_bound = reserve(sizeof(f4) * pad(d.ring_size, 4));
     h.total_bytes = static_cast<int32_t>(off);
     blob.assign(off, 0);
     std::memcpy(blob.data(), &h, sizeof h);
@@ -232,6 +238,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.texture = rdi(p, 96);
         s.hollow = rdi(p, 100) != 0;  // std140 bool = 4 bytes; the host writes 0/1 + zero padding
         std::memcpy(reinterpret_cast<DevSphere*>(blob.data() + h.off_sphere) + i, &s, sizeof s);
+        std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_sph_geom) + i, &s.geom, sizeof(f4));
+        if (s.hollow) reinterpret_cast<uint32_t*>(blob.data() + h.off_sph_hollow)[i >> 5] |= 1u << (i & 31);
         std::memcpy(mat_at(TYPE_SPHERE, i), p, 64);
     }
     for (int i = 0; i < d.plane_size; i++) {
@@ -245,7 +253,9 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     for (int i = 0; i < d.surface_size; i++) {
         const unsigned char* p = blocks[BLK_SURFACES].data() + static_cast<size_t>(i) * SZ_SURFACE;
         DevSurface s;
+        DevSurfaceCull sc;
         std::memset(&s, 0, sizeof s);
+        std::memset(&sc, 0, sizeof sc);
         s.quat = rd4(p, 64);
         const f3 vmin = mk3(rdf(p, 80), rdf(p, 84), rdf(p, 88)), vmax = mk3(rdf(p, 96), rdf(p, 100), rdf(p, 104));
         const float a = rdf(p, 124), b = rdf(p, 128), c = rdf(p, 132), dd = rdf(p, 136), e = rdf(p, 140), f = rdf(p, 144);
@@ -271,20 +281,21 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                 }
                 wv[r] = Rm[0][r] * ql[0] + Rm[1][r] * ql[1] + Rm[2][r] * ql[2];
             }
-            s.sym0 = mk4(static_cast<float>(A[0][0]), static_cast<float>(A[0][1]), static_cast<float>(A[0][2]), static_cast<float>(A[1][1]));
+            sc.sym0 = mk4(static_cast<float>(A[0][0]), static_cast<float>(A[0][1]), static_cast<float>(A[0][2]), static_cast<float>(A[1][1]));
             const float margin = 1e-6f + 1e-5f * (std::fabs(a) + std::fabs(b) + std::fabs(c));
-            s.sym1 = mk4(static_cast<float>(A[1][2]), static_cast<float>(A[2][2]), margin, 0.0f);
+            sc.sym1 = mk4(static_cast<float>(A[1][2]), static_cast<float>(A[2][2]), margin, 0.0f);
             const double lo[3] = {vmin.x, vmin.y, vmin.z}, hi[3] = {vmax.x, vmax.y, vmax.z};
             double clo[3], chi[3];
-            s.bound = mk4(0.0f, 0.0f, 0.0f, -1.0f);
+            sc.bound = mk4(0.0f, 0.0f, 0.0f, -1.0f);
             if (quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi)) {
                 const double cx = 0.5 * (clo[0] + chi[0]), cy = 0.5 * (clo[1] + chi[1]), cz = 0.5 * (clo[2] + chi[2]);
                 const double hx = 0.5 * (chi[0] - clo[0]), hy = 0.5 * (chi[1] - clo[1]), hz = 0.5 * (chi[2] - clo[2]);
                 const double rad = std::sqrt(hx * hx + hy * hy + hz * hz) * 1.01 + 0.01;
-                if (rad == rad && rad < 1.0e15) s.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
+                if (rad == rad && rad < 1.0e15) sc.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
             }
         }
         std::memcpy(reinterpret_cast<DevSurface*>(blob.data() + h.off_surface) + i, &s, sizeof s);
+        std::memcpy(reinterpret_cast<DevSurfaceCull*>(blob.data() + h.off_surf_cull) + i, &sc, sizeof sc);
         std::memcpy(mat_at(TYPE_SURFACE, i), p, 64);
     }
     for (int i = 0; i < d.box_size; i++) {
@@ -306,10 +317,13 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const float R2 = R * R, r2 = r * r;
         s.radii = mk4(R, r, R2, r2);
         const double rb = (std::fabs(static_cast<double>(R)) + std::fabs(static_cast<double>(r))) * 1.01 + 0.01;
-        const double rf = (100.0 + rb) * 1.001;
-        s.k = mk4(4.0f * R2, static_cast<float>(rb * rb), static_cast<float>(rf * rf), 0.0f);
+        const double hole = (std::fabs(static_cast<double>(R)) - std::fabs(static_cast<double>(r))) * 0.99 - 0.01;
+        s.k = mk4(4.0f * R2, static_cast<float>(rb * rb), static_cast<float>(rb * rb), hole > 0.0 ? static_cast<float>(hole * hole) : 0.0f);
         s.qinv = quat_inv(s.quat);
+        s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), 0.0f, 0.0f, 0.0f);
         std::memcpy(reinterpret_cast<DevTorus*>(blob.data() + h.off_torus) + i, &s, sizeof s);
+        const f4 tb = mk4(s.pos.x, s.pos.y, s.pos.z, s.k.y);
+        std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_torus_bound) + i, &tb, sizeof tb);
         std::memcpy(mat_at(TYPE_TORUS, i), p, 64);
     }
     for (int i = 0; i < d.ring_size; i++) {
@@ -323,6 +337,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const f3 nrm = quat_rotate(quat_inv(s.quat), mk3(0.0f, 0.0f, -1.0f));
         s.normal = mk4(nrm.x, nrm.y, nrm.z, 0.0f);
         std::memcpy(reinterpret_cast<DevRing*>(blob.data() + h.off_ring) + i, &s, sizeof s);
+        const f4 rbnd = mk4(s.pos_tex.x, s.pos_tex.y, s.pos_tex.z, s.radii.w);
+        std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_ring_bound) + i, &rbnd, sizeof rbnd);
         std::memcpy(mat_at(TYPE_RING, i), p, 64);
     }
     for (int i = 0; i < d.light_point_size; i++) {

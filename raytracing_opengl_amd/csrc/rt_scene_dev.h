@@ -52,9 +52,11 @@ struct alignas(16) DevSurface {
     f4 f_vmin;         // f, v_min xyz (world-space clip box, trap T6)
     f4 vmax;           // v_max xyz, w unused
     f4 qinv;           // quat_inv(quat)
+};
+struct alignas(16) DevSurfaceCull {  // first-level record of a quadric (surface_cull)
     f4 bound;          // cull sphere of the CLIPPED surface: centre xyz (world), w = radius^2 (inflated); w < 0: unbounded
     f4 sym0;           // symmetric M = R^T diag(a,b,c) R : m00, m01, m02, m11
-    f4 sym1;           // m12, m22, |p2| margin, unused        (p2 ~ d^T M d, see surface_cull)
+    f4 sym1;           // m12, m22, |p2| margin, unused        (p2 ~ d^T M d)
 };
 struct alignas(16) DevBox {
     f4 quat;
@@ -66,8 +68,9 @@ struct alignas(16) DevTorus {
     f4 quat;
     f4 pos;            // xyz
     f4 radii;          // R, r, R*R, r*r
-    f4 k;              // x = 4*R*R, y = cull radius^2 (inflated), z = far-origin radius^2 ((100+R+r) inflated), w unused
+    f4 k;              // x = 4*R*R, y = world cull-sphere radius^2, z = puck radius^2 ((R+r) inflated), w = hole radius^2 ((R-r) deflated, 0 = none)
     f4 qinv;
+    f4 cull;           // x = puck half height (r inflated), yzw unused
 };
 struct alignas(16) DevRing {
     f4 quat;
@@ -97,6 +100,14 @@ struct alignas(16) DevSceneHeader {
     uint32_t off_sphere, off_plane, off_surface, off_box;
     uint32_t off_torus, off_ring, off_light_point, off_light_direct;
     uint32_t off_mat[8];  // materials per PrimType 0..5 (6,7 unused)
+    // first-level ("cull") arrays: 16-byte records scanned 4 at a time with one batched scalar load.
+    // Each is padded with zero records to a multiple of 4 entries (surf_cull: of 2).
+    uint32_t off_sph_geom;     // f4 per sphere: centre, r*r  (the sphere test itself)
+    uint32_t off_sph_hollow;   // uint32 bit per sphere (bit i&31 of word i>>5)
+    uint32_t off_surf_cull;    // DevSurfaceCull per quadric
+    uint32_t off_torus_bound;  // f4 per torus: centre, inflated bounding radius^2
+    uint32_t off_ring_bound;   // f4 per ring:  centre, inflated outer radius^2
+    uint32_t _pad[3];
 };
 
 // ---- textures --------------------------------------------------------------------------------
@@ -110,12 +121,14 @@ struct DevTexture {
     int32_t width, height;
     int32_t wrap;            // 0 REPEAT, 1 CLAMP_TO_EDGE
     int32_t levels;
+    float fwidth, fheight;   // (float)width, (float)height: kept as scalars instead of per-lane conversions
     uint32_t level_off[MAX_MIPS];  // dword offset of each mip level
 };
 struct DevCubemap {
     const uint32_t* texels;  // 6 faces back to back (+X,-X,+Y,-Y,+Z,-Z), each size*size dwords
     int32_t size;
     int32_t face_mask;       // bit f set = face present (a missing face samples black)
+    float fsize;             // (float)size
 };
 
 }  // namespace rtdev

@@ -168,6 +168,8 @@ void fill_tex_table(rtx_context* ctx, TexTable& T)
         d.width = t.width;
         d.height = t.height;
         d.wrap = t.wrap;
+        d.fwidth = static_cast<float>(t.width);
+        d.fheight = static_cast<float>(t.height);
         d.levels = ctx->opt_lod ? t.levels : 1;
         std::memcpy(d.level_off, t.level_off, sizeof d.level_off);
     }
@@ -177,6 +179,7 @@ void fill_tex_table(rtx_context* ctx, TexTable& T)
         if (it != ctx->textures.end() && it->second.cube) {
             T.sky.texels = it->second.d_texels;
             T.sky.size = it->second.width;
+            T.sky.fsize = static_cast<float>(it->second.width);
             T.sky.face_mask = it->second.face_mask;
         }
     }
@@ -214,6 +217,7 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     }
     RtLaunchParams p;
     std::memset(&p, 0, sizeof p);
+    std::memcpy(&p.hdr, ctx->blob.data(), sizeof p.hdr);
     p.scene = ctx->d_scene;
     p.scene_bytes = ctx->scene_bytes;
     p.fb_w = ctx->width;

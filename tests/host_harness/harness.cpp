@@ -52,6 +52,7 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
             rtpack::to_rgba8(t.texels, t.width, t.height, t.channels, keep.back().data());
             T.tex[s].texels = keep.back().data();
             T.tex[s].width = t.width; T.tex[s].height = t.height; T.tex[s].wrap = t.wrap; T.tex[s].levels = 1;
+            T.tex[s].fwidth = (float)t.width; T.tex[s].fheight = (float)t.height;
         }
     }
     if (fr->sky_size > 0) {
@@ -62,6 +63,7 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
             if (fr->sky_faces[f]) { rtpack::to_rgba8(fr->sky_faces[f], fr->sky_size, fr->sky_size, fr->sky_channels, keep.back().data() + fsz * f); mask |= 1 << f; }
         T.sky.texels = keep.back().data();
         T.sky.size = fr->sky_size;
+        T.sky.fsize = (float)fr->sky_size;
         T.sky.face_mask = mask;
     }
     uint64_t tot[4] = {0, 0, 0, 0};
@@ -108,10 +110,10 @@ int harness_kat(int type, const void* record, const float ro[3], const float rd[
     bool hit = false, cull = false;
     f3 nor = mk3(0, 0, 0);
     f2 uv = mk2(0, 0);
-    if (type == TYPE_SURFACE) { cull = surface_cull(S.surfaces[0], o, dd); hit = intersect_surface(S.surfaces[0], o, dd, tmin, t); }
-    if (type == TYPE_BOX) { hit = intersect_box(S.boxes[0], o, dd, tmin, t, nor); }
-    if (type == TYPE_TORUS) { cull = torus_cull(S.tori[0], o, dd, tmin); hit = intersect_torus(S.tori[0], o, dd, tmin, t); }
-    if (type == TYPE_RING) { cull = ring_cull(S.rings[0], o, dd, tmin); hit = intersect_ring(S.rings[0], o, dd, tmin, t, uv); }
+    if (type == TYPE_SURFACE) { cull = surface_cull(S.surf_cull()[0], o, dd); hit = intersect_surface(S.surfaces()[0], o, dd, tmin, t); }
+    if (type == TYPE_BOX) { RayBoxCtx bctx; hit = intersect_box(S.boxes()[0], o, dd, tmin, t, nor, bctx); }
+    if (type == TYPE_TORUS) { bool solved; cull = torus_cull(S.torus_bound()[0], o, dd, tmin); if (!cull) { float t2; intersect_torus_c<true>(S.tori()[0], o, dd, tmin, t2, solved); cull = !solved; } hit = intersect_torus(S.tori()[0], o, dd, tmin, t); }
+    if (type == TYPE_RING) { cull = ring_cull(S.ring_bound()[0], o, dd, tmin); hit = intersect_ring(S.rings()[0], o, dd, tmin, t, uv); }
     out[0] = hit ? 1.0f : 0.0f;
     out[1] = t;
     out[2] = cull ? 1.0f : 0.0f;
