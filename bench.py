@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds", type=int, default=0)
     ap.add_argument("--cull", type=int, default=1)
+    ap.add_argument("--lod", type=int, default=1, help="1: mip chain + quad-derivative LOD (reference texture state); 0: level-0 bilinear")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,7 +71,7 @@ def main():
     W, H = args.width, args.height
     sc = scenes.build_scene(args.scene, W, H, args.depth)
     ts = textures.default_texture_set(scale=args.texture_scale)
-    gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank)
+    gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank, texture_lod=args.lod)
     gl.set_option(wrapper.RTX_OPT_CULL, args.cull)
     gl.set_option(wrapper.RTX_OPT_SCENE_LDS, args.lds)
 
@@ -156,7 +157,7 @@ def main():
                                    f"RGBA32F target, seeded synthetic textures at reference sizes/{args.texture_scale}",
                        "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
                        "parallelism": "single GPU" if world == 1 else f"{world} GPUs, interleaved {band_rows}-row bands, RCCL gather to rank 0",
-                       "cull": args.cull, "scene_in_lds": args.lds},
+                       "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod},
             "ms_per_frame": round(ms_per_step, 4),
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -171,7 +172,7 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
-            o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"])
+            o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod)
             cores = os.cpu_count() or 1
             cpu_s, reps = 0.0, 0
             while cpu_s < 10.0 and reps < 20:   # bounded sample: whole frames until >= 10 s of wall time

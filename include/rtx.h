@@ -68,7 +68,8 @@ typedef enum rtx_option {
                                 quadric / box / ring tests (parity-gated); 0: literal scans */
     RTX_OPT_COUNT_RAYS = 1,  /* 1: kernel also counts closest-hit and shadow rays (rtx_stats) */
     RTX_OPT_SCENE_LDS = 2,   /* 1: stage the scene tables into LDS per workgroup; 0: scalar (SMEM) loads */
-    RTX_OPT_TEXTURE_LOD = 3  /* 0: level-0 bilinear everywhere; 1: mip chain + quad-derivative LOD */
+    RTX_OPT_TEXTURE_LOD = 3  /* 1 (default): mip chain + trilinear + quad-derivative LOD, the reference's texture
+                                state (GLWrapper.cpp:337-343, rt.frag:326-338); 0: level-0 bilinear everywhere */
 } rtx_option;
 
 typedef struct rtx_stats {

@@ -93,7 +93,7 @@ def lib():
 class OracleScene:
     """Holds one frame description (blocks + textures) alive for orc_render calls."""
 
-    def __init__(self, scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, texture_lod: int = 0):
+    def __init__(self, scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, texture_lod: int = 1):
         """scene_blocks: object with .defines (15-tuple) and .blocks (name -> bytes);
         textures: iterable of (sampler_uniform_name, unit, HxWxC uint8 array); cubemap: six NxNxC uint8 arrays."""
         self._keep = []

@@ -22,9 +22,9 @@
  *     dot = x*x' + y*y' + z*z' (left to right), length = sqrt(dot), normalize = v / length(v),
  *     reflect = I - 2*dot(N,I)*N, refract per spec, min(a,b) = b<a?b:a, max(a,b) = a<b?b:a,
  *     clamp = min(max(x,lo),hi), step(e,x) = x<e?0:1, sign;
- *   - pow/exp/log2 use libm (continuous in their inputs; differences vs the device are ~1 ulp);
- *   - atan/asin (equirect uv, :323-324) use the fixed float64 series below so that texture
- *     coordinates are bit-reproducible;
+ *   - pow/exp use libm (they only shape colours; differences vs the device are ~1 ulp);
+ *   - atan/asin (equirect uv, :323-324) and log2 (texture LOD) use the fixed float64 series below so
+ *     that texel addresses, blend weights and the alpha they produce are bit-reproducible;
  *   - texture filtering, which GL leaves implementation-defined, follows DESIGN.md "Texture rule".
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared).
@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ucontext.h>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -176,6 +177,11 @@ typedef struct {
     vec2 opt_uv;     /* :149 */
     float frag_x, frag_y; /* gl_FragCoord.xy */
     orc_counters* cnt;
+    /* texture_lod == 1: this invocation runs as one of the 4 coroutines of a 2x2 pixel quad */
+    int step;             /* closest-hit rays traced so far by this pixel = lock-step index (DESIGN.md texture rule) */
+    int light_index;      /* which light calcShade is processing (part of the fetch key) */
+    struct quad_s* quad;  /* NULL when texture_lod == 0 */
+    int quad_slot;        /* 0..3: bit0 = x&1, bit1 = y&1 */
 } inv_t;
 
 /* ---------------------------------------------------------------------------------------------
@@ -340,6 +346,210 @@ static vec4 sample_cube(const orc_cubemap* c, vec3 d)
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * Texture rule, phase B: mip chain, trilinear, quad-derivative LOD (DESIGN.md "Texture rule";
+ * SURVEY.md Appendix E). GL leaves all of this implementation-defined; the rule is:
+ *  - mips: RGBA8, level L is max(1,w>>L) x max(1,h>>L); a texel is the rounded integer mean
+ *    ((a+b+c+d+2)>>2) of the source texels (min(2i,ws-1), min(2i+1,ws-1)) x (same in j);
+ *  - lambda <= 0 (or NaN): level-0 bilinear; else levels floor(lambda), +1 (clamped to the last),
+ *    blended (1-f)*c0 + f*c1 with f = lambda - floor(lambda);
+ *  - explicit LOD of getSphereTexture (:326-338): lambda = log2(max(df.x,df.y)*1024),
+ *    df = |dFdx uv| + |dFdy uv|, df.x zeroed when > 0.5;
+ *  - implicit LOD of texture() (ring :396,647; box :433-435): lambda = log2(max(|d(uv*size)/dx|, |d(uv*size)/dy|));
+ *  - derivatives are differences inside the 2x2 pixel quad (aligned to even pixel coordinates):
+ *    dFdx = right - left in the pixel's row, dFdy = top - bottom in its column; a neighbour counts only
+ *    if, at the same lock-step index, it executes the same fetch (same site, light, ring, tap) of the
+ *    same sampler on the same primitive; otherwise that axis' derivative is 0;
+ *  - pixels of a quad that fall outside an odd-sized framebuffer run as helper invocations.
+ * ------------------------------------------------------------------------------------------- */
+#define ORC_MAX_MIPS 15
+typedef struct {
+    const uint8_t* key_texels; int key_w, key_h, key_c;
+    int levels; int w[ORC_MAX_MIPS], h[ORC_MAX_MIPS];
+    uint8_t* data[ORC_MAX_MIPS]; /* RGBA8 */
+} orc_mipchain;
+static orc_mipchain g_mips[16];
+static int g_mips_n = 0;
+
+static const orc_mipchain* mip_get(const orc_texture* t)
+{
+    if (t->width <= 0 || !t->texels) return NULL;
+    for (int k = 0; k < g_mips_n; k++)
+        if (g_mips[k].key_texels == t->texels && g_mips[k].key_w == t->width && g_mips[k].key_h == t->height && g_mips[k].key_c == t->channels) return &g_mips[k];
+    if (g_mips_n == 16) { /* recycle the oldest */
+        for (int l = 0; l < g_mips[0].levels; l++) free(g_mips[0].data[l]);
+        memmove(&g_mips[0], &g_mips[1], 15 * sizeof g_mips[0]);
+        g_mips_n = 15;
+    }
+    orc_mipchain* m = &g_mips[g_mips_n++];
+    memset(m, 0, sizeof *m);
+    m->key_texels = t->texels; m->key_w = t->width; m->key_h = t->height; m->key_c = t->channels;
+    int w = t->width, h = t->height;
+    m->w[0] = w; m->h[0] = h;
+    m->data[0] = (uint8_t*)malloc((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const uint8_t* p = t->texels + i * t->channels;
+        uint8_t* o = m->data[0] + i * 4;
+        if (t->channels == 4) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
+        else if (t->channels == 3) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 255; }
+        else { o[0] = p[0]; o[1] = 0; o[2] = 0; o[3] = 255; }
+    }
+    int L = 0;
+    while ((w > 1 || h > 1) && L + 1 < ORC_MAX_MIPS) {
+        const int ws = w, hs = h;
+        w = w > 1 ? w >> 1 : 1;
+        h = h > 1 ? h >> 1 : 1;
+        L++;
+        m->w[L] = w; m->h[L] = h;
+        m->data[L] = (uint8_t*)malloc((size_t)w * h * 4);
+        const uint8_t* src = m->data[L - 1];
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                int i0 = 2 * i < ws - 1 ? 2 * i : ws - 1, i1 = 2 * i + 1 < ws - 1 ? 2 * i + 1 : ws - 1;
+                int j0 = 2 * j < hs - 1 ? 2 * j : hs - 1, j1 = 2 * j + 1 < hs - 1 ? 2 * j + 1 : hs - 1;
+                for (int c = 0; c < 4; c++) {
+                    int sum = src[((size_t)j0 * ws + i0) * 4 + c] + src[((size_t)j0 * ws + i1) * 4 + c] + src[((size_t)j1 * ws + i0) * 4 + c] +
+                              src[((size_t)j1 * ws + i1) * 4 + c];
+                    m->data[L][((size_t)j * w + i) * 4 + c] = (uint8_t)((sum + 2) >> 2);
+                }
+            }
+    }
+    m->levels = L + 1;
+    return m;
+}
+
+static vec4 sample_mip_level(const orc_mipchain* m, int level, int wrap, vec2 uv)
+{
+    orc_texture t;
+    t.width = m->w[level]; t.height = m->h[level]; t.channels = 4; t.wrap = wrap; t.texels = m->data[level];
+    return sample2d_level0(&t, uv);
+}
+static vec4 sample2d_lod(const orc_texture* t, vec2 uv, float lambda)
+{
+    const orc_mipchain* m = mip_get(t);
+    if (!m) return v4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (!(lambda > 0.0f)) return sample_mip_level(m, 0, t->wrap, uv); /* magnification, -inf and NaN */
+    const float top = (float)(m->levels - 1);
+    if (lambda > top) lambda = top;
+    const float fl = floorf(lambda);
+    const int l0 = (int)fl;
+    const float f = lambda - fl;
+    const vec4 c0 = sample_mip_level(m, l0, t->wrap, uv);
+    if (l0 + 1 > m->levels - 1) return c0;
+    const vec4 c1 = sample_mip_level(m, l0 + 1, t->wrap, uv);
+    return v4((1.0f - f) * c0.x + f * c1.x, (1.0f - f) * c0.y + f * c1.y, (1.0f - f) * c0.z + f * c1.z, (1.0f - f) * c0.w + f * c1.w);
+}
+
+/* log2 of the LOD rule: a fixed float64 sequence (exponent split, then ln(m) = 2 atanh((m-1)/(m+1)) as a
+ * 10-term series, times 1/ln 2), rounded once to float -- so that the trilinear blend weight, and through a
+ * blended alpha the `alpha < 1` pass-through decision (:884), are bit-reproducible across libm / device. */
+static float orc_log2(float xf)
+{
+    if (!(xf > 0.0f)) return xf == 0.0f ? -INFINITY : NAN;
+    if (xf > 3.0e38f) return INFINITY;
+    double x = (double)xf;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ffu) - 1023;
+    uint64_t mb = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    memcpy(&m, &mb, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double z = (m - 1.0) / (m + 1.0);
+    double z2 = z * z;
+    double p = 1.0 / 19.0;
+    p = 1.0 / 17.0 + z2 * p;
+    p = 1.0 / 15.0 + z2 * p;
+    p = 1.0 / 13.0 + z2 * p;
+    p = 1.0 / 11.0 + z2 * p;
+    p = 1.0 / 9.0 + z2 * p;
+    p = 1.0 / 7.0 + z2 * p;
+    p = 1.0 / 5.0 + z2 * p;
+    p = 1.0 / 3.0 + z2 * p;
+    p = 1.0 + z2 * p;
+    double ln_m = 2.0 * z * p;
+    return (float)((double)e + ln_m * 1.4426950408889634074);
+}
+
+/* ---- 2x2 quad lock-step machinery ---- */
+enum { SITE_HIT = 0, SITE_SHADOW = 1 };
+enum { LOD_EXPLICIT_SPHERE = 0, LOD_IMPLICIT = 1 };
+typedef struct { int step, site, a, b, slot, ptype, pnum; } fetch_key;
+typedef struct {
+    int active;      /* pixel exists in this quad (inside the even-rounded framebuffer) */
+    int done;
+    int waiting;
+    fetch_key key;
+    vec2 uv;
+    int mode;
+    vec4 result;
+    ucontext_t ctx;
+    inv_t iv;
+    vec4 color;
+    char* stack;
+} quad_lane;
+typedef struct quad_s {
+    quad_lane lane[4];
+    ucontext_t sched;
+    int current;
+} quad_t;
+
+static int key_cmp(const fetch_key* p, const fetch_key* q)
+{
+    const int* a = (const int*)p; const int* b = (const int*)q;
+    for (int k = 0; k < 7; k++) { if (a[k] < b[k]) return -1; if (a[k] > b[k]) return 1; }
+    return 0;
+}
+
+/* texture fetch as seen by the pixel program */
+static vec4 tex_fetch(inv_t* iv, int slot, int site, int a, int b, int ptype, int pnum, vec2 uv, int mode)
+{
+    const orc_texture* t = &iv->fr->tex[slot];
+    if (!iv->quad) return sample2d_level0(t, uv); /* texture_lod == 0 */
+    quad_t* q = iv->quad;
+    quad_lane* me = &q->lane[iv->quad_slot];
+    me->key.step = iv->step; me->key.site = site; me->key.a = a; me->key.b = b; me->key.slot = slot; me->key.ptype = ptype; me->key.pnum = pnum;
+    me->uv = uv;
+    me->mode = mode;
+    me->waiting = 1;
+    swapcontext(&me->ctx, &q->sched); /* yield; the scheduler fills me->result */
+    return me->result;
+}
+
+static void quad_resolve(quad_t* q, const orc_frame* fr)
+{
+    /* smallest pending key */
+    int first = -1;
+    for (int k = 0; k < 4; k++)
+        if (q->lane[k].active && q->lane[k].waiting && (first < 0 || key_cmp(&q->lane[k].key, &q->lane[first].key) < 0)) first = k;
+    const fetch_key key = q->lane[first].key;
+    int in_set[4];
+    for (int k = 0; k < 4; k++) in_set[k] = q->lane[k].active && q->lane[k].waiting && key_cmp(&q->lane[k].key, &key) == 0;
+    vec4 res[4];
+    for (int k = 0; k < 4; k++) {
+        if (!in_set[k]) continue;
+        const int kx = k ^ 1, ky = k ^ 2; /* bit0 = x&1, bit1 = y&1 */
+        vec2 ddx = v2(0.0f, 0.0f), ddy = v2(0.0f, 0.0f);
+        if (in_set[kx]) { const quad_lane* r = &q->lane[k | 1]; const quad_lane* l = &q->lane[k & ~1]; ddx = v2(r->uv.x - l->uv.x, r->uv.y - l->uv.y); }
+        if (in_set[ky]) { const quad_lane* tp = &q->lane[k | 2]; const quad_lane* bt = &q->lane[k & ~2]; ddy = v2(tp->uv.x - bt->uv.x, tp->uv.y - bt->uv.y); }
+        const orc_texture* t = &fr->tex[key.slot];
+        float lambda;
+        if (q->lane[k].mode == LOD_EXPLICIT_SPHERE) {
+            vec2 df = v2(fabsf(ddx.x) + fabsf(ddy.x), fabsf(ddx.y) + fabsf(ddy.y)); /* fwidth(uv), :326 */
+            if (df.x > 0.5f) df.x = 0.0f;                                          /* :327 */
+            lambda = orc_log2(gl_max(df.x, df.y) * 1024.0f);                       /* :331 */
+        } else {
+            const float w = (float)t->width, h = (float)t->height;
+            const float rx = sqrtf((ddx.x * w) * (ddx.x * w) + (ddx.y * h) * (ddx.y * h));
+            const float ry = sqrtf((ddy.x * w) * (ddy.x * w) + (ddy.y * h) * (ddy.y * h));
+            lambda = orc_log2(gl_max(rx, ry));
+        }
+        res[k] = sample2d_lod(t, q->lane[k].uv, lambda);
+    }
+    for (int k = 0; k < 4; k++)
+        if (in_set[k]) { q->lane[k].result = res[k]; q->lane[k].waiting = 0; }
+}
+
+/* ---------------------------------------------------------------------------------------------
  * rt.frag functions, in file order
  * ------------------------------------------------------------------------------------------- */
 static inline void swapf(float* a, float* b) { float tmp = *a; *a = *b; *b = tmp; } /* :273-278 */
@@ -380,17 +590,16 @@ static vec3 getRayDir(const inv_t* iv) /* :313-317 */
     return normalize3(rotate(iv->scene->quat_camera_rotation, result));
 }
 
-static vec4 getSphereTexture(inv_t* iv, vec3 sphereNormal, vec4 quat, int texNum) /* :319-340 */
+static vec4 getSphereTexture(inv_t* iv, vec3 sphereNormal, vec4 quat, int texNum, int sphereNum) /* :319-340 */
 {
     if (quat.x != 0.0f || quat.y != 0.0f || quat.z != 0.0f || quat.w != 1.0f) sphereNormal = rotate(quat, sphereNormal);
     float u = 0.5f + orc_atan2(sphereNormal.z, sphereNormal.x) / (2.0f * PI_F);
     float v = 0.5f - orc_asin(sphereNormal.y) / PI_F;
     vec2 uv = v2(u, v);
-    /* texture_lod == 0: level 0 (DESIGN.md texture rule, phase A) */
+    /* df = fwidth(uv), the seam fix and textureLod(..., log2(max(df.x,df.y)*1024)) (:326-338) happen in
+     * tex_fetch/quad_resolve, which see the whole 2x2 quad; with texture_lod == 0 the fetch is level-0 bilinear */
     vec4 color = v4(0.0f, 0.0f, 0.0f, 0.0f); /* texNum not in {1,2,3}: undefined in GLSL (T15); pinned to 0 */
-    if (texNum == 1) color = sample2d_level0(&iv->fr->tex[ORC_TEX_SPHERE_1], uv);
-    if (texNum == 2) color = sample2d_level0(&iv->fr->tex[ORC_TEX_SPHERE_2], uv);
-    if (texNum == 3) color = sample2d_level0(&iv->fr->tex[ORC_TEX_SPHERE_3], uv);
+    if (texNum >= 1 && texNum <= 3) color = tex_fetch(iv, ORC_TEX_SPHERE_1 + (texNum - 1), SITE_HIT, 0, 0, TYPE_SPHERE, sphereNum, uv, LOD_EXPLICIT_SPHERE);
     return color;
 }
 
@@ -440,10 +649,9 @@ static vec3 getRingNormal(const inv_t* iv, int num) /* :391-394 */
 {
     return rotate(quat_inv(iv->rings[num].quat_rotation), v3(0.0f, 0.0f, -1.0f));
 }
-static vec4 getRingTexture(inv_t* iv, int num, vec2 uv) /* :395-397 */
+static vec4 getRingTexture(inv_t* iv, int site, int light, int ringNum, vec2 uv) /* :395-397 */
 {
-    (void)num;
-    return sample2d_level0(&iv->fr->tex[ORC_TEX_RING], uv);
+    return tex_fetch(iv, ORC_TEX_RING, site, light, ringNum, TYPE_RING, ringNum, uv, LOD_IMPLICIT);
 }
 
 static int intersectBox(inv_t* iv, vec3 ro, vec3 rd, int num, float tmin, float* t) /* :399-427 */
@@ -476,10 +684,9 @@ static vec4 getBoxTexture(inv_t* iv, vec3 pt, vec3 normal, int num) /* :428-436 
     vec3 pos = rotate(box->quat_rotation, box->pos);
     pt = rotate(box->quat_rotation, pt);
     normal = rotate(box->quat_rotation, normal);
-    const orc_texture* tx = &iv->fr->tex[ORC_TEX_BOX];
-    vec4 a = sample2d_level0(tx, v2(0.5f * (pt.z - pos.z) - 0.5f, 0.5f * (pt.y - pos.y) - 0.5f));
-    vec4 b = sample2d_level0(tx, v2(0.5f * (pt.z - pos.z) - 0.5f, 0.5f * (pt.x - pos.x) - 0.5f));
-    vec4 c = sample2d_level0(tx, v2(0.5f * (pt.x - pos.x) - 0.5f, 0.5f * (pt.y - pos.y) - 0.5f));
+    vec4 a = tex_fetch(iv, ORC_TEX_BOX, SITE_HIT, 0, 0, TYPE_BOX, num, v2(0.5f * (pt.z - pos.z) - 0.5f, 0.5f * (pt.y - pos.y) - 0.5f), LOD_IMPLICIT);
+    vec4 b = tex_fetch(iv, ORC_TEX_BOX, SITE_HIT, 1, 0, TYPE_BOX, num, v2(0.5f * (pt.z - pos.z) - 0.5f, 0.5f * (pt.x - pos.x) - 0.5f), LOD_IMPLICIT);
+    vec4 c = tex_fetch(iv, ORC_TEX_BOX, SITE_HIT, 2, 0, TYPE_BOX, num, v2(0.5f * (pt.x - pos.x) - 0.5f, 0.5f * (pt.y - pos.y) - 0.5f), LOD_IMPLICIT);
     float wx = fabsf(normal.x), wy = fabsf(normal.y), wz = fabsf(normal.z);
     return v4(wx * a.x + wy * b.x + wz * c.x, wx * a.y + wy * b.y + wz * c.y, wx * a.z + wy * b.z + wz * c.z,
               wx * a.w + wy * b.w + wz * c.w);
@@ -616,6 +823,7 @@ static float calcInter(inv_t* iv, vec3 ro, vec3 rd, int* num, int* type) /* :587
     float t = 0.0f;
     int i;
     iv->cnt->rays_closest++;
+    iv->step++;
     for (i = 0; i < iv->PLANE_SIZE; i++) {
         iv->cnt->tests[TYPE_PLANE]++;
         if (intersectPlane(ro, rd, iv->planes[i].normal, iv->planes[i].pos, tmin, &t)) { *num = i; tmin = t; *type = TYPE_PLANE; }
@@ -673,7 +881,7 @@ static float inShadow(inv_t* iv, vec3 ro, vec3 rd, float dist) /* :630-658 */
         iv->cnt->tests[TYPE_RING]++;
         if (intersectRing(iv, ro, rd, i, dist, &t)) {
             const rt_ring* ring = &iv->rings[i];
-            if (ring->textureNum > 0) shadow += getRingTexture(iv, ring->textureNum, iv->opt_uv).w;
+            if (ring->textureNum > 0) shadow += getRingTexture(iv, SITE_SHADOW, iv->light_index, i, iv->opt_uv).w;
             else shadow = 1.0f;
         }
     }
@@ -714,6 +922,7 @@ static vec3 calcShade(inv_t* iv, vec3 pt, vec3 rd, const rt_material* material, 
         light_dir = sub3(v3(light->pos.x, light->pos.y, light->pos.z), pt);
         dist = length3(light_dir);
         distDiv = 1.0f + light->linear_k * dist + light->quadratic_k * dist * dist;
+        iv->light_index = i;
         calcShade2(iv, light_dir, light_color, light->intensity, pt, rd, material, normal, doShadow, dist, distDiv, &diffuse, &specular);
     }
     for (i = 0; i < iv->LIGHT_DIRECT_SIZE; i++) {
@@ -721,6 +930,7 @@ static vec3 calcShade(inv_t* iv, vec3 pt, vec3 rd, const rt_material* material, 
         light_dir = neg3(iv->lights_direct[i].direction);
         dist = maxDist;
         distDiv = 1.0f;
+        iv->light_index = iv->LIGHT_POINT_SIZE + i;
         calcShade2(iv, light_dir, light_color, iv->lights_direct[i].intensity, pt, rd, material, normal, doShadow, dist, distDiv, &diffuse,
                    &specular);
     }
@@ -762,7 +972,7 @@ static hit_record get_hit_info(inv_t* iv, vec3 ro, vec3 rd, vec3 pt, float t, in
         hr.bias_mult = 0.0f;
         hr.alpha = 1.0f;
         if (sphere->textureNum != 0) {
-            vec4 texColor = getSphereTexture(iv, hr.normal, sphere->quat_rotation, sphere->textureNum);
+            vec4 texColor = getSphereTexture(iv, hr.normal, sphere->quat_rotation, sphere->textureNum, num);
             hr.mat.color = v3(texColor.x, texColor.y, texColor.z);
             hr.alpha = texColor.w;
         }
@@ -798,7 +1008,7 @@ static hit_record get_hit_info(inv_t* iv, vec3 ro, vec3 rd, vec3 pt, float t, in
         hr.normal = getRingNormal(iv, num);
         hr.alpha = 1.0f;
         if (ring->textureNum != 0) {
-            vec4 texColor = getRingTexture(iv, ring->textureNum, iv->opt_uv);
+            vec4 texColor = getRingTexture(iv, SITE_HIT, 0, num, iv->opt_uv);
             hr.mat.color = v3(texColor.x, texColor.y, texColor.z);
             hr.alpha = texColor.w;
         }
@@ -947,6 +1157,69 @@ static void inv_init(inv_t* iv, const orc_frame* fr, orc_counters* cnt)
     iv->cnt = cnt;
 }
 
+/* ---- quad execution (texture_lod == 1) ---- */
+static __thread quad_t* tls_quad;
+static void lane_entry(void)
+{
+    quad_t* q = tls_quad;
+    quad_lane* L = &q->lane[q->current];
+    L->color = shade_pixel(&L->iv);
+    L->done = 1; /* returning resumes q->sched through uc_link */
+}
+#define ORC_CORO_STACK (256 * 1024)
+
+static void render_quad(quad_t* q, const inv_t* base, const orc_frame* fr, int qx, int qy, int y0, int y1, float* out_rgba, orc_counters* local,
+                        orc_counters* discard)
+{
+    for (int k = 0; k < 4; k++) {
+        quad_lane* L = &q->lane[k];
+        const int x = 2 * qx + (k & 1), y = 2 * qy + (k >> 1);
+        L->active = 1; /* inside the even-rounded framebuffer by construction: helper invocation if outside the real one */
+        L->done = 0;
+        L->waiting = 0;
+        L->iv = *base;
+        const int stored = x < fr->fb_width && y < fr->fb_height && y >= y0 && y < y1;
+        L->iv.cnt = stored ? local : discard;
+        L->iv.quad = q;
+        L->iv.quad_slot = k;
+        L->iv.step = 0;
+        L->iv.frag_x = (float)x + 0.5f;
+        L->iv.frag_y = (float)y + 0.5f;
+        getcontext(&L->ctx);
+        L->ctx.uc_stack.ss_sp = L->stack;
+        L->ctx.uc_stack.ss_size = ORC_CORO_STACK;
+        L->ctx.uc_link = &q->sched;
+        makecontext(&L->ctx, lane_entry, 0);
+    }
+    tls_quad = q;
+    for (;;) {
+        int all_done = 1;
+        for (int k = 0; k < 4; k++) {
+            quad_lane* L = &q->lane[k];
+            if (!L->done) all_done = 0;
+            if (!L->done && !L->waiting) {
+                q->current = k;
+                swapcontext(&q->sched, &L->ctx); /* runs lane k until it asks for a texel or finishes */
+            }
+        }
+        if (all_done) break;
+        int any_waiting = 0, any_runnable = 0;
+        for (int k = 0; k < 4; k++) {
+            if (q->lane[k].done) continue;
+            if (q->lane[k].waiting) any_waiting = 1; else any_runnable = 1;
+        }
+        if (!any_runnable && any_waiting) quad_resolve(q, fr);
+    }
+    for (int k = 0; k < 4; k++) {
+        const int x = 2 * qx + (k & 1), y = 2 * qy + (k >> 1);
+        if (x < fr->fb_width && y < fr->fb_height && y >= y0 && y < y1) {
+            float* o = out_rgba + ((size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x) * 4;
+            const vec4 c = q->lane[k].color;
+            o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+        }
+    }
+}
+
 /* Render rows [y0, y1) (row 0 = bottom, gl_FragCoord convention) into out_rgba, which holds
  * (y1 - y0) * fb_width RGBA float pixels. nthreads <= 0: all cores. Returns 0. */
 int orc_render(const orc_frame* fr, int y0, int y1, float* out_rgba, orc_counters* counters, int nthreads)
@@ -955,6 +1228,8 @@ int orc_render(const orc_frame* fr, int y0, int y1, float* out_rgba, orc_counter
     memset(&total, 0, sizeof total);
     if (y0 < 0) y0 = 0;
     if (y1 > fr->fb_height) y1 = fr->fb_height;
+    if (fr->texture_lod)
+        for (int k = 0; k < ORC_TEX_COUNT; k++) (void)mip_get(&fr->tex[k]); /* build mip chains before the parallel region */
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     else omp_set_num_threads(omp_get_num_procs());
@@ -963,19 +1238,32 @@ int orc_render(const orc_frame* fr, int y0, int y1, float* out_rgba, orc_counter
 #endif
 #pragma omp parallel
     {
-        orc_counters local;
+        orc_counters local, discard;
         memset(&local, 0, sizeof local);
+        memset(&discard, 0, sizeof discard);
         inv_t iv;
         inv_init(&iv, fr, &local);
+        if (!fr->texture_lod) {
 #pragma omp for schedule(dynamic, 1)
-        for (int y = y0; y < y1; y++) {
-            for (int x = 0; x < fr->fb_width; x++) {
-                iv.frag_x = (float)x + 0.5f;
-                iv.frag_y = (float)y + 0.5f;
-                vec4 c = shade_pixel(&iv);
-                float* o = out_rgba + ((size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x) * 4;
-                o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+            for (int y = y0; y < y1; y++) {
+                for (int x = 0; x < fr->fb_width; x++) {
+                    iv.frag_x = (float)x + 0.5f;
+                    iv.frag_y = (float)y + 0.5f;
+                    iv.step = 0;
+                    vec4 c = shade_pixel(&iv);
+                    float* o = out_rgba + ((size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x) * 4;
+                    o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+                }
             }
+        } else {
+            quad_t* q = (quad_t*)calloc(1, sizeof(quad_t));
+            for (int k = 0; k < 4; k++) q->lane[k].stack = (char*)malloc(ORC_CORO_STACK);
+            const int qy0 = y0 / 2, qy1 = (y1 + 1) / 2, qx1 = (fr->fb_width + 1) / 2;
+#pragma omp for schedule(dynamic, 1)
+            for (int qy = qy0; qy < qy1; qy++)
+                for (int qx = 0; qx < qx1; qx++) render_quad(q, &iv, fr, qx, qy, y0, y1, out_rgba, &local, &discard);
+            for (int k = 0; k < 4; k++) free(q->lane[k].stack);
+            free(q);
         }
 #pragma omp critical
         counters_add(&total, &local);
@@ -1036,3 +1324,17 @@ void orc_kat_sample_cube(const orc_cubemap* c, const float d[3], float out[4])
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
 float orc_kat_text_round_trip(float v) { return text_round_trip(v); }
+float orc_kat_log2(float v) { return orc_log2(v); }
+void orc_kat_sample2d_lod(const orc_texture* t, float u, float v, float lambda, float out[4])
+{
+    vec4 c = sample2d_lod(t, v2(u, v), lambda);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+}
+/* copies mip level `level` (RGBA8) into out; returns its width<<16 | height, 0 if the level does not exist */
+int orc_kat_mip_level(const orc_texture* t, int level, uint8_t* out)
+{
+    const orc_mipchain* m = mip_get(t);
+    if (!m || level < 0 || level >= m->levels) return 0;
+    memcpy(out, m->data[level], (size_t)m->w[level] * m->h[level] * 4);
+    return (m->w[level] << 16) | m->h[level];
+}

@@ -27,9 +27,19 @@
 #if defined(__HIPCC__)
 #define RT_HD __host__ __device__ __forceinline__
 #define RT_HDM __host__ __device__ __forceinline__
+// Cold, register-hungry leaves (Durand-Kerner, trilinear taps, float64 atan/asin) can be compiled out
+// of line as a register-allocation boundary.
+// (Measured: real calls make the whole kernel take the 256-VGPR call ABI budget and add scratch
+// frames -- 912 B/lane -- so the leaves stay inlined unless RT_OUTLINE_COLD is defined.)
+#if defined(RT_OUTLINE_COLD)
+#define RT_COLD __host__ __device__ __attribute__((noinline))
+#else
+#define RT_COLD __host__ __device__ __forceinline__
+#endif
 #else
 #define RT_HD static inline
 #define RT_HDM inline
+#define RT_COLD static inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -138,7 +148,7 @@ RT_HD double atan_unit(double a)  // 0 <= a <= 1
     p = 1.0 - s * p;
     return off + a * p;
 }
-RT_HD float rt_atan2(float yf, float xf)
+RT_COLD float rt_atan2(float yf, float xf)
 {
     const double y = (double)yf, x = (double)xf;
     const double ay = y < 0.0 ? -y : y, ax = x < 0.0 ? -x : x;
@@ -153,7 +163,7 @@ RT_HD float rt_atan2(float yf, float xf)
     }
     return (float)r;
 }
-RT_HD float rt_asin(float xf)
+RT_COLD float rt_asin(float xf)
 {
     const double x = (double)xf;
     const double c = sqrt(1.0 - x * x);
@@ -168,6 +178,36 @@ RT_HD float rt_asin(float xf)
         if (x < 0.0) r = -r;
     }
     return (float)r;
+}
+
+// log2 for the texture LOD (rt.frag:331-337 and the implicit-LOD rule). The LOD decides the blend
+// weight between two mip levels, and a trilinear alpha of (1-f)*1 + f*1 may or may not round to
+// exactly 1.0 depending on the last bit of f -- which flips the `alpha < 1` pass-through test
+// (rt.frag:884). So log2, too, is a fixed float64 sequence (exponent split + atanh series), bit-
+// reproducible on host and device; the oracle states the same algorithm independently.
+RT_HD float rt_log2(float xf)
+{
+    if (!(xf > 0.0f)) return xf == 0.0f ? -INFINITY : NAN;
+    if (xf > 3.0e38f) return INFINITY;
+    const double x = (double)xf;
+    const uint64_t bits = __builtin_bit_cast(uint64_t, x);
+    int e = (int)((bits >> 52) & 0x7ffu) - 1023;
+    double m = __builtin_bit_cast(double, (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);  // [1,2)
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double z = (m - 1.0) / (m + 1.0);
+    const double z2 = z * z;
+    double p = 1.0 / 19.0;
+    p = 1.0 / 17.0 + z2 * p;
+    p = 1.0 / 15.0 + z2 * p;
+    p = 1.0 / 13.0 + z2 * p;
+    p = 1.0 / 11.0 + z2 * p;
+    p = 1.0 / 9.0 + z2 * p;
+    p = 1.0 / 7.0 + z2 * p;
+    p = 1.0 / 5.0 + z2 * p;
+    p = 1.0 / 3.0 + z2 * p;
+    p = 1.0 + z2 * p;
+    const double ln_m = 2.0 * z * p;
+    return (float)((double)e + ln_m * 1.4426950408889634074);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -213,6 +253,7 @@ RT_HD SceneView make_view(const char* blob) { return make_view(blob, reinterpret
 struct TexTable {
     DevTexture tex[TEX_SLOTS];
     DevCubemap sky;
+    int32_t lod;  // 0: level-0 bilinear everywhere; 1: mip chain + quad-derivative LOD (DESIGN.md "Texture rule")
 };
 
 // Optional per-wave phase timers (profiling builds only, -DRT_PHASE_TIMERS): wave-cycles spent in
@@ -294,12 +335,15 @@ RT_HD void axis_taps(float u, int n, float fn, int wrap, int& i0, int& i1, float
     i0 = i;
     i1 = k;
 }
-RT_HD f4 bilinear_taps(const uint32_t* base, int w, int i0, int i1, int j0, int j1, float a, float b)
+// `first` = dword index of the image's first texel inside `base` (a mip level / cube face): all
+// addressing is base (wave-uniform pointer) + 32-bit per-lane index.
+RT_HD f4 bilinear_taps(const uint32_t* base, uint32_t first, int w, int i0, int i1, int j0, int j1, float a, float b)
 {
-    const uint32_t p00 = base[(size_t)j0 * (size_t)w + (size_t)i0];
-    const uint32_t p10 = base[(size_t)j0 * (size_t)w + (size_t)i1];
-    const uint32_t p01 = base[(size_t)j1 * (size_t)w + (size_t)i0];
-    const uint32_t p11 = base[(size_t)j1 * (size_t)w + (size_t)i1];
+    const uint32_t r0 = first + (uint32_t)j0 * (uint32_t)w, r1 = first + (uint32_t)j1 * (uint32_t)w;
+    const uint32_t p00 = base[r0 + (uint32_t)i0];
+    const uint32_t p10 = base[r0 + (uint32_t)i1];
+    const uint32_t p01 = base[r1 + (uint32_t)i0];
+    const uint32_t p11 = base[r1 + (uint32_t)i1];
     const f4 t00 = unpack_rgba8(p00), t10 = unpack_rgba8(p10), t01 = unpack_rgba8(p01), t11 = unpack_rgba8(p11);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     f4 r;
@@ -316,7 +360,47 @@ RT_HD f4 sample2d_level0(const DevTexture& t, float u, float v)
     float a, b;
     axis_taps(u, t.width, t.fwidth, t.wrap, i0, i1, a);
     axis_taps(v, t.height, t.fheight, t.wrap, j0, j1, b);
-    return bilinear_taps(t.texels, t.width, i0, i1, j0, j1, a, b);
+    return bilinear_taps(t.texels, 0u, t.width, i0, i1, j0, j1, a, b);
+}
+// One mip level: dimensions max(1, w>>l) x max(1, h>>l), texels at level_off[l].
+RT_HD f4 sample2d_level(const DevTexture& t, int level, float u, float v)
+{
+    int w = t.width >> level, h = t.height >> level;
+    w = w < 1 ? 1 : w;
+    h = h < 1 ? 1 : h;
+    int i0, i1, j0, j1;
+    float a, b;
+    axis_taps(u, w, (float)w, t.wrap, i0, i1, a);
+    axis_taps(v, h, (float)h, t.wrap, j0, j1, b);
+    return bilinear_taps(t.texels, t.level_off[level], w, i0, i1, j0, j1, a, b);
+}
+// lambda <= 0 (also -inf, NaN): level-0 bilinear; otherwise floor(lambda) and the next level
+// (clamped to the last), blended (1-f)*c0 + f*c1.
+RT_COLD f4 sample2d_lod(const DevTexture& t, float u, float v, float lambda)
+{
+    if (t.texels == nullptr) return mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    int l0 = 0;
+    float f = 0.0f;
+    bool two = false;
+    if (lambda > 0.0f) {
+        const float top = (float)(t.levels - 1);
+        if (lambda > top) lambda = top;
+        const float fl = floorf(lambda);
+        l0 = (int)fl;
+        f = lambda - fl;
+        two = l0 + 1 <= t.levels - 1;
+    }
+    // the two levels are sampled one after the other by the SAME code (not unrolled): four taps in
+    // flight at a time keeps the sampler's register footprint at the bilinear one
+    f4 c0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && !RT_ANY(two)) break;
+        const f4 c = sample2d_level(t, l0 + pass * (two ? 1 : 0), u, v);
+        if (pass == 0) c0 = c; else c1 = c;
+    }
+    if (!two) return c0;
+    return mk4((1.0f - f) * c0.x + f * c1.x, (1.0f - f) * c0.y + f * c1.y, (1.0f - f) * c0.z + f * c1.z, (1.0f - f) * c0.w + f * c1.w);
 }
 // texture(skybox, d): GL face table, per-face bilinear, CLAMP_TO_EDGE, not seamless (rt.frag:893)
 RT_HD f4 sample_cube(const DevCubemap& c, f3 d)
@@ -334,7 +418,7 @@ RT_HD f4 sample_cube(const DevCubemap& c, f3 d)
     float a, b;
     axis_taps(s, c.size, c.fsize, 1, i0, i1, a);
     axis_taps(t, c.size, c.fsize, 1, j0, j1, b);
-    return bilinear_taps(c.texels + (size_t)face * (size_t)c.size * (size_t)c.size, c.size, i0, i1, j0, j1, a, b);
+    return bilinear_taps(c.texels, (uint32_t)face * (uint32_t)c.size * (uint32_t)c.size, c.size, i0, i1, j0, j1, a, b);
 }
 
 // The single 2-D texture fetch site. Each lane may request a fetch from a different sampler slot;
@@ -352,14 +436,66 @@ RT_HD int rt_first_slot(bool pending, int slot)
     return slot;
 #endif
 }
-RT_HD f4 fetch2d(const TexTable& T, bool want, int slot, float u, float v)
+// Values of the horizontal / vertical neighbour inside the lane's 2x2 pixel quad. The lane mapping
+// of the kernel puts a quad in 4 consecutive lanes (bit0 = x&1, bit1 = y&1), so this is a DPP
+// quad_perm move, no LDS. Must be called with all four lanes of the quad active.
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD int quad_other_x(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
+RT_HD int quad_other_y(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }  // quad_perm [2,3,0,1]
+RT_HD int rt_lane_id() { return (int)(threadIdx.x & 63u); }
+#else
+RT_HD int quad_other_x(int v) { return v; }  // the host harness has no quads: texture_lod must be 0 there
+RT_HD int quad_other_y(int v) { return v; }
+RT_HD int rt_lane_id() { return 0; }
+#endif
+RT_HD float quad_other_x(float v) { return __builtin_bit_cast(float, quad_other_x(__builtin_bit_cast(int, v))); }
+RT_HD float quad_other_y(float v) { return __builtin_bit_cast(float, quad_other_y(__builtin_bit_cast(int, v))); }
+
+// `prim` identifies the primitive being textured (type and index): a quad neighbour contributes to
+// a derivative only if it executes this very fetch for the same sampler and the same primitive.
+RT_HD f4 fetch2d(const TexTable& T, bool want, int slot, int prim, float u, float v)
 {
+    float dudx = 0.0f, dvdx = 0.0f, dudy = 0.0f, dvdy = 0.0f;
+    if (T.lod) {
+        const int key = want ? (slot | (prim << 3)) : -1;
+        const int lane = rt_lane_id();
+        const int kx = quad_other_x(key), ky = quad_other_y(key);
+        const float ux = quad_other_x(u), vx = quad_other_x(v), uy = quad_other_y(u), vy = quad_other_y(v);
+        if (want && kx == key) {  // dFdx = right - left
+            const bool right = (lane & 1) != 0;
+            dudx = right ? u - ux : ux - u;
+            dvdx = right ? v - vx : vx - v;
+        }
+        if (want && ky == key) {  // dFdy = top - bottom (y grows upwards, gl_FragCoord)
+            const bool top = (lane & 2) != 0;
+            dudy = top ? u - uy : uy - u;
+            dvdy = top ? v - vy : vy - v;
+        }
+    }
     f4 out = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     bool pending = want;
     while (RT_ANY(pending)) {
         const int s = rt_first_slot(pending, slot);
         const bool mine = pending && slot == s;
-        if (mine) out = sample2d_level0(T.tex[s], u, v);
+        if (mine) {
+            const DevTexture& t = T.tex[s];
+            if (T.lod) {
+                float lambda;
+                if (s <= TEX_SPHERE_4) {  // getSphereTexture: textureLod(.., log2(max(df.x,df.y)*1024)), rt.frag:326-338
+                    float dfx = fabsf(dudx) + fabsf(dudy);
+                    const float dfy = fabsf(dvdx) + fabsf(dvdy);
+                    if (dfx > 0.5f) dfx = 0.0f;
+                    lambda = rt_log2(gl_max(dfx, dfy) * 1024.0f);
+                } else {                  // texture(): implicit LOD from the texel-space footprint
+                    const float rx = sqrtf((dudx * t.fwidth) * (dudx * t.fwidth) + (dvdx * t.fheight) * (dvdx * t.fheight));
+                    const float ry = sqrtf((dudy * t.fwidth) * (dudy * t.fwidth) + (dvdy * t.fheight) * (dvdy * t.fheight));
+                    lambda = rt_log2(gl_max(rx, ry));
+                }
+                out = sample2d_lod(t, u, v, lambda);
+            } else {
+                out = sample2d_level0(t, u, v);
+            }
+        }
         pending = pending && !mine;
     }
     return out;
@@ -477,7 +613,7 @@ RT_HD float dk_step(f2& c0, f2 c1, f2 c2, f2 c3, const TorusRay& w)
     c0.y -= fc.y;
     return gl_max(fabsf(fc.x), fabsf(fc.y));
 }
-RT_HD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
+RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
 {
     const float eps = 0.001f;
     TorusRay w;
@@ -772,7 +908,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
 // early exit is exact. The any-hit scan is an OR (a float sum for textured rings only), so the
 // cheap classes go first; ring order is kept for the sum.
 template <bool CULL, bool COUNT>
-RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 rd, float dist, LaneCounters& cnt)
+RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt)
 {
     float shadow = 0.0f;
     float t = 0.0f;
@@ -836,12 +972,18 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 
             if (!RT_ANY(on)) break;
         }
     }
-    // rings: textured rings ADD their alpha (trap T10) -- ring order is kept for the float sum
-    if (RT_ANY(on)) {
+    // rings: textured rings ADD their alpha (trap T10) -- ring order is kept for the float sum.
+    // With quad-derivative LOD every lane for which the REFERENCE runs inShadow (ref_on: it neither
+    // skips dp == 0 lights nor stops at shadow >= 1) must still present its ring uv at the fetch, because
+    // its quad neighbours difference against it; such lanes fetch but do not accumulate.
+    const bool lod = T.lod != 0;
+    const bool ring_on = lod ? ref_on : on;
+    if (RT_ANY(ring_on)) {
         const int n = S.h->n_ring;
         const f4* bound = S.ring_bound();
         for (int i = 0; i < n; i += 4) {
-            bool need[4] = {on, on && i + 1 < n, on && i + 2 < n, on && i + 3 < n};
+            const bool live = lod ? ref_on : on;
+            bool need[4] = {live, live && i + 1 < n, live && i + 2 < n, live && i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !ring_cull(b[k], ro, rd, dist);)
@@ -849,11 +991,12 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 
             for (int k = 0; k < 4; k++) {
                 if (RT_ANY(need[k])) {
                     f2 uv = mk2(0.0f, 0.0f);
-                    const bool hit = need[k] && on && intersect_ring(S.rings()[i + k], ro, rd, dist, t, uv);
+                    const bool geom_hit = need[k] && intersect_ring(S.rings()[i + k], ro, rd, dist, t, uv);
+                    const bool hit = geom_hit && on;
                     const int texnum = __builtin_bit_cast(int, S.rings()[i + k].pos_tex.w);
                     if (texnum > 0) {
-                        if (RT_ANY(hit)) {
-                            const f4 c = sample2d_level0(T.tex[TEX_RING], uv.x, uv.y);
+                        if (RT_ANY(geom_hit)) {
+                            const f4 c = fetch2d(T, geom_hit, TEX_RING, (TYPE_RING << 20) | (i + k), uv.x, uv.y);
                             if (hit) shadow += c.w;
                         }
                     } else if (hit) {
@@ -862,7 +1005,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 
                     on = on && shadow < 1.0f;
                 }
             }
-            if (!RT_ANY(on)) break;
+            if (!lod && !RT_ANY(on)) break;
         }
     }
     return gl_min(shadow, 1.0f);
@@ -913,7 +1056,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         // (NaN dp must still take the full path so that it propagates like in the shader.)
         const bool cast = on && !(dp == 0.0f);
         RT_PH_BEGIN(_sh0);
-        const float sh = 1.0f - in_shadow<CULL, COUNT>(S, T, cast, pt, light_dir, dist, cnt);
+        const float sh = 1.0f - in_shadow<CULL, COUNT>(S, T, cast, on, pt, light_dir, dist, cnt);
         RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
@@ -1067,14 +1210,15 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
 
     // ---- texture taps (wave-uniform sites) ----
     if (RT_ANY(slot >= 0)) {
-        const f4 c0 = fetch2d(T, slot >= 0, slot, u, v);
+        const int prim = (type << 20) | num;
+        const f4 c0 = fetch2d(T, slot >= 0, slot, prim, u, v);
         if (slot >= 0 && !box_tex) {
             h.surf.color = mk3(c0.x, c0.y, c0.z);
             h.alpha = c0.w;
         }
         if (RT_ANY(box_tex)) {
-            const f4 c1 = fetch2d(T, box_tex, TEX_BOX, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.x - lpos.x) - 0.5f);
-            const f4 c2 = fetch2d(T, box_tex, TEX_BOX, 0.5f * (lp.x - lpos.x) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
+            const f4 c1 = fetch2d(T, box_tex, TEX_BOX, prim, 0.5f * (lp.z - lpos.z) - 0.5f, 0.5f * (lp.x - lpos.x) - 0.5f);
+            const f4 c2 = fetch2d(T, box_tex, TEX_BOX, prim, 0.5f * (lp.x - lpos.x) - 0.5f, 0.5f * (lp.y - lpos.y) - 0.5f);
             if (box_tex) {
                 const float wx = fabsf(ln.x), wy = fabsf(ln.y), wz = fabsf(ln.z);
                 h.surf.color = mk3(wx * c0.x + wy * c1.x + wz * c2.x, wx * c0.y + wy * c1.y + wz * c2.y, wx * c0.z + wy * c1.z + wz * c2.z);

@@ -63,7 +63,12 @@ __global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
     const int band_j = row_local / p.band_rows;
     const int within = row_local - band_j * p.band_rows;
     const int y = (p.band_first + band_j * p.band_stride) * p.band_rows + within;
-    const bool alive = (x < p.fb_w) && (y < p.fb_h) && (row_local < p.rows_local);
+    const bool real = (x < p.fb_w) && (y < p.fb_h) && (row_local < p.rows_local);
+    // With quad-derivative LOD the pixels that complete a 2x2 quad beyond an odd-sized framebuffer run
+    // as helper invocations (traced, never stored or counted), like a rasteriser's helper lanes.
+    const bool helper = p.tex.lod != 0 && !real && (x < ((p.fb_w + 1) & ~1)) && (y < ((p.fb_h + 1) & ~1)) &&
+                        (row_local < p.rows_local + (p.fb_h & 1));
+    const bool alive = real || helper;
 
     const char* blob = p.scene;
     if (LDS) {
@@ -83,7 +88,8 @@ __global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
 #endif
     const f4 px = trace_pixel<CULL, COUNT>(S, p.tex, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
 
-    if (alive) {
+    if (!real) cnt = LaneCounters{};
+    if (real) {
         const size_t idx = (size_t)row_local * (size_t)p.fb_w + (size_t)x;
         if (p.out_f32) {
             typedef float v4f __attribute__((ext_vector_type(4)));

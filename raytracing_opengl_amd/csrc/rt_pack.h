@@ -373,4 +373,39 @@ inline void to_rgba8(const unsigned char* src, int w, int h, int channels, uint3
     }
 }
 
+// glGenerateMipmap stand-in (DESIGN.md "Texture rule"): appends levels 1.. to `texels` (level 0 on
+// entry, RGBA8 dwords). Level L is max(1,w>>L) x max(1,h>>L); each texel is the rounded integer mean
+// ((a+b+c+d+2)>>2 per channel) of source texels (min(2i,ws-1), min(2i+1,ws-1)) x (same in j).
+// Returns the level count and fills the dword offset of every level.
+inline int build_mip_chain(std::vector<uint32_t>& texels, int w, int h, uint32_t* level_off, int max_levels)
+{
+    int levels = 1;
+    size_t src_off = 0;
+    level_off[0] = 0;
+    while ((w > 1 || h > 1) && levels < max_levels) {
+        const int ws = w, hs = h;
+        w = w > 1 ? w >> 1 : 1;
+        h = h > 1 ? h >> 1 : 1;
+        const size_t dst_off = texels.size();
+        texels.resize(dst_off + static_cast<size_t>(w) * h);
+        level_off[levels] = static_cast<uint32_t>(dst_off);
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                const int i0 = 2 * i < ws - 1 ? 2 * i : ws - 1, i1 = 2 * i + 1 < ws - 1 ? 2 * i + 1 : ws - 1;
+                const int j0 = 2 * j < hs - 1 ? 2 * j : hs - 1, j1 = 2 * j + 1 < hs - 1 ? 2 * j + 1 : hs - 1;
+                const uint32_t p00 = texels[src_off + static_cast<size_t>(j0) * ws + i0], p10 = texels[src_off + static_cast<size_t>(j0) * ws + i1];
+                const uint32_t p01 = texels[src_off + static_cast<size_t>(j1) * ws + i0], p11 = texels[src_off + static_cast<size_t>(j1) * ws + i1];
+                uint32_t out = 0;
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t sum = ((p00 >> (8 * c)) & 255u) + ((p10 >> (8 * c)) & 255u) + ((p01 >> (8 * c)) & 255u) + ((p11 >> (8 * c)) & 255u);
+                    out |= ((sum + 2u) >> 2) << (8 * c);
+                }
+                texels[dst_off + static_cast<size_t>(j) * w + i] = out;
+            }
+        src_off = dst_off;
+        levels++;
+    }
+    return levels;
+}
+
 }  // namespace rtpack

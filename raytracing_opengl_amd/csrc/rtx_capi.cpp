@@ -89,7 +89,7 @@ struct rtx_context {
     float* d_fb_f32 = nullptr;
     uint32_t* d_fb_u8 = nullptr;
     // options
-    int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 0;
+    int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 1;
     unsigned long long* d_counters = nullptr;
     // timing
     hipEvent_t ev_start[EVENT_RING], ev_stop[EVENT_RING];
@@ -173,6 +173,7 @@ void fill_tex_table(rtx_context* ctx, TexTable& T)
         d.levels = ctx->opt_lod ? t.levels : 1;
         std::memcpy(d.level_off, t.level_off, sizeof d.level_off);
     }
+    T.lod = ctx->opt_lod;
     const int unit = ctx->sampler_unit[SAMPLER_SKYBOX];
     if (unit >= 0 && unit < UNIT_COUNT) {
         auto it = ctx->textures.find(ctx->unit_texture_cube[unit]);
@@ -390,7 +391,7 @@ int rtx_texture2d_create(rtx_context* ctx, int width, int height, int channels, 
     t.wrap = wrap == RTX_WRAP_CLAMP_TO_EDGE ? 1 : 0;
     std::vector<uint32_t> host(static_cast<size_t>(width) * height);
     rtpack::to_rgba8(texels, width, height, channels, host.data());
-    t.levels = 1;
+    t.levels = rtpack::build_mip_chain(host, width, height, t.level_off, MAX_MIPS);  // glGenerateMipmap (GLWrapper.cpp:337)
     t.dwords = host.size();
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_texels), t.dwords * 4));
     HIP_TRY(hipMemcpy(t.d_texels, host.data(), t.dwords * 4, hipMemcpyHostToDevice));
@@ -474,10 +475,7 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_CULL: ctx->opt_cull = value != 0; break;
         case RTX_OPT_COUNT_RAYS: ctx->opt_count = value != 0; break;
         case RTX_OPT_SCENE_LDS: ctx->opt_lds = value != 0; break;
-        case RTX_OPT_TEXTURE_LOD:
-            if (value != 0) return fail(RTX_ERR_INVALID, "RTX_OPT_TEXTURE_LOD=1 (mip chain + quad-derivative LOD) is not implemented yet");
-            ctx->opt_lod = 0;
-            break;
+        case RTX_OPT_TEXTURE_LOD: ctx->opt_lod = value != 0; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;

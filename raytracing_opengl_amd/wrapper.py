@@ -186,7 +186,7 @@ class SceneUploader:
             self.wrapper.update_buffer(ubo, data)
 
 
-def make_renderer(scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, device: int = 0) -> GLWrapper:
+def make_renderer(scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, device: int = 0, texture_lod: int = 1) -> GLWrapper:
     """The start-up sequence of reference main.cpp:25-157 for a prepared scene: context, specialise,
     skybox, textures, blocks."""
     gl = GLWrapper(fb_width, fb_height, False, device=device)
@@ -200,4 +200,5 @@ def make_renderer(scene_blocks, fb_width: int, fb_height: int, textures=None, cu
     up = SceneUploader(scene_blocks, gl)
     up.init()
     gl.uploader = up
+    gl.set_option(RTX_OPT_TEXTURE_LOD, texture_lod)
     return gl

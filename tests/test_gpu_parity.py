@@ -52,11 +52,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("lod", [1, 0])
 @pytest.mark.parametrize("kind,w,h,depth", CASES)
-def test_frame_parity_and_ray_counts(mid_textures, kind, w, h, depth):
+def test_frame_parity_and_ray_counts(mid_textures, kind, w, h, depth, lod):
     sc = scenes.build_scene(kind, w, h, depth)
-    ref, cnt = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"]).render()
-    img, img8, st = _render_gpu(sc, w, h, mid_textures)
+    ref, cnt = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"], texture_lod=lod).render()
+    img, img8, st = _render_gpu(sc, w, h, mid_textures, {wrapper.RTX_OPT_TEXTURE_LOD: lod})
     mx, nbad, nanbad = _compare(img, ref)
     assert nanbad == 0
     assert mx <= TOL and nbad == 0, f"max diff {mx}, {nbad} components over {TOL}"
@@ -76,6 +77,43 @@ def test_kernel_variants_agree_with_oracle(small_textures, kind, w, h, depth, op
     mx, nbad, nanbad = _compare(img, ref)
     assert nanbad == 0 and mx <= TOL and nbad == 0
     assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
+
+
+# ---- texture rule phase B: mip chain + trilinear + quad-derivative LOD ----
+LOD_CASES = [("default", 960, 540, 4, {}), ("default", 640, 360, 5, dict(time=4.0, delta=0.3, yaw=55.0, pitch=-4.0, cam_pos=(2.0, 1.0, -4.0))),
+             ("default", 333, 207, 3, {}),  # odd framebuffer: helper invocations complete the edge quads
+             ("default", 640, 360, 4, dict(yaw=80.0, pitch=3.0, cam_pos=(0.0, 0.5, 2.0)))]  # looking at the crate / Saturn
+
+
+@pytest.mark.parametrize("kind,w,h,depth,kw", LOD_CASES)
+def test_frame_parity_with_mip_lod(mid_textures, kind, w, h, depth, kw):
+    sc = scenes.build_scene(kind, w, h, depth, **kw)
+    ref, cnt = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"], texture_lod=1).render()
+    ref0, _ = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"], texture_lod=0).render()
+    img, _img8, st = _render_gpu(sc, w, h, mid_textures, {wrapper.RTX_OPT_TEXTURE_LOD: 1})
+    mx, nbad, nanbad = _compare(img, ref)
+    assert nanbad == 0 and mx <= TOL and nbad == 0, f"max diff {mx}, {nbad} components over {TOL}"
+    assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
+    assert np.abs(ref - ref0).max() > 1e-3  # the LOD rule actually changes pixels on this view
+
+
+def test_lod_bands_match_full_frame(small_textures):
+    """Quads never straddle row bands (multiples of 8 rows), so LOD results are band-independent."""
+    import torch
+    from raytracing_opengl_amd import bands
+    w, h, world, band_rows = 320, 200, 3, 8
+    sc = scenes.build_scene("default", w, h, 4)
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=1)
+    gl.draw()
+    full = torch.from_numpy(gl.read_pixels())
+    parts = []
+    for r in range(world):
+        buf = torch.zeros((bands.max_local_rows(h, band_rows, world), w, 4), dtype=torch.float32, device="cuda:0")
+        gl.draw_bands(band_rows, r, world, buf.data_ptr(), wrapper.RTX_RGBA32F)
+        gl.finish()
+        parts.append(buf.cpu())
+    assert torch.equal(bands.unpermute(parts, h, band_rows, world).view(torch.int32), full.view(torch.int32))
+    gl.stop()
 
 
 def test_moving_camera_and_animation(small_textures):

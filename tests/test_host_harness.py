@@ -1,7 +1,9 @@
 """Logic check without a GPU: the product's device header (rt_device.h) + scene packer
 (rt_pack.h), compiled for the host by tests/host_harness, against the independently written
 oracle. On the host both sides use the same libm, so agreement must be BIT-EXACT -- with the
-conservative culls on and off (DESIGN.md "Culls"), and the ray counts must be identical."""
+conservative culls on and off (DESIGN.md "Culls"), and the ray counts must be identical.
+The host build has no 2x2 quads, so these checks run the level-0 texture mode (texture_lod = 0);
+the quad-derivative LOD mode is covered on the GPU (tests/test_gpu_parity.py)."""
 import numpy as np
 import pytest
 
@@ -20,7 +22,7 @@ def test_unorm8_is_exact(built):
 @pytest.mark.parametrize("cull", [False, True])
 def test_device_logic_matches_oracle_bit_exactly(built, small_textures, kind, w, h, depth, cull):
     sc = scenes.build_scene(kind, w, h, depth)
-    ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"]).render()
+    ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
     img, hc = harness.render(sc, w, h, small_textures["textures"], small_textures["cubemap"], cull=cull)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"]
@@ -31,7 +33,7 @@ def test_device_logic_matches_oracle_bit_exactly(built, small_textures, kind, w,
 
 def test_animated_and_rotated_camera(built, small_textures):
     sc = scenes.build_scene("default", 200, 120, 5, time=7.0, delta=1.3, yaw=-35.0, pitch=12.0, cam_pos=(-6.0, 2.0, -3.0))
-    ref, _ = oracle.OracleScene(sc, 200, 120, small_textures["textures"], small_textures["cubemap"]).render()
+    ref, _ = oracle.OracleScene(sc, 200, 120, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
     img, _ = harness.render(sc, 200, 120, small_textures["textures"], small_textures["cubemap"], cull=True)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
@@ -41,6 +43,6 @@ def test_unbound_samplers_and_missing_faces(built, small_textures):
     faces = list(small_textures["cubemap"])
     faces[2] = None  # a face that failed to load stays black (reference GLWrapper.cpp:301-305)
     tex = [t for t in small_textures["textures"] if t[0] != "texture_box"]
-    ref, _ = oracle.OracleScene(sc, 160, 90, tex, faces).render()
+    ref, _ = oracle.OracleScene(sc, 160, 90, tex, faces, texture_lod=0).render()
     img, _ = harness.render(sc, 160, 90, tex, faces, cull=True)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))

@@ -204,9 +204,46 @@ def test_ray_count_pins(built, mid_textures):
     """SURVEY.md Appendix C.3 pins (nearest-texel probe): rays/pixel within 1 % of the survey numbers."""
     for (w, h, d), (closest, shadow, dk_mean) in {(640, 480, 1): (1.060, 0.613, 12.05), (480, 270, 4): (1.420, 0.885, 12.8)}.items():
         sc = scenes.build_scene("default", w, h, d)
-        _img, c = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"]).render()
+        _img, c = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"], texture_lod=0).render()
         px = w * h
         assert c["rays_closest"] / px == pytest.approx(closest, rel=0.01)
         assert c["rays_shadow"] / px == pytest.approx(shadow, rel=0.02)
         assert c["dk_sweeps"] / c["dk_solves"] == pytest.approx(dk_mean, rel=0.03)
         assert c["segment_cap_hits"] == 0 and c["tir_breaks"] == 0
+
+
+def test_mip_chain_and_trilinear_rule():
+    """Phase-B texture rule of the oracle: integer box-filtered mips with floor-halving sizes, odd
+    sizes handled by clamping the second tap, trilinear blend between floor(lambda) and the next level."""
+    lib = oracle.lib()
+    lib.orc_kat_mip_level.restype = ctypes.c_int
+    lib.orc_kat_mip_level.argtypes = [ctypes.POINTER(oracle.Texture), ctypes.c_int, ctypes.c_void_p]
+    lib.orc_kat_sample2d_lod.argtypes = [ctypes.POINTER(oracle.Texture), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float * 4]
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(5, 12, 3), dtype=np.uint8)  # odd height
+    t = oracle.Texture(12, 5, 3, 0, img.ctypes.data)
+    out = np.zeros((5 * 12 * 4,), np.uint8)
+    dims = lib.orc_kat_mip_level(ctypes.byref(t), 1, out.ctypes.data)
+    assert dims == (6 << 16 | 2)
+    lvl1 = out[: 6 * 2 * 4].reshape(2, 6, 4)
+    src = np.concatenate([img, np.full((5, 12, 1), 255, np.uint8)], axis=-1).astype(np.int32)
+    for j in range(2):
+        for i in range(6):
+            exp = (src[2 * j, 2 * i] + src[2 * j, 2 * i + 1] + src[2 * j + 1, 2 * i] + src[2 * j + 1, 2 * i + 1] + 2) >> 2
+            assert (lvl1[j, i] == exp).all()
+    dims = lib.orc_kat_mip_level(ctypes.byref(t), 2, out.ctypes.data)
+    assert dims == (3 << 16 | 1)
+    assert lib.orc_kat_mip_level(ctypes.byref(t), 3, out.ctypes.data) == (1 << 16 | 1)
+    assert lib.orc_kat_mip_level(ctypes.byref(t), 4, out.ctypes.data) == 0
+    c0, c1, cm = (ctypes.c_float * 4)(), (ctypes.c_float * 4)(), (ctypes.c_float * 4)()
+    lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.3, 0.6, 1.0, c0)
+    lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.3, 0.6, 2.0, c1)
+    lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.3, 0.6, 1.25, cm)
+    for k in range(4):
+        assert cm[k] == pytest.approx(0.75 * c0[k] + 0.25 * c1[k], abs=1e-6)
+    lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.3, 0.6, -5.0, c0)
+    lib.orc_kat_sample2d(ctypes.byref(t), 0.3, 0.6, c1)
+    assert list(c0) == list(c1)                       # lambda <= 0 -> level-0 bilinear
+    lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.3, 0.6, 99.0, c0)
+    lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.9, 0.1, 3.0, c1)
+    assert list(c0) == list(c1)                       # clamped to the 1x1 top level
