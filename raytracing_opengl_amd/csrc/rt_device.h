@@ -1278,47 +1278,59 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         get_hit_info(S, T, hit, ro, rd, pt, tm, num, type, h);
         RT_PH_LAP(cnt, PH_HITINFO);
 
-        // ---- classify ----
+        // ---- classify: everything that does not need the shaded colour happens BEFORE the shading call
+        // (next ray, iteration count, unshaded radiance), so that only a weight and a mask factor stay
+        // live across the shadow scans ----
         enum { ACT_NONE = 0, ACT_SIDE, ACT_REFLECT, ACT_DIFFUSE };
         int act = ACT_NONE;
-        f3 sh_pt = pt, sh_n = h.normal;
+        f3 sh_pt = pt;
         f3 n = h.normal;
-        float R = 0.0f, Tm = 1.0f;
+        float w_s = 0.0f;     // scalar weight of the shaded term (R, T or alpha, by branch)
+        float k_mask = 1.0f;  // mask factor applied AFTER the shaded term was weighted with the old mask
         bool finished = false;  // lane leaves the loop after this trip
         bool sky = false;
-        bool arm_side = false;
-        f3 next_ro = ro, next_rd = rd;
-        f3 add = mk3(0.0f, 0.0f, 0.0f);  // radiance that needs no shading evaluation, already weighted
+        f3 new_ro = ro, new_rd = rd;
 
         if (alive) {
             if (is_side) {
                 // getReflectedColor: light sphere -> its colour; miss -> BLACK (trap T3); else one shade
                 if (type == TYPE_POINT_LIGHT) {
-                    add = (xyz(S.lights_point()[num].color_intensity) * side_R) * mask;
+                    color = color + (xyz(S.lights_point()[num].color_intensity) * side_R) * mask;
                 } else if (hit) {
                     act = ACT_SIDE;
-                    sh_pt = dot3(rd, h.normal) < 0.0f ? pt + h.normal * h.bias : pt - h.normal * h.bias;
-                    sh_n = h.normal;  // unflipped (trap T18)
+                    sh_pt = dot3(rd, n) < 0.0f ? pt + n * h.bias : pt - n * h.bias;  // n stays unflipped (trap T18)
+                    w_s = side_R;
                 }
+                k_mask = 1.0f - side_R;
+                if (side_R >= 1.0f) finished = true;  // total reflection: checked after the mirror term (rt.frag:865)
+                new_ro = cont_ro;
+                new_rd = cont_rd;
+                side = false;
             } else if (!hit) {
                 sky = true;
                 finished = true;
             } else if (type == TYPE_POINT_LIGHT) {
-                add = xyz(S.lights_point()[num].color_intensity) * mask;
+                color = color + xyz(S.lights_point()[num].color_intensity) * mask;
                 finished = true;
             } else {
                 const bool outside = dot3(rd, n) < 0.0f;
                 n = outside ? n : -n;
+                float R;
                 if (h.refraction > 0.0f)
                     R = fresnel_reflect_amount(outside ? 1.0f : h.refraction, outside ? h.refraction : 1.0f, rd, n, h.reflection);
                 else
                     R = get_fresnel(n, rd, h.reflection);
-                Tm = 1.0f - R;
                 if (h.refraction > 0.0f) {  // refractive, rt.frag:851-873
-                    next_ro = pt - n * h.bias;
-                    next_rd = gl_refract(rd, n, outside ? 1.0f / h.refraction : h.refraction);
+                    const f3 next_ro = pt - n * h.bias;
+                    const f3 next_rd = gl_refract(rd, n, outside ? 1.0f / h.refraction : h.refraction);
                     if (outside && h.reflection > 0.0f) {
-                        arm_side = true;  // next trip: the mirror ray; the refracted ray waits in cont_*
+                        // next trip: the mirror ray; the refracted ray waits in cont_*
+                        side = true;
+                        side_R = R;
+                        cont_ro = next_ro;
+                        cont_rd = next_rd;
+                        new_ro = pt + n * h.bias;
+                        new_rd = gl_reflect(rd, n);
                     } else {
                         if (!outside) {
                             absorbDistance += tm;  // accumulates over all inside segments (trap T12)
@@ -1326,16 +1338,29 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
                                               expf(-h.absorb.z * absorbDistance));
                         }
                         if (R >= 1.0f) finished = true;
+                        new_ro = next_ro;
+                        new_rd = next_rd;
                     }
                     // i is not advanced: "i--" cancels the loop increment (rt.frag:870-872, trap T2)
                 } else if (h.reflection > 0.0f) {  // reflective, rt.frag:874-880
                     act = ACT_REFLECT;
                     sh_pt = pt + n * h.bias;
-                    sh_n = n;
+                    w_s = 1.0f - R;
+                    k_mask = R;
+                    new_ro = sh_pt;
+                    new_rd = gl_reflect(rd, n);
+                    i++;
                 } else {  // diffuse, rt.frag:881-890
                     act = ACT_DIFFUSE;
                     sh_pt = pt + n * h.bias;
-                    sh_n = n;
+                    w_s = h.alpha;
+                    if (h.alpha < 1.0f) {  // alpha pass-through keeps rd, costs an iteration (trap T13)
+                        new_ro = pt - n * h.bias;
+                        k_mask = 1.0f - h.alpha;
+                        i++;
+                    } else {
+                        finished = true;
+                    }
                 }
             }
         }
@@ -1345,51 +1370,22 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         if (RT_ANY(sky)) {
             if (sky) {
                 const f4 c = sample_cube(T.sky, rd);
-                add = mk3(c.x, c.y, c.z) * mask;
+                color = color + mk3(c.x, c.y, c.z) * mask;
             }
         }
 
         RT_PH_LAP(cnt, PH_SKY);
         // ---- the single shading site ----
-        const f3 col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, sh_n, cnt);
+        const f3 col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
         RT_PH_LAP(cnt, PH_SHADE);
 
         // ---- apply + advance ----
         if (alive) {
-            color = color + add;
-            if (is_side) {
-                if (act == ACT_SIDE) color = color + (col * side_R) * mask;
-                mask = mask * (1.0f - side_R);
-                if (side_R >= 1.0f) finished = true;  // total reflection: checked after the mirror term (rt.frag:865)
-                ro = cont_ro;
-                rd = cont_rd;
-                side = false;
-            } else if (arm_side) {
-                side = true;
-                side_R = R;
-                cont_ro = next_ro;
-                cont_rd = next_rd;
-                ro = pt + n * h.bias;
-                rd = gl_reflect(rd, n);
-            } else if (act == ACT_REFLECT) {
-                color = color + (col * Tm) * mask;
-                ro = sh_pt;
-                rd = gl_reflect(rd, n);
-                mask = mask * R;
-                i++;
-            } else if (act == ACT_DIFFUSE) {
-                color = color + (col * mask) * h.alpha;
-                if (h.alpha < 1.0f) {  // alpha pass-through keeps rd, costs an iteration (trap T13)
-                    ro = pt - n * h.bias;
-                    mask = mask * (1.0f - h.alpha);
-                    i++;
-                } else {
-                    finished = true;
-                }
-            } else if (!finished) {  // refraction without a mirror term
-                ro = next_ro;
-                rd = next_rd;
-            }
+            if (act == ACT_DIFFUSE) color = color + (col * mask) * w_s;          // calcShade * mask * alpha
+            else if (act != ACT_NONE) color = color + (col * w_s) * mask;        // calcShade * R|T * mask
+            mask = mask * k_mask;  // x * 1.0f == x: lanes without a mask change are untouched
+            ro = new_ro;
+            rd = new_rd;
             // loop condition of the shader's for(), evaluated before the next MAIN trip
             if (finished || (!side && (i >= iterations || segments >= RT_SEGMENT_CAP))) alive = false;
         }
