@@ -116,6 +116,21 @@ def test_lod_bands_match_full_frame(small_textures):
     gl.stop()
 
 
+@pytest.mark.parametrize("lod", [1, 0])
+@pytest.mark.parametrize("name", ["glass_tir", "inside_box", "degenerate_rings"])
+def test_trap_scenes_on_gpu(small_textures, name, lod):
+    """TIR, refractive boxes with the shared 256-segment cap, origins inside boxes (T21), exact-zero
+    direction components (T5), degenerate quadric branch (T4), two textured rings in one shadow ray (T10)."""
+    import trap_scenes
+    w, h = (321, 181) if name == "inside_box" else (320, 180)
+    sc = trap_scenes.ALL[name](w, h)
+    ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=lod).render()
+    img, _i8, st = _render_gpu(sc, w, h, small_textures, {wrapper.RTX_OPT_TEXTURE_LOD: lod})
+    mx, nbad, nanbad = _compare(img, ref)
+    assert nanbad == 0 and mx <= TOL and nbad == 0, f"{name}: max diff {mx}, {nbad} over"
+    assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
+
+
 def test_moving_camera_and_animation(small_textures):
     """Per-frame update_buffer path (reference SceneManager.cpp:257-276): same context, new blocks."""
     w, h = 320, 180
