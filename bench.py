@@ -99,7 +99,7 @@ def main():
             gather.frame(pending[k & 1])
             pending[k & 1] = None
         gl.draw_bands(band_rows, rank, world, buf.data_ptr(), wrapper.RTX_RGBA32F, stream)
-        pending[k & 1] = gather.gather(buf)      # async; overlaps the next step's trace
+        pending[k & 1] = gather.gather(buf, k & 1)  # async; overlaps the next step's trace (recv slot k&1 on the root)
 
     def drain(pending):
         out = None

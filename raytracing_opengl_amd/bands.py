@@ -65,9 +65,12 @@ def unpermute(gathered: list[torch.Tensor], height: int, band_rows: int, world: 
 class FrameGather:
     """Pre-allocated gather of packed row bands to rank `dst`.
 
-    gather(local) starts the collective (async) and returns a handle; frame(handle) waits and returns
-    the un-permuted (H, W, C) frame on dst (None elsewhere).  `local` must hold max_local_rows rows
-    (pad rows are ignored).  On one rank it degenerates to a view of the local buffer.
+    gather(local, slot) starts the collective (async) and returns a handle; frame(handle) waits and
+    returns the un-permuted (H, W, C) frame on dst (None elsewhere).  `local` must hold
+    max_local_rows rows (pad rows are ignored).  `slot` (0/1) selects one of two receive-buffer sets on
+    the root so that the gather of frame k+1 may be issued before frame k has been un-permuted
+    (double buffering: a slot may be reused only after frame() was called on its previous handle).
+    On one rank it degenerates to a view of the local buffer.
     """
 
     def __init__(self, height: int, width: int, channels: int, band_rows: int, dtype, device, dst: int = 0, group=None):
@@ -79,22 +82,23 @@ class FrameGather:
         self.rows_local = local_rows(height, band_rows, self.rank, self.world)
         self.recv = None
         if self.world > 1 and self.rank == dst:
-            self.recv = [torch.empty((self.rows_max, width, channels), dtype=dtype, device=device) for _ in range(self.world)]
+            self.recv = [[torch.empty((self.rows_max, width, channels), dtype=dtype, device=device) for _ in range(self.world)]
+                         for _slot in range(2)]
 
     def new_local(self, dtype, device) -> torch.Tensor:
         return torch.empty((self.rows_max, self.width, self.channels), dtype=dtype, device=device)
 
-    def gather(self, local: torch.Tensor):
+    def gather(self, local: torch.Tensor, slot: int = 0):
         if self.world == 1:
-            return (None, local)
-        work = dist.gather(local, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
-        return (work, local)
+            return (None, local, slot)
+        work = dist.gather(local, self.recv[slot & 1] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        return (work, local, slot)
 
     def frame(self, handle):
-        work, local = handle
+        work, local, slot = handle
         if self.world == 1:
             return unpermute([local], self.height, self.band_rows, 1)
         work.wait()
         if self.rank != self.dst:
             return None
-        return unpermute(self.recv, self.height, self.band_rows, self.world)
+        return unpermute(self.recv[slot & 1], self.height, self.band_rows, self.world)

@@ -30,19 +30,28 @@ def _worker(rank, world, port, h, w, band_rows, q):
         full = _reference_frame(h, w)
         fg = bands.FrameGather(h, w, 4, band_rows, torch.float32, "cpu", dst=0)
         ok = True
-        for _frame in range(3):  # several frames through the double-buffered protocol
-            local = fg.new_local(torch.float32, "cpu").zero_()
+        # frames k = 0..4 through the double-buffered protocol of bench.py: gather k is issued while
+        # frame k-1 is still un-consumed; every frame carries a different payload (full * (k+1))
+        pending = [None, None]
+        locals_ = [fg.new_local(torch.float32, "cpu"), fg.new_local(torch.float32, "cpu")]
+
+        def check(handle, k):
+            out = fg.frame(handle)
+            return torch.equal(out, full * (k + 1)) if rank == 0 else out is None
+
+        for k in range(5):
+            if pending[k & 1] is not None:
+                ok = ok and check(*pending[k & 1])
+            local = locals_[k & 1].zero_()
             off = 0
             for b in bands.rank_bands(h, band_rows, rank, world):
                 y0, y1 = bands.band_span(h, band_rows, b)
-                local[off:off + (y1 - y0)] = full[y0:y1]
+                local[off:off + (y1 - y0)] = full[y0:y1] * (k + 1)
                 off += y1 - y0
             assert off == fg.rows_local
-            out = fg.frame(fg.gather(local))
-            if rank == 0:
-                ok = ok and torch.equal(out, full)
-            else:
-                ok = ok and out is None
+            pending[k & 1] = (fg.gather(local, k & 1), k)
+        for j in (1, 0):  # frames 3 and 4 are still pending, in that order
+            ok = ok and check(*pending[j])
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
