@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds", type=int, default=0)
     ap.add_argument("--cull", type=int, default=1)
+    ap.add_argument("--xcd", type=int, default=0, help="1: XCD-aware super-tile workgroup order; 0: row-major")
     ap.add_argument("--lod", type=int, default=1, help="1: mip chain + quad-derivative LOD (reference texture state); 0: level-0 bilinear")
     args = ap.parse_args()
 
@@ -74,6 +75,7 @@ def main():
     gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank, texture_lod=args.lod)
     gl.set_option(wrapper.RTX_OPT_CULL, args.cull)
     gl.set_option(wrapper.RTX_OPT_SCENE_LDS, args.lds)
+    gl.set_option(wrapper.RTX_OPT_XCD_REMAP, args.xcd)
 
     band_rows = ((H + 7) // 8) * 8 if world == 1 else bands.choose_band_rows(H, world)
     gather = bands.FrameGather(H, W, 4, band_rows, torch.float32, device, dst=0)
@@ -157,7 +159,7 @@ def main():
                                    f"RGBA32F target, seeded synthetic textures at reference sizes/{args.texture_scale}",
                        "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
                        "parallelism": "single GPU" if world == 1 else f"{world} GPUs, interleaved {band_rows}-row bands, RCCL gather to rank 0",
-                       "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod},
+                       "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd},
             "ms_per_frame": round(ms_per_step, 4),
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -68,8 +68,11 @@ typedef enum rtx_option {
                                 quadric / box / ring tests (parity-gated); 0: literal scans */
     RTX_OPT_COUNT_RAYS = 1,  /* 1: kernel also counts closest-hit and shadow rays (rtx_stats) */
     RTX_OPT_SCENE_LDS = 2,   /* 1: stage the scene tables into LDS per workgroup; 0: scalar (SMEM) loads */
-    RTX_OPT_TEXTURE_LOD = 3  /* 1 (default): mip chain + trilinear + quad-derivative LOD, the reference's texture
+    RTX_OPT_TEXTURE_LOD = 3, /* 1 (default): mip chain + trilinear + quad-derivative LOD, the reference's texture
                                 state (GLWrapper.cpp:337-343, rt.frag:326-338); 0: level-0 bilinear everywhere */
+    RTX_OPT_XCD_REMAP = 4    /* 1: workgroups are dealt to the 8 XCDs in 128x32-pixel super-tiles (texture lines stay in
+                                one XCD's L2); 0 (default): plain row-major order. Measured on the 4K default scene:
+                                FETCH_SIZE 96.3 vs 97.5 MB, kernel 0.939 vs 0.902 ms -- no reuse to win, so it is off. */
 } rtx_option;
 
 typedef struct rtx_stats {

@@ -12,6 +12,8 @@ struct RtLaunchParams {
     // row-band set traced by this launch: bands band_first, +band_stride, ... of band_rows rows
     // each, stored packed (rows_local rows in total) at out_*
     int32_t band_rows, band_first, band_stride, rows_local;
+    int32_t xcd_remap;        // 1: XCD-aware super-tile order (see rt_kernel.hip)
+    int32_t grid_x, grid_y, st_nx, st_ny;  // filled by rt_launch_trace
     float* out_f32;           // RGBA32F, 16 B/pixel, or nullptr
     uint32_t* out_u8;         // RGBA8, 4 B/pixel, or nullptr
     unsigned long long* counters;  // 4 x u64 (COUNT variant) or nullptr

@@ -89,7 +89,7 @@ struct rtx_context {
     float* d_fb_f32 = nullptr;
     uint32_t* d_fb_u8 = nullptr;
     // options
-    int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 1;
+    int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 1, opt_xcd = 0;
     unsigned long long* d_counters = nullptr;
     // timing
     hipEvent_t ev_start[EVENT_RING], ev_stop[EVENT_RING];
@@ -227,6 +227,7 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     p.band_first = band_first;
     p.band_stride = band_stride;
     p.rows_local = rows_local;
+    p.xcd_remap = ctx->opt_xcd;
     p.out_f32 = out_f32;
     p.out_u8 = out_u8;
     p.counters = ctx->d_counters;
@@ -476,6 +477,7 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_COUNT_RAYS: ctx->opt_count = value != 0; break;
         case RTX_OPT_SCENE_LDS: ctx->opt_lds = value != 0; break;
         case RTX_OPT_TEXTURE_LOD: ctx->opt_lod = value != 0; break;
+        case RTX_OPT_XCD_REMAP: ctx->opt_xcd = value != 0; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;
@@ -488,6 +490,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_COUNT_RAYS: *value = ctx->opt_count; break;
         case RTX_OPT_SCENE_LDS: *value = ctx->opt_lds; break;
         case RTX_OPT_TEXTURE_LOD: *value = ctx->opt_lod; break;
+        case RTX_OPT_XCD_REMAP: *value = ctx->opt_xcd; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;

@@ -131,6 +131,16 @@ def test_trap_scenes_on_gpu(small_textures, name, lod):
     assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
 
 
+@pytest.mark.parametrize("w,h", [(960, 540), (333, 207), (1000, 40)])
+def test_xcd_remap_is_a_pure_reordering(small_textures, w, h):
+    """The XCD-aware super-tile workgroup order must give the bit-identical frame and ray counts."""
+    sc = scenes.build_scene("default", w, h, 4)
+    a, _a8, sa = _render_gpu(sc, w, h, small_textures, {wrapper.RTX_OPT_XCD_REMAP: 1})
+    b, _b8, sb = _render_gpu(sc, w, h, small_textures, {wrapper.RTX_OPT_XCD_REMAP: 0})
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (sa["rays_closest"], sa["rays_shadow"]) == (sb["rays_closest"], sb["rays_shadow"])
+
+
 def test_moving_camera_and_animation(small_textures):
     """Per-frame update_buffer path (reference SceneManager.cpp:257-276): same context, new blocks."""
     w, h = 320, 180
