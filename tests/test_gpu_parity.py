@@ -208,6 +208,35 @@ def test_full_size_properties(mid_textures):
     gl.stop()
 
 
+@pytest.mark.parametrize("kind,depth,rows", [("quadric", 4, (0, 640, 1080, 1504, 2152)), ("torus", 6, (320, 1080, 1400))])
+def test_full_size_stress_configs(small_textures, kind, depth, rows):
+    """BASELINE.json configs[2] / configs[3] at their own size (3840x2160): two draws bit-identical, oracle
+    parity and exact ray counts on 8-row bands sampled across the frame (the oracle needs minutes for a
+    whole frame of these scenes)."""
+    import torch
+    w, h = 3840, 2160
+    sc = scenes.build_scene(kind, w, h, depth)
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.draw()
+    a = gl.read_pixels()
+    gl.draw()
+    b = gl.read_pixels()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    o = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    band = torch.zeros((8, w, 4), dtype=torch.float32, device="cuda:0")
+    for y0 in rows:
+        ref, cnt = o.render(y0, y0 + 8)
+        mx, nbad, nanbad = _compare(a[y0:y0 + 8], ref)
+        assert nanbad == 0 and mx <= TOL, (kind, y0, mx)
+        gl.draw_bands(8, y0 // 8, 1 << 20, band.data_ptr(), wrapper.RTX_RGBA32F)  # exactly the band starting at y0
+        gl.finish()
+        st = gl.stats()
+        assert (st["rays_closest"], st["rays_shadow"]) == (cnt["rays_closest"], cnt["rays_shadow"]), (kind, y0)
+        assert np.array_equal(band.cpu().numpy().view(np.uint32), a[y0:y0 + 8].view(np.uint32))
+    gl.stop()
+
+
 def test_error_behaviour():
     """Order and name errors mirror the reference's failure points (GLWrapper.cpp:360,370-375)."""
     gl = wrapper.GLWrapper(64, 64)
