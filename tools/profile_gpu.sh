@@ -10,7 +10,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH=${PROF_CMD:-"python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline $EXTRA"}
+BENCH=${PROF_CMD:-"python $REPO/bench.py --no-cpu-baseline $EXTRA"}
 cd /tmp
 echo "== kernel trace + stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
