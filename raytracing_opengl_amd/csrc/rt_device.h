@@ -1060,11 +1060,16 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
-            diffuse = diffuse + (((light_color * m.color) * m.diffuse) * intensity) / distDiv;
+            // directional lights have distDiv == 1 (rt.frag:703) and x / 1.0f == x exactly: the three IEEE
+            // divisions are skipped for them (wave-uniform branch on the light index)
+            const bool unit_div = li >= n_lp;
+            const f3 dterm = ((light_color * m.color) * m.diffuse) * intensity;
+            diffuse = diffuse + (unit_div ? dterm : dterm / distDiv);
             if (m.specular > 0) {
                 const f3 refl = gl_reflect(light_dir, normal);
                 const float specDp = gl_clamp(dot3(rd, refl), 0.0f, 1.0f);
-                specular = specular + ((light_color * powf(specDp, (float)m.specular)) * intensity) / distDiv;
+                const f3 sterm = (light_color * powf(specDp, (float)m.specular)) * intensity;
+                specular = specular + (unit_div ? sterm : sterm / distDiv);
             }
         }
     }
