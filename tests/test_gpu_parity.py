@@ -237,6 +237,25 @@ def test_full_size_stress_configs(small_textures, kind, depth, rows):
     gl.stop()
 
 
+def _golden_ids():
+    import golden_frames
+    import os
+    return golden_frames.FILES, [os.path.basename(p)[:-4] for p in golden_frames.FILES]
+
+
+@pytest.mark.parametrize("lod", [1, 0])
+@pytest.mark.parametrize("path", _golden_ids()[0], ids=_golden_ids()[1])
+def test_committed_golden_frames(path, lod):
+    """The HIP tracer against the committed golden vectors (inputs + expected frames in one .npz)."""
+    import golden_frames
+    g = golden_frames.load(path)
+    tex = {"textures": g["textures"], "cubemap": g["cubemap"]}
+    img, _i8, st = _render_gpu(g["scene"], g["width"], g["height"], tex, {wrapper.RTX_OPT_TEXTURE_LOD: lod})
+    mx, nbad, nanbad = _compare(img, g["frames"][lod])
+    assert nanbad == 0 and mx <= TOL and nbad == 0
+    assert (st["rays_closest"], st["rays_shadow"]) == g["rays"][lod]
+
+
 def test_error_behaviour():
     """Order and name errors mirror the reference's failure points (GLWrapper.cpp:360,370-375)."""
     gl = wrapper.GLWrapper(64, 64)
