@@ -364,17 +364,41 @@ static vec4 sample_cube(const orc_cubemap* c, vec3 d)
 #define ORC_MAX_MIPS 15
 typedef struct {
     const uint8_t* key_texels; int key_w, key_h, key_c;
+    uint64_t key_sum; /* FNV-1a of the level-0 bytes: the caller may reuse an address for other texels */
     int levels; int w[ORC_MAX_MIPS], h[ORC_MAX_MIPS];
     uint8_t* data[ORC_MAX_MIPS]; /* RGBA8 */
 } orc_mipchain;
 static orc_mipchain g_mips[16];
 static int g_mips_n = 0;
 
+static uint64_t fnv1a(const uint8_t* p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+/* validate != 0: re-hash the texels (done once per orc_render call, before the parallel region);
+ * validate == 0: trust the address key (lookups from inside the render). */
+static const orc_mipchain* mip_lookup(const orc_texture* t, int validate)
+{
+    if (t->width <= 0 || !t->texels) return NULL;
+    const size_t nbytes = (size_t)t->width * t->height * t->channels;
+    const uint64_t sum = validate ? fnv1a(t->texels, nbytes) : 0;
+    for (int k = 0; k < g_mips_n; k++)
+        if (g_mips[k].key_texels == t->texels && g_mips[k].key_w == t->width && g_mips[k].key_h == t->height && g_mips[k].key_c == t->channels) {
+            if (!validate || g_mips[k].key_sum == sum) return &g_mips[k];
+            for (int l = 0; l < g_mips[k].levels; l++) free(g_mips[k].data[l]); /* same address, other content: rebuild */
+            memmove(&g_mips[k], &g_mips[k + 1], (size_t)(g_mips_n - k - 1) * sizeof g_mips[0]);
+            g_mips_n--;
+            break;
+        }
+    return NULL;
+}
 static const orc_mipchain* mip_get(const orc_texture* t)
 {
     if (t->width <= 0 || !t->texels) return NULL;
-    for (int k = 0; k < g_mips_n; k++)
-        if (g_mips[k].key_texels == t->texels && g_mips[k].key_w == t->width && g_mips[k].key_h == t->height && g_mips[k].key_c == t->channels) return &g_mips[k];
+    const orc_mipchain* hit = mip_lookup(t, 0);
+    if (hit) return hit;
     if (g_mips_n == 16) { /* recycle the oldest */
         for (int l = 0; l < g_mips[0].levels; l++) free(g_mips[0].data[l]);
         memmove(&g_mips[0], &g_mips[1], 15 * sizeof g_mips[0]);
@@ -383,6 +407,7 @@ static const orc_mipchain* mip_get(const orc_texture* t)
     orc_mipchain* m = &g_mips[g_mips_n++];
     memset(m, 0, sizeof *m);
     m->key_texels = t->texels; m->key_w = t->width; m->key_h = t->height; m->key_c = t->channels;
+    m->key_sum = fnv1a(t->texels, (size_t)t->width * t->height * t->channels);
     int w = t->width, h = t->height;
     m->w[0] = w; m->h[0] = h;
     m->data[0] = (uint8_t*)malloc((size_t)w * h * 4);
@@ -1229,7 +1254,10 @@ int orc_render(const orc_frame* fr, int y0, int y1, float* out_rgba, orc_counter
     if (y0 < 0) y0 = 0;
     if (y1 > fr->fb_height) y1 = fr->fb_height;
     if (fr->texture_lod)
-        for (int k = 0; k < ORC_TEX_COUNT; k++) (void)mip_get(&fr->tex[k]); /* build mip chains before the parallel region */
+        for (int k = 0; k < ORC_TEX_COUNT; k++) { /* (re)build mip chains before the parallel region */
+            (void)mip_lookup(&fr->tex[k], 1);     /* drops a stale chain whose address was reused for other texels */
+            (void)mip_get(&fr->tex[k]);
+        }
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     else omp_set_num_threads(omp_get_num_procs());
@@ -1327,12 +1355,14 @@ float orc_kat_text_round_trip(float v) { return text_round_trip(v); }
 float orc_kat_log2(float v) { return orc_log2(v); }
 void orc_kat_sample2d_lod(const orc_texture* t, float u, float v, float lambda, float out[4])
 {
+    (void)mip_lookup(t, 1);
     vec4 c = sample2d_lod(t, v2(u, v), lambda);
     out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
 }
 /* copies mip level `level` (RGBA8) into out; returns its width<<16 | height, 0 if the level does not exist */
 int orc_kat_mip_level(const orc_texture* t, int level, uint8_t* out)
 {
+    (void)mip_lookup(t, 1);
     const orc_mipchain* m = mip_get(t);
     if (!m || level < 0 || level >= m->levels) return 0;
     memcpy(out, m->data[level], (size_t)m->w[level] * m->h[level] * 4);
