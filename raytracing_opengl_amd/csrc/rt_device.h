@@ -50,6 +50,13 @@
 
 namespace rtdev {
 
+// two-wide float vector: element-wise IEEE operations (v_pk_*_f32 on the device, SSE on the host)
+#if defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float v2f __attribute__((vector_size(8)));
+#endif
+
 // ------------------------------------------------------------------------------------------
 // small vector algebra (component order and association exactly as GLSL evaluates them)
 // ------------------------------------------------------------------------------------------
@@ -108,21 +115,37 @@ RT_HD f3 quat_rotate(f4 q, f3 v)
 }
 
 // Exact shortcut for rotations by the identity quaternion (floor slabs, un-rotated crates, ...):
-// with q = (+-0,+-0,+-0,1) every product in quat_rotate other than 1*v_i is a signed zero, so the
-// result equals v bit for bit PROVIDED every component of v is finite and non-zero (a zero
-// component could change sign, an infinite one would turn 0*inf into NaN). `plain3` is that
-// proviso; when it fails the full formula runs.
+// with q = (+-0,+-0,+-0,1) every product in quat_rotate other than 1*v_i is a signed zero and the
+// sums of those zeros come out as +0 whatever their signs, so for FINITE v the result is v with
+// each -0 component turned into +0, i.e. v + 0.0f component-wise, bit for bit (an infinite component
+// would turn 0*inf into NaN: then the full formula runs). Checked for all 8 zero-sign patterns of q
+// against quat_rotate on signed zeros, denormals, huge and random finite vectors (tests/test_culls.py).
+// `plain3` (finite and no zero component) is the stronger proviso under which the result is v itself.
 RT_HD bool quat_is_identity(f4 q) { return q.x == 0.0f && q.y == 0.0f && q.z == 0.0f && q.w == 1.0f; }
-RT_HD bool plain3(f3 v)
+RT_HD bool finite3(f3 v)
 {
     const float z = v.x * 0.0f + v.y * 0.0f + v.z * 0.0f;  // NaN iff some component is inf/NaN
-    return z == 0.0f && v.x != 0.0f && v.y != 0.0f && v.z != 0.0f;
+    return z == 0.0f;
 }
+RT_HD bool plain3(f3 v) { return finite3(v) && v.x != 0.0f && v.y != 0.0f && v.z != 0.0f; }
 RT_HD f3 quat_rotate_id(f4 q, bool identity, f3 v)
 {
-    f3 r = v;
-    if (!(identity && plain3(v))) r = quat_rotate(q, v);
+    f3 r = mk3(v.x + 0.0f, v.y + 0.0f, v.z + 0.0f);
+    if (!(identity && finite3(v))) r = quat_rotate(q, v);
     return r;
+}
+// pow() of the shading terms (rt.frag:689 specular, :716 Fresnel): x in [0,1], y >= 1. GLSL defines
+// pow(x,y) as exp2(y*log2(x)) at the implementation's precision; on the device it is exactly that on the
+// hardware log/exp units (4 instructions instead of ~160 for the correctly rounded libm routine).
+// Measured max abs error against double pow over [0,1] for y = 1..5000: 8.0e-8 (ocml powf: 6.2e-8),
+// tools/micro/pow_err.hip. Colour-only, covered by the 1e-4 tolerance (DESIGN.md "Numerics").
+RT_HD float rt_pow(float x, float y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+#else
+    return powf(x, y);
+#endif
 }
 
 // atan(y,x) / asin(x) of the equirect mapping (rt.frag:323-324): fixed float64 series, only
@@ -221,7 +244,7 @@ RT_HD float rt_log2(float xf)
 // Typed access to the DevScene blob. Array addresses are re-derived from the header offsets at
 // each use (two scalar ops) instead of being kept in 30 SGPRs for the whole kernel.
 struct SceneView {
-    const DevSceneHeader* h;   // counts, camera, offsets (kernel arguments on the device)
+    const DevSceneHeader* h;   // counts, camera, offsets
     const char* blob;
     template <class T> RT_HDM const T* at(uint32_t off) const { return reinterpret_cast<const T*>(blob + off); }
     RT_HDM const DevSphere* spheres() const { return at<DevSphere>(h->off_sphere); }
@@ -239,8 +262,7 @@ struct SceneView {
     RT_HDM const f4* torus_bound() const { return at<f4>(h->off_torus_bound); }
     RT_HDM const f4* ring_bound() const { return at<f4>(h->off_ring_bound); }
 };
-// `hdr` may live somewhere faster than the blob (the kernel passes a copy in its kernel arguments,
-// so counts, camera and array offsets do not sit behind a dependent load of the blob).
+// `hdr` normally is the blob's own first record; with the tables staged in LDS it stays in global memory.
 RT_HD SceneView make_view(const char* blob, const DevSceneHeader* hdr)
 {
     SceneView S;
@@ -594,28 +616,51 @@ struct TorusRay {  // ray-invariant terms of cTorus (rt.frag:445-455), hoisted o
     float axy, bxy, cxy;  // the same three over .xy
     float k;              // 4*R2
 };
-RT_HD f2 cmul(f2 p, f2 q) { return mk2(p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x); }
-RT_HD f2 torus_poly(f2 t, const TorusRay& w)
+// Complex numbers live in two-wide vectors (re, im), so the complex products and the polynomial's
+// real/imaginary halves evaluate as packed FP32 instructions: per half exactly the operations, operands
+// and association of the shader's cMul / cTorus / the Durand-Kerner update (rt.frag:438-476).
+RT_HD v2f c_xx(v2f v) { v2f r; r[0] = v[0]; r[1] = v[0]; return r; }
+RT_HD v2f c_yy(v2f v) { v2f r; r[0] = v[1]; r[1] = v[1]; return r; }
+RT_HD v2f c_yx(v2f v) { v2f r; r[0] = v[1]; r[1] = v[0]; return r; }
+RT_HD v2f mk2v(float x, float y) { v2f r; r[0] = x; r[1] = y; return r; }
+// (p.x*q.x - p.y*q.y, p.x*q.y + p.y*q.x); a - b is a + (-b) in IEEE arithmetic
+RT_HD v2f cmul(v2f p, v2f q)
 {
-    const f2 t2 = mk2(t.x * t.x - t.y * t.y, 2.0f * t.x * t.y);
-    f2 res = mk2(t2.x * w.a + 2.0f * t.x * w.b + w.c, t2.y * w.a + 2.0f * t.y * w.b + 0.0f);
+    const v2f a = c_xx(p) * q;
+    v2f b = c_yy(p) * c_yx(q);
+    b[0] = -b[0];
+    return a + b;
+}
+RT_HD v2f torus_poly(v2f t, const TorusRay& w)
+{
+    const v2f sq = t * t;                                        // (x*x, y*y)
+    const v2f two_t = t * 2.0f;                                  // (2*x, 2*y)
+    const v2f t2 = mk2v(sq[0] - sq[1], two_t[0] * t[1]);          // t*t as a complex number
+    v2f res = t2 * w.a + two_t * w.b + mk2v(w.c, 0.0f);
     res = cmul(res, res);
-    const f2 res2 = mk2(w.k * (t2.x * w.axy + 2.0f * t.x * w.bxy + w.cxy), w.k * (t2.y * w.axy + 2.0f * t.y * w.bxy + 0.0f));
-    return mk2(res.x - res2.x, res.y - res2.y);
+    const v2f res2 = (t2 * w.axy + two_t * w.bxy + mk2v(w.cxy, 0.0f)) * w.k;
+    return res - res2;
 }
-RT_HD float dk_step(f2& c0, f2 c1, f2 c2, f2 c3, const TorusRay& w)
+RT_HD float dk_step(v2f& c0, v2f c1, v2f c2, v2f c3, const TorusRay& w)
 {
-    f2 fc = torus_poly(c0, w);
-    const f2 den = cmul(mk2(c0.x - c1.x, c0.y - c1.y), cmul(mk2(c0.x - c2.x, c0.y - c2.y), mk2(c0.x - c3.x, c0.y - c3.y)));
-    const float dd = den.x * den.x + den.y * den.y;
-    fc = cmul(fc, mk2(den.x / dd, -den.y / dd));
-    c0.x -= fc.x;
-    c0.y -= fc.y;
-    return gl_max(fabsf(fc.x), fabsf(fc.y));
+    v2f fc = torus_poly(c0, w);
+    const v2f den = cmul(c0 - c1, cmul(c0 - c2, c0 - c3));
+    const v2f d2 = den * den;
+    const float dd = d2[0] + d2[1];
+    fc = cmul(fc, mk2v(den[0] / dd, -den[1] / dd));
+    c0 = c0 - fc;
+    return gl_max(fabsf(fc[0]), fabsf(fc[1]));
 }
+#if defined(RT_DK_STATS) && defined(__HIPCC__)
+__device__ unsigned long long g_dk[8];  // diagnostic build only: wave execs, lane solves, wave sweeps, lane sweeps, wave cycles
+#endif
 RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
 {
     const float eps = 0.001f;
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long _dk_t0 = clock64();
+    int _dk_sweeps = 0;
+#endif
     TorusRay w;
     w.a = dot3(rd, rd);
     w.b = dot3(ro, rd);
@@ -624,23 +669,46 @@ RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, 
     w.bxy = dot2(ro.x, ro.y, rd.x, rd.y);
     w.cxy = dot2(ro.x, ro.y, ro.x, ro.y);
     w.k = T.k.x;
-    f2 c0 = mk2(1.0f, 0.0f);
-    f2 c1 = mk2(0.4f, 0.9f);
-    f2 c2 = cmul(c1, mk2(0.4f, 0.9f));
-    f2 c3 = cmul(c2, mk2(0.4f, 0.9f));
+    v2f c0 = mk2v(1.0f, 0.0f);
+    v2f c1 = mk2v(0.4f, 0.9f);
+    v2f c2 = cmul(c1, mk2v(0.4f, 0.9f));
+    v2f c3 = cmul(c2, mk2v(0.4f, 0.9f));
     for (int i = 0; i < 60; i++) {
         float e = dk_step(c0, c1, c2, c3, w);
         e = gl_max(e, dk_step(c1, c2, c3, c0, w));
         e = gl_max(e, dk_step(c2, c3, c0, c1, w));
         e = gl_max(e, dk_step(c3, c0, c1, c2, w));
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+        _dk_sweeps++;
+#endif
         if (e < eps) break;  // per-lane exit: a converged lane must stop updating its roots (trap T14)
     }
-    float r0 = c0.x, r1 = c1.x, r2 = c2.x, r3 = c3.x;
-    if (fabsf(c0.y) > eps || r0 < 0.0f) r0 = 10000.0f;
-    if (fabsf(c1.y) > eps || r1 < 0.0f) r1 = 10000.0f;
-    if (fabsf(c2.y) > eps || r2 < 0.0f) r2 = 10000.0f;
-    if (fabsf(c3.y) > eps || r3 < 0.0f) r3 = 10000.0f;
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    {
+        unsigned long long m = __ballot(1);
+        const int first = __ffsll((long long)m) - 1;
+        int mx = 0;
+        while (m) { const int l = __ffsll((long long)m) - 1; const int v = __shfl(_dk_sweeps, l, 64); mx = v > mx ? v : mx; m &= m - 1; }
+        atomicAdd(&g_dk[1], 1ull);
+        atomicAdd(&g_dk[3], (unsigned long long)_dk_sweeps);
+        if ((int)(threadIdx.x & 63) == first) {
+            atomicAdd(&g_dk[0], 1ull);
+            atomicAdd(&g_dk[2], (unsigned long long)mx);
+            atomicAdd(&g_dk[4], (unsigned long long)clock64() - _dk_t0);
+        }
+        if (_dk_sweeps >= 60) atomicAdd(&g_dk[6], 1ull);
+    }
+#endif
+    float r0 = c0[0], r1 = c1[0], r2 = c2[0], r3 = c3[0];
+    if (fabsf(c0[1]) > eps || r0 < 0.0f) r0 = 10000.0f;
+    if (fabsf(c1[1]) > eps || r1 < 0.0f) r1 = 10000.0f;
+    if (fabsf(c2[1]) > eps || r2 < 0.0f) r2 = 10000.0f;
+    if (fabsf(c3[1]) > eps || r3 < 0.0f) r3 = 10000.0f;
     t = gl_min(gl_min(r0, r1), gl_min(r2, r3));
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    if (t > 0.0f && t < 100.0f && t < tmin) atomicAdd(&g_dk[7], 1ull);
+    else if (t > 0.0f && t < 100.0f) atomicAdd(&g_dk[5], 1ull);   // real root, but beyond the limit
+#endif
     return t > 0.0f && t < 100.0f && t < tmin;
 }
 // Conservative pre-test in WORLD space (no rotation needed): true = the solve can be skipped.
@@ -1133,7 +1201,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
             if (m.specular > 0) {
                 const f3 refl = gl_reflect(light_dir, normal);
                 const float specDp = gl_clamp(dot3(rd, refl), 0.0f, 1.0f);
-                const f3 sterm = (light_color * powf(specDp, (float)m.specular)) * intensity;
+                const f3 sterm = (light_color * rt_pow(specDp, (float)m.specular)) * intensity;
                 specular = specular + (unit_div ? sterm : sterm / distDiv);
             }
         }
@@ -1145,7 +1213,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
 RT_HD float get_fresnel(f3 normal, f3 rd, float reflection)
 {
     const float ndotv = gl_clamp(dot3(normal, -rd), 0.0f, 1.0f);
-    return reflection + (1.0f - reflection) * powf(1.0f - ndotv, 5.0f);
+    return reflection + (1.0f - reflection) * rt_pow(1.0f - ndotv, 5.0f);
 }
 RT_HD float fresnel_reflect_amount(float n1, float n2, f3 normal, f3 incident, float refl)
 {
@@ -1233,7 +1301,7 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
         const f3 d = quat_rotate_id(Q.quat, ident, rd);
         const f3 tm = d * t + o;
         const f3 n = mk3(2.0f * Q.pos_a.w * tm.x, 2.0f * Q.bcde.x * tm.y + Q.bcde.w, 2.0f * Q.bcde.y * tm.z + Q.bcde.z);
-        h.normal = normalize3(quat_rotate(Q.qinv, n));
+        h.normal = normalize3(quat_rotate_id(Q.qinv, ident, n));
     }
     if (on && type == TYPE_BOX) {  // + tri-planar texture, rt.frag:428-436
         const DevBox& B = S.boxes()[num];
@@ -1242,11 +1310,12 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
         f3 nor = mk3(0.0f, 0.0f, 0.0f);
         RayBoxCtx bctx;
         intersect_box(B, ro, rd, RT_FLT_MAX, tt, nor, bctx);  // re-derive the winning box's normal (+inf tmin: same result path)
-        h.normal = quat_rotate(B.qinv, nor);
+        const bool ident = quat_is_identity(B.quat);   // then qinv = (-0,-0,-0,1) is one too
+        h.normal = quat_rotate_id(B.qinv, ident, nor);
         if (__builtin_bit_cast(int, B.form_tex.w) != 0) {
-            lpos = quat_rotate(B.quat, xyz(B.pos));
-            lp = quat_rotate(B.quat, pt);
-            ln = quat_rotate(B.quat, h.normal);
+            lpos = quat_rotate_id(B.quat, ident, xyz(B.pos));
+            lp = quat_rotate_id(B.quat, ident, pt);
+            ln = quat_rotate_id(B.quat, ident, h.normal);
             box_tex = true;
             slot = TEX_BOX;
             u = 0.5f * (lp.z - lpos.z) - 0.5f;
@@ -1262,7 +1331,7 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
         const f3 pos = o + d * t;
         const float s = dot3(pos, pos) - P.radii.w;
         const f3 n = pos * mk3(s - P.radii.z * 1.0f, s - P.radii.z * 1.0f, s - P.radii.z * -1.0f);
-        h.normal = normalize3(quat_rotate(P.qinv, n));
+        h.normal = normalize3(quat_rotate_id(P.qinv, ident, n));
     }
     if (on && type == TYPE_RING) {  // + strip texture, rt.frag:391-397
         const DevRing& R = S.rings()[num];

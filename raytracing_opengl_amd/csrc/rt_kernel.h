@@ -5,7 +5,6 @@
 #include "rt_device.h"
 
 struct RtLaunchParams {
-    rtdev::DevSceneHeader hdr; // copy of the blob's header: counts, camera, array offsets without a dependent load
     const char* scene;        // DevScene blob (device memory)
     int32_t scene_bytes;
     int32_t fb_w, fb_h;       // framebuffer size = gl_FragCoord range

@@ -16,6 +16,17 @@
 
 using namespace rtdev;
 
+#ifdef RT_DK_STATS
+extern "C" __attribute__((visibility("default"))) int rtx_debug_dk_stats(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dk), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dk), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 #ifdef RT_PHASE_TIMERS
 __device__ unsigned long long g_phase[PH_COUNT];
 extern "C" __attribute__((visibility("default"))) int rtx_debug_phase_counters(unsigned long long* out, int reset)
@@ -101,7 +112,11 @@ __global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
         __syncthreads();
         blob = smem;
     }
-    const SceneView S = make_view(blob, &p.hdr);
+    // The header (counts, camera, array offsets) is read from the blob with scalar loads where it is used.
+    // A copy in the kernel arguments was measured slower: the compiler keeps all of it in SGPRs, runs out,
+    // and parks the excess in VGPR lanes -- v_writelane/v_readlane are VALU issue slots, and VALU issue
+    // is what bounds this kernel (4K default scene: 765 -> 741 us without the copy).
+    const SceneView S = make_view(blob, reinterpret_cast<const DevSceneHeader*>(p.scene));
 
     LaneCounters cnt = {};
 #ifdef RT_PHASE_TIMERS

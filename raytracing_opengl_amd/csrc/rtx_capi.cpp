@@ -218,7 +218,6 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     }
     RtLaunchParams p;
     std::memset(&p, 0, sizeof p);
-    std::memcpy(&p.hdr, ctx->blob.data(), sizeof p.hdr);
     p.scene = ctx->d_scene;
     p.scene_bytes = ctx->scene_bytes;
     p.fb_w = ctx->width;

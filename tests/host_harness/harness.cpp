@@ -120,6 +120,42 @@ int harness_kat(int type, const void* record, const float ro[3], const float rd[
     return 0;
 }
 
+// quat_rotate_id's shortcut: for every identity quaternion (all 8 zero-sign patterns) and finite v the full
+// rotation formula must give v + 0.0f bit for bit; with a non-finite component the shortcut must not be taken.
+// Returns the number of mismatches over special values (signed zeros, denormals, huge) and n random bit patterns.
+int harness_identity_rotation_mismatches(int n_random, unsigned seed)
+{
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto same = [&](f3 a, f3 b) {
+        auto eq = [&](float x, float y) { return bits(x) == bits(y) || (x != x && y != y); };
+        return eq(a.x, b.x) && eq(a.y, b.y) && eq(a.z, b.z);
+    };
+    const float inf = __builtin_inff(), nan = __builtin_nanf("");
+    const float vals[] = {-1.0f, -0.0f, 0.0f, 1.0f, 0.3f, -2.5f, 1e-42f, -1e-42f, 3e38f, -3e38f, 1e-30f, inf, -inf, nan};
+    int bad = 0;
+    uint32_t st = seed ? seed : 1u;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 17; st ^= st << 5; return st; };
+    for (int sgn = 0; sgn < 8; sgn++) {
+        const f4 q = mk4((sgn & 1) ? -0.0f : 0.0f, (sgn & 2) ? -0.0f : 0.0f, (sgn & 4) ? -0.0f : 0.0f, 1.0f);
+        if (!quat_is_identity(q)) bad++;
+        for (float x : vals) for (float y : vals) for (float z : vals) {
+            const f3 v = mk3(x, y, z);
+            if (!same(quat_rotate_id(q, true, v), quat_rotate(q, v))) bad++;
+        }
+        for (int k = 0; k < n_random; k++) {
+            float f[3];
+            for (int j = 0; j < 3; j++) {
+                const uint32_t u = rnd();
+                std::memcpy(&f[j], &u, 4);
+                if ((rnd() % 7u) == 0u) f[j] = (rnd() & 1u) ? -0.0f : 0.0f;
+            }
+            const f3 v = mk3(f[0], f[1], f[2]);
+            if (!same(quat_rotate_id(q, true, v), quat_rotate(q, v))) bad++;
+        }
+    }
+    return bad;
+}
+
 // exhaustive check of the divide-free unorm8 against byte/255.0f
 int harness_unorm8_mismatches()
 {

@@ -132,3 +132,12 @@ def test_default_scene_quadrics_get_a_bound(built):
         pos = struct.unpack_from("<3f", rec, 112)
         c, h = _check(oracle.TYPE_SURFACE, rec, rng, pos, 3.0, 400)
         assert c > 100 and h > 20, (i, c, h)
+
+
+def test_identity_rotation_shortcut_is_exact(built):
+    """quat_rotate_id: identity quaternion (any zero signs) + finite v == the full formula, bit for bit."""
+    import ctypes
+    lib = harness.lib()
+    lib.harness_identity_rotation_mismatches.restype = ctypes.c_int
+    lib.harness_identity_rotation_mismatches.argtypes = [ctypes.c_int, ctypes.c_uint]
+    assert lib.harness_identity_rotation_mismatches(300000, 12345) == 0

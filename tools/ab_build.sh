@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build A/B variants of librtx_hip.so into raytracing_opengl_amd/variants/ (git-ignored, shipped by gpurun).
+#   tools/ab_build.sh name1 "-DFLAG_A" name2 "-DFLAG_B -DRT_WAVES_PER_EU=3" ...
+# The variant's flags are appended to the product flags (a later -D/-f wins).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p raytracing_opengl_amd/variants
+BASE="-DRT_WAVES_PER_EU=4 --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc"
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  ( /opt/rocm/bin/hipcc $BASE $flags -shared -o raytracing_opengl_amd/variants/librtx_hip_$name.so \
+      raytracing_opengl_amd/csrc/rt_kernel.hip -x hip raytracing_opengl_amd/csrc/rtx_capi.cpp 2>&1 | grep -v "warning\|^$" | head -5; echo "built $name" ) &
+done
+wait

@@ -30,7 +30,7 @@ def variant(sc, drop=None, keep_first=None, depth=None):
     return v
 
 
-def time_scene(sc, ts, steps=20):
+def time_scene(sc, ts, steps=int(os.environ.get("ABLATE_STEPS", "20"))):
     gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"])
     gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
     gl.draw()

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Static facts about the product kernel <CULL=1,COUNT=0,LDS=0>: instruction mix, registers, spills.
+# usage: tools/isa_stats.sh [extra hipcc flags]
+cd "$(dirname "$0")/.."
+OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
+/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=4 --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
+python3 - "$OUT" <<'PY'
+import re,sys
+txt=open(sys.argv[1]).read()
+i=txt.find('rt_trace_kernelILb1ELb0ELb0EEEv14RtLaunchParams:')
+j=txt.find('.end_amdhsa_kernel',i)
+body=txt[i:j]
+ins=[l.strip() for l in body.split('\n') if l.startswith('\t') and not l.strip().startswith(('.',';'))]
+valu=[l for l in ins if l.startswith('v_')]
+c=lambda p: sum(l.startswith(p) for l in ins)
+print('instrs',len(ins),'valu',len(valu),'pk',c('v_pk_'),'writelane',c('v_writelane'),'readlane',c('v_readlane'),'s_load',c('s_load'),'scratch',c('scratch_'), 'div',c('v_div_fixup'))
+print(re.findall(r'; (?:NumVgprs|ScratchSize|NumSgprs|Occupancy): \d+', txt[j:j+4000])[:4])
+PY
