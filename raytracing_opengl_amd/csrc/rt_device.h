@@ -1171,16 +1171,15 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
             light_dir = xyz(L.pos_r2) - pt;
             dist = length3(light_dir);
             distDiv = 1.0f + L.atten.x * dist + L.atten.y * dist * dist;
+            light_dir = normalize3(light_dir);   // calcShade2
         } else {
             const DevLightDirect& L = S.lights_direct()[li - n_lp];
             light_color = xyz(L.color_intensity);
             intensity = L.color_intensity.w;
-            light_dir = -xyz(L.direction);
+            light_dir = xyz(L.dir_n);            // normalize(-direction), hoisted to the packer
             dist = RT_MAXDIST;
             distDiv = 1.0f;
         }
-        // calcShade2
-        light_dir = normalize3(light_dir);
         const float dp = gl_clamp(dot3(normal, light_dir), 0.0f, 1.0f);
         light_color = light_color * dp;
         if (COUNT && on) cnt.shadow_ref++;
@@ -1258,15 +1257,18 @@ RT_HD void load_material(const DevMaterial& M, Hit& h)
     h.absorb = mk3(M.absorb[0], M.absorb[1], M.absorb[2]);
 }
 
-// `on` = lane has a hit to describe. Texture fetches sit in wave-uniform control flow.
-RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 rd, f3 pt, float t, int num, int type, Hit& h)
+RT_HD void clear_hit(Hit& h)
 {
     h.normal = mk3(0.0f, 0.0f, 0.0f);
     h.alpha = 1.0f;
+    h.bias = 0.0f;
     h.surf.color = mk3(0.0f, 0.0f, 0.0f);
     h.surf.diffuse = 0.0f; h.surf.specular = 0; h.surf.kd = 0.0f; h.surf.ks = 0.0f;
     h.reflection = 0.0f; h.refraction = 0.0f; h.absorb = mk3(0.0f, 0.0f, 0.0f);
-
+}
+// `on` = lane has a hit to describe (h was cleared by the caller). Texture fetches sit in wave-uniform control flow.
+RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f3 rd, f3 pt, float t, int num, int type, Hit& h)
+{
     // texture request of this lane: slot < 0 = none. Boxes need three taps (tri-planar).
     int slot = -1;
     float u = 0.0f, v = 0.0f;
@@ -1414,7 +1416,10 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         RT_PH_LAP(cnt, PH_SCAN);
         const f3 pt = ro + rd * tm;
         Hit h;
-        get_hit_info(S, T, hit, ro, rd, pt, tm, num, type, h);
+        clear_hit(h);
+        // wave-uniform skip: a wave whose live lanes all missed (sky tiles, mirror rays leaving the scene)
+        // has no hit to describe and, below, nothing to shade
+        if (RT_ANY(hit)) get_hit_info(S, T, hit, ro, rd, pt, tm, num, type, h);
         RT_PH_LAP(cnt, PH_HITINFO);
 
         // ---- classify: everything that does not need the shaded colour happens BEFORE the shading call
@@ -1515,7 +1520,8 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
 
         RT_PH_LAP(cnt, PH_SKY);
         // ---- the single shading site ----
-        const f3 col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
+        f3 col = mk3(0.0f, 0.0f, 0.0f);
+        if (RT_ANY(act != ACT_NONE)) col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
         RT_PH_LAP(cnt, PH_SHADE);
 
         // ---- apply + advance ----

@@ -92,9 +92,11 @@ __global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
     const int ty = ((lane >> 4) & 3) * 2 + ((lane >> 1) & 1);
     const int x = bx * 32 + wave * 8 + tx;
     const int row_local = by * 8 + ty;  // row inside this launch's packed band set
-    const int band_j = row_local / p.band_rows;
-    const int within = row_local - band_j * p.band_rows;
-    const int y = (p.band_first + band_j * p.band_stride) * p.band_rows + within;
+    // band_rows is a multiple of 8, so the eight rows of a workgroup lie in ONE band: the band index is
+    // wave-uniform (scalar division), not a per-lane integer division
+    const int band_j = (by * 8) / p.band_rows;
+    const int y0_wg = (p.band_first + band_j * p.band_stride) * p.band_rows + (by * 8 - band_j * p.band_rows);
+    const int y = y0_wg + ty;
     const bool real = (x < p.fb_w) && (y < p.fb_h) && (row_local < p.rows_local);
     // With quad-derivative LOD the pixels that complete a 2x2 quad beyond an odd-sized framebuffer run
     // as helper invocations (traced, never stored or counted), like a rasteriser's helper lanes.
@@ -132,8 +134,7 @@ __global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
     const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
     const int x2 = bx * 32 + wave2 * 8 + ((lane2 >> 2) & 3) * 2 + (lane2 & 1);
     const int row2 = by * 8 + ((lane2 >> 4) & 3) * 2 + ((lane2 >> 1) & 1);
-    const int band2 = row2 / p.band_rows;
-    const int y2 = (p.band_first + band2 * p.band_stride) * p.band_rows + (row2 - band2 * p.band_rows);
+    const int y2 = y0_wg + ((lane2 >> 4) & 3) * 2 + ((lane2 >> 1) & 1);
     const bool real2 = (x2 < p.fb_w) && (y2 < p.fb_h) && (row2 < p.rows_local);
     if (!real2) cnt = LaneCounters{};
     if (real2) {

@@ -355,6 +355,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         DevLightDirect s;
         s.direction = rd3(p, 0, 0.0f);
         s.color_intensity = rd4(p, 16);
+        const f3 ln = normalize3(-xyz(s.direction));
+        s.dir_n = mk4(ln.x, ln.y, ln.z, 0.0f);
         std::memcpy(reinterpret_cast<DevLightDirect*>(blob.data() + h.off_light_direct) + i, &s, sizeof s);
     }
     return true;

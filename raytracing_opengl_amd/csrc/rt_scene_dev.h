@@ -86,6 +86,8 @@ struct alignas(16) DevLightPoint {
 struct alignas(16) DevLightDirect {
     f4 direction;      // xyz as given (not normalised)
     f4 color_intensity;
+    f4 dir_n;          // normalize(-direction): the light vector of calcShade (rt.frag:700-703), hoisted -- the same
+                       // IEEE sqrt and divisions on the same operands, done once on the host instead of per shaded lane
 };
 
 struct alignas(16) DevSceneHeader {

@@ -76,6 +76,13 @@ def main():
         cases.append(("closest-only d1: torus only", variant(base, drop=NL + ["boxes_buf", "spheres_buf", "surfaces_buf", "rings_buf"], depth=1)))
         cases.append(("closest-only d1: ring only", variant(base, drop=NL + ["boxes_buf", "spheres_buf", "surfaces_buf", "toruses_buf"], depth=1)))
         cases.append(("closest-only d1: nothing", variant(base, drop=NL + ["boxes_buf", "spheres_buf", "surfaces_buf", "toruses_buf", "rings_buf"], depth=1)))
+    if os.environ.get("ABLATE_SERIES") == "fixed":
+        cases = [("empty scene, 0 iterations", variant(base, drop=list(IDX), depth=0)),
+                 ("empty scene (sky only)", variant(base, drop=list(IDX))),
+                 ("empty scene, no sky texture", None),
+                 ("floor box only, no lights, d1", variant(base, drop=NL + ["surfaces_buf", "spheres_buf", "toruses_buf", "rings_buf"], keep_first={"boxes_buf": 1}, depth=1)),
+                 ("floor box only, no lights, d4", variant(base, drop=NL + ["surfaces_buf", "spheres_buf", "toruses_buf", "rings_buf"], keep_first={"boxes_buf": 1})),
+                 ("floor box only, 2 lights, d1", variant(base, drop=["surfaces_buf", "spheres_buf", "toruses_buf", "rings_buf"], keep_first={"boxes_buf": 1}, depth=1))]
     only = os.environ.get("ABLATE_ONLY")
     for name, sc in cases:
         if only and only not in name:
