@@ -166,6 +166,18 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "note": "HBM-write roofline of the RGBA32F frame (16 B/pixel); the path is ALU/divergence-bound, see DESIGN.md"},
         }
+        # The kernel's real ceiling is VALU issue, which the bound/peak vocabulary above cannot name: report it beside.
+        valu_file = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(valu_file) and world == 1 and (W, H, args.depth, args.scene, args.cull, args.lod) == (WIDTH, HEIGHT, DEPTH, SCENE, 1, 1):
+            try:
+                v = json.load(open(valu_file))
+                rate = v["valu_insts_per_launch"] / (kernel_ms * 1e-3)
+                out["roofline"]["valu"] = {"insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1),
+                                           "peak": round(v["peak_wave_insts_per_s"] / 1e9, 1), "unit": "G wave-instructions/s",
+                                           "frac": round(rate / v["peak_wave_insts_per_s"], 4), "lane_utilisation": v["lane_utilisation"],
+                                           "note": "instruction count from rocprofv3 PMC (profiles/valu.json), duration live"}
+            except Exception:
+                pass
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file) and world == 1 and (W, H, args.depth, args.scene) == (WIDTH, HEIGHT, DEPTH, SCENE):
             try:
