@@ -122,6 +122,10 @@ RT_HD f3 quat_rotate(f4 q, f3 v)
 // against quat_rotate on signed zeros, denormals, huge and random finite vectors (tests/test_culls.py).
 // `plain3` (finite and no zero component) is the stronger proviso under which the result is v itself.
 RT_HD bool quat_is_identity(f4 q) { return q.x == 0.0f && q.y == 0.0f && q.z == 0.0f && q.w == 1.0f; }
+// The packer evaluates quat_is_identity once per primitive and stores the answer as an integer in a spare
+// record field: on the device a wave-uniform FLOAT comparison still costs VALU instructions (four v_cmp per
+// test, no scalar float compare on gfx950), an integer one is a scalar s_cmp.
+RT_HD bool ident_flag(float w) { return __builtin_bit_cast(int, w) != 0; }
 RT_HD bool finite3(f3 v)
 {
     const float z = v.x * 0.0f + v.y * 0.0f + v.z * 0.0f;  // NaN iff some component is inf/NaN
@@ -554,7 +558,7 @@ RT_HD bool intersect_plane(f3 ro, f3 rd, f3 n, f3 p, float tmin, float& t)
 // rt.frag:372-390. uv is written only on a hit (the shader's global opt_uv)
 RT_HD bool intersect_ring(const DevRing& R, f3 ro, f3 rd, float tmin, float& t, f2& uv)
 {
-    const bool ident = quat_is_identity(R.quat);
+    const bool ident = ident_flag(R.normal.w);
     const f3 d = quat_rotate_id(R.quat, ident, rd);
     const f3 o = quat_rotate_id(R.quat, ident, ro - xyz(R.pos_tex));
     t = -o.z / d.z;
@@ -582,7 +586,7 @@ struct RayBoxCtx {
 };
 RT_HD bool intersect_box(const DevBox& B, f3 ro, f3 rd, float tmin, float& t, f3& nor, RayBoxCtx& ctx)
 {
-    const bool ident = quat_is_identity(B.quat);
+    const bool ident = ident_flag(B.pos.w);
     if (ident && !ctx.have) {
         ctx.have = true;
         ctx.rd_plain = plain3(rd);
@@ -799,7 +803,7 @@ RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
 template <bool CULL>
 RT_HD bool intersect_torus_c(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t, bool& solved)
 {
-    const bool ident = quat_is_identity(T.quat);
+    const bool ident = ident_flag(T.pos.w);
     const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos));
     const f3 d = quat_rotate_id(T.quat, ident, rd);
     solved = false;
@@ -817,7 +821,7 @@ RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t
 RT_HD bool is_between(f3 v, f3 lo, f3 hi) { return (v.x > lo.x && v.y > lo.y && v.z > lo.z) && (v.x < hi.x && v.y < hi.y && v.z < hi.z); }
 RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t)
 {
-    const bool ident = quat_is_identity(Q.quat);
+    const bool ident = ident_flag(Q.vmax.w);
     const f3 ro = quat_rotate_id(Q.quat, ident, ro_w - xyz(Q.pos_a));
     const f3 rd = quat_rotate_id(Q.quat, ident, rd_w);
     const float a = Q.pos_a.w, b = Q.bcde.x, c = Q.bcde.y, d = Q.bcde.z, e = Q.bcde.w, f = Q.f_vmin.x;
@@ -1298,7 +1302,7 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
     if (on && type == TYPE_SURFACE) {  // getSurfaceNormal rt.frag:573-584
         const DevSurface& Q = S.surfaces()[num];
         load_material(S.mats(TYPE_SURFACE)[num], h);
-        const bool ident = quat_is_identity(Q.quat);
+        const bool ident = ident_flag(Q.vmax.w);
         const f3 o = quat_rotate_id(Q.quat, ident, ro - xyz(Q.pos_a));
         const f3 d = quat_rotate_id(Q.quat, ident, rd);
         const f3 tm = d * t + o;
@@ -1312,7 +1316,7 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
         f3 nor = mk3(0.0f, 0.0f, 0.0f);
         RayBoxCtx bctx;
         intersect_box(B, ro, rd, RT_FLT_MAX, tt, nor, bctx);  // re-derive the winning box's normal (+inf tmin: same result path)
-        const bool ident = quat_is_identity(B.quat);   // then qinv = (-0,-0,-0,1) is one too
+        const bool ident = ident_flag(B.pos.w);   // then qinv = (-0,-0,-0,1) is one too
         h.normal = quat_rotate_id(B.qinv, ident, nor);
         if (__builtin_bit_cast(int, B.form_tex.w) != 0) {
             lpos = quat_rotate_id(B.quat, ident, xyz(B.pos));
@@ -1327,7 +1331,7 @@ RT_HD void get_hit_info(const SceneView& S, const TexTable& T, bool on, f3 ro, f
     if (on && type == TYPE_TORUS) {  // getTorusNormal rt.frag:488-496
         const DevTorus& P = S.tori()[num];
         load_material(S.mats(TYPE_TORUS)[num], h);
-        const bool ident = quat_is_identity(P.quat);
+        const bool ident = ident_flag(P.pos.w);
         const f3 o = quat_rotate_id(P.quat, ident, ro - xyz(P.pos));
         const f3 d = quat_rotate_id(P.quat, ident, rd);
         const f3 pos = o + d * t;

@@ -262,7 +262,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.pos_a = mk4(rdf(p, 112), rdf(p, 116), rdf(p, 120), a);
         s.bcde = mk4(b, c, dd, e);
         s.f_vmin = mk4(f, vmin.x, vmin.y, vmin.z);
-        s.vmax = mk4(vmax.x, vmax.y, vmax.z, 0.0f);
+        s.vmax = mk4(vmax.x, vmax.y, vmax.z, int_bits(quat_is_identity(s.quat) ? 1 : 0));
         s.qinv = quat_inv(s.quat);
         // cull data (surface_cull in rt_device.h): symmetric M for the p2 pre-check + a bounding
         // sphere of the part of the surface inside the world-space clip box (may not exist)
@@ -302,7 +302,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const unsigned char* p = blocks[BLK_BOXES].data() + static_cast<size_t>(i) * SZ_BOX;
         DevBox s;
         s.quat = rd4(p, 64);
-        s.pos = rd3(p, 80, 0.0f);
+        s.pos = rd3(p, 80, int_bits(quat_is_identity(s.quat) ? 1 : 0));
         s.form_tex = rd3(p, 96, int_bits(rdi(p, 108)));
         s.qinv = quat_inv(s.quat);
         std::memcpy(reinterpret_cast<DevBox*>(blob.data() + h.off_box) + i, &s, sizeof s);
@@ -312,7 +312,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const unsigned char* p = blocks[BLK_TORUSES].data() + static_cast<size_t>(i) * SZ_TORUS;
         DevTorus s;
         s.quat = rd4(p, 64);
-        s.pos = rd3(p, 80, 0.0f);
+        s.pos = rd3(p, 80, int_bits(quat_is_identity(s.quat) ? 1 : 0));
         const float R = rdf(p, 96), r = rdf(p, 100);
         const float R2 = R * R, r2 = r * r;
         s.radii = mk4(R, r, R2, r2);
@@ -335,7 +335,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const double ring_rb = std::sqrt(static_cast<double>(r2)) * 1.001 + 0.01;  // NaN for a negative r2: never culled
         s.radii = mk4(r1, r2, r2 - r1, static_cast<float>(ring_rb * ring_rb));
         const f3 nrm = quat_rotate(quat_inv(s.quat), mk3(0.0f, 0.0f, -1.0f));
-        s.normal = mk4(nrm.x, nrm.y, nrm.z, 0.0f);
+        s.normal = mk4(nrm.x, nrm.y, nrm.z, int_bits(quat_is_identity(s.quat) ? 1 : 0));
         std::memcpy(reinterpret_cast<DevRing*>(blob.data() + h.off_ring) + i, &s, sizeof s);
         const f4 rbnd = mk4(s.pos_tex.x, s.pos_tex.y, s.pos_tex.z, s.radii.w);
         std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_ring_bound) + i, &rbnd, sizeof rbnd);

@@ -50,7 +50,7 @@ struct alignas(16) DevSurface {
     f4 pos_a;          // pos xyz, a
     f4 bcde;           // b, c, d, e
     f4 f_vmin;         // f, v_min xyz (world-space clip box, trap T6)
-    f4 vmax;           // v_max xyz, w unused
+    f4 vmax;           // v_max xyz, w = int bits: 1 if quat is the identity (any zero signs)
     f4 qinv;           // quat_inv(quat)
 };
 struct alignas(16) DevSurfaceCull {  // first-level record of a quadric (surface_cull)
@@ -60,13 +60,13 @@ struct alignas(16) DevSurfaceCull {  // first-level record of a quadric (surface
 };
 struct alignas(16) DevBox {
     f4 quat;
-    f4 pos;            // xyz
+    f4 pos;            // xyz, w = int bits: 1 if quat is the identity
     f4 form_tex;       // half extents xyz, w = textureNum as float bits (int)
     f4 qinv;
 };
 struct alignas(16) DevTorus {
     f4 quat;
-    f4 pos;            // xyz
+    f4 pos;            // xyz, w = int bits: 1 if quat is the identity
     f4 radii;          // R, r, R*R, r*r
     f4 k;              // x = 4*R*R, y = world cull-sphere radius^2, z = puck radius^2 ((R+r) inflated), w = hole radius^2 ((R-r) deflated, 0 = none)
     f4 qinv;
@@ -76,7 +76,7 @@ struct alignas(16) DevRing {
     f4 quat;
     f4 pos_tex;        // pos xyz, w = textureNum (int bits)
     f4 radii;          // r1, r2 (squared radii, trap T7), r2 - r1, w = cull radius^2 (r2 inflated)
-    f4 normal;         // rotate(quat_inv(quat), (0,0,-1))  (rt.frag:391-394)
+    f4 normal;         // rotate(quat_inv(quat), (0,0,-1))  (rt.frag:391-394), w = int bits: 1 if quat is the identity
 };
 struct alignas(16) DevLightPoint {
     f4 pos_r2;         // xyz, w = radius*radius (light sphere, closest-hit only)
