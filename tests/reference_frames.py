@@ -1,0 +1,96 @@
+"""Shared by tools/gen_reference_frames.py and tests/test_reference_frames.py: the cases for which the REFERENCE's own
+fragment shader was executed (Mesa llvmpipe, oracle/ref_gl) and its RGBA32F output committed as
+tests/golden/ref_frame_<name>.npz.
+
+Each fixture holds the nine std140 scene blocks, the texture-set scale (the procedural textures are regenerated from
+raytracing_opengl_amd/textures.py and checked against a stored SHA-256) and the reference frame.
+
+`limits` are acceptance bounds for |candidate - reference| per pixel (max over RGB): fraction of pixels allowed over
+1e-4 and over 1e-2. They are the measured oracle-vs-reference figures with head-room; the reasons the two cannot agree
+everywhere are listed in DESIGN.md section 2 (llvmpipe evaluates normalize() as v*rsqrt(dot), fuses differently, and its
+mip-map level selection is an approximation the GL specification allows; Durand-Kerner stops at 1e-3)."""
+import hashlib
+import os
+import struct
+
+import numpy as np
+
+from raytracing_opengl_amd import scenes, textures
+from raytracing_opengl_amd.scenes import BLOCK_NAMES, SceneBlocks
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+W, H = 256, 144
+TEX_SCALE = 8
+
+
+def _strip_textures(sc, spheres=True, rings=True, boxes=True):
+    """textureNum := 0 (rt.frag:749,763,772): untextured variant of a scene."""
+    def patch(name, rec, off):
+        b = bytearray(sc.blocks[name])
+        for i in range(len(b) // rec):
+            b[i * rec + off:i * rec + off + 4] = struct.pack("<i", 0)
+        sc.blocks[name] = bytes(b)
+    if spheres: patch("spheres_buf", 112, 96)
+    if rings: patch("rings_buf", 112, 92)
+    if boxes: patch("boxes_buf", 112, 108)
+    return sc
+
+
+def _trap(name):
+    import trap_scenes
+    return trap_scenes.ALL[name](W, H)
+
+
+# name -> (scene builder, textured?, (max fraction > 1e-4, max fraction > 1e-2))
+CASES = {
+    "default_untextured": (lambda: _strip_textures(scenes.build_scene("default", W, H, 4)), False, (0.004, 0.0006)),
+    "default": (lambda: scenes.build_scene("default", W, H, 4), True, (0.10, 0.012)),
+    "quadric": (lambda: scenes.build_scene("quadric", W, H, 4), False, (0.006, 0.0006)),
+    "torus": (lambda: scenes.build_scene("torus", W, H, 4), False, (0.09, 0.003)),
+    "trap_inside_box": (lambda: _trap("inside_box"), False, (0.0005, 0.0)),
+    "trap_degenerate_rings_untextured": (lambda: _strip_textures(_trap("degenerate_rings")), False, (0.0005, 0.0)),
+    "trap_degenerate_rings": (lambda: _trap("degenerate_rings"), True, (0.12, 0.03)),
+    "trap_glass_tir": (lambda: _trap("glass_tir"), False, (0.06, 0.012)),
+}
+
+
+def texture_set():
+    return textures.default_texture_set(scale=TEX_SCALE)
+
+
+def input_digest(sc, ts) -> str:
+    h = hashlib.sha256()
+    h.update(repr(tuple(int(v) for v in sc.defines[:9])).encode())
+    h.update(np.asarray(sc.defines[9:15], dtype=np.float32).tobytes())
+    for name in BLOCK_NAMES:
+        h.update(sc.blocks.get(name, b""))
+    for uniform, unit, img in ts["textures"]:
+        h.update(uniform.encode()); h.update(bytes([unit])); h.update(np.ascontiguousarray(img).tobytes())
+    for f in ts["cubemap"]:
+        h.update(np.ascontiguousarray(f).tobytes())
+    return h.hexdigest()
+
+
+def path(name):
+    return os.path.join(GOLDEN, f"ref_frame_{name}.npz")
+
+
+def load(name):
+    """-> dict(scene, textures, cubemap, frame (H,W,3 float32, row 0 = bottom), limits, renderer)"""
+    z = np.load(path(name))
+    d = z["defines"]
+    defines = tuple(int(v) for v in d[:9]) + tuple(float(np.float32(v)) for v in d[9:15])
+    blocks = {n: z["block_" + n].tobytes() if ("block_" + n) in z.files else b"" for n in BLOCK_NAMES}
+    sc = SceneBlocks(defines=defines, blocks=blocks)
+    ts = texture_set()
+    if input_digest(sc, ts) != str(z["digest"]):
+        raise RuntimeError(f"inputs of reference frame '{name}' no longer reproduce (textures.py changed?)")
+    return dict(scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
+                frame=z["frame"], limits=CASES[name][2], renderer=str(z["renderer"]))
+
+
+def compare(candidate, reference_rgb):
+    """-> (fraction of pixels over 1e-4, fraction over 1e-2, max abs difference); NaN anywhere counts as over both."""
+    d = np.abs(candidate[..., :3].astype(np.float64) - reference_rgb.astype(np.float64)).max(axis=2)
+    d = np.where(np.isnan(d), np.inf, d)
+    return float((d > 1e-4).mean()), float((d > 1e-2).mean()), float(d.max())

@@ -1,0 +1,72 @@
+"""Parity against the REFERENCE ITSELF: tests/golden/ref_frame_*.npz hold the output of the reference's own fragment
+shader (assets/shaders/rt.frag, executed on Mesa llvmpipe by oracle/ref_gl + tools/gen_reference_frames.py in the build
+container). The oracle, the host build of the product's device code and -- on the GPU box -- the HIP kernel are compared
+with those pixels. Limits and their reasons: tests/reference_frames.py, DESIGN.md section 2."""
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import reference_frames as rf
+from oracle import oracle
+
+NAMES = list(rf.CASES)
+
+
+def _check(name, img, ref):
+    f4, f2, mx = rf.compare(img, ref["frame"])
+    lim4, lim2 = ref["limits"]
+    assert f4 <= lim4, f"{name}: {100*f4:.3f}% of pixels differ from the reference shader by more than 1e-4 (limit {100*lim4:.2f}%)"
+    assert f2 <= lim2, f"{name}: {100*f2:.3f}% of pixels differ from the reference shader by more than 1e-2 (limit {100*lim2:.2f}%)"
+    return f4, f2, mx
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_shader(built, name):
+    ref = rf.load(name)
+    assert "llvmpipe" in ref["renderer"]
+    img, _ = oracle.OracleScene(ref["scene"], ref["width"], ref["height"], ref["textures"], ref["cubemap"], texture_lod=1).render(0, ref["height"], threads=8)
+    _check(name, img, ref)
+
+
+def test_exact_cases_are_exact(built):
+    """Where nothing implementation-defined is involved (no mip-mapped textures, no iterative solver, no degenerate glass
+    box), the oracle reproduces the reference shader's pixels to float noise."""
+    for name in ("trap_inside_box", "trap_degenerate_rings_untextured"):
+        ref = rf.load(name)
+        img, _ = oracle.OracleScene(ref["scene"], ref["width"], ref["height"], ref["textures"], ref["cubemap"], texture_lod=1).render(0, ref["height"], threads=8)
+        _f4, _f2, mx = rf.compare(img, ref["frame"])
+        assert mx < 1e-4, (name, mx)
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if not rf.CASES[n][1]])
+def test_product_device_code_on_host_matches_reference_shader(built, name):
+    """The product's device header compiled for the host (no quads there: untextured cases only)."""
+    ref = rf.load(name)
+    img, _ = harness.render(ref["scene"], ref["width"], ref["height"], ref["textures"], ref["cubemap"], cull=True)
+    _check(name, img, ref)
+
+
+def test_reference_run_is_reproducible(built):
+    """Build container only: executing the reference's shader again gives the committed pixels bit for bit."""
+    from oracle.ref_gl import ref_gl
+    if not ref_gl.available():
+        pytest.skip("needs /root/reference and Mesa llvmpipe (build container only)")
+    os.environ.setdefault("GALLIVM_PERF", "no_aos_sampling,no_quad_lod")
+    name = "trap_inside_box"
+    ref = rf.load(name)
+    again, _ = ref_gl.render(ref["scene"], ref["width"], ref["height"], ref["textures"], ref["cubemap"])
+    assert np.array_equal(again[..., :3], ref["frame"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_kernel_matches_reference_shader(built, name):
+    from raytracing_opengl_amd import wrapper
+    ref = rf.load(name)
+    gl = wrapper.make_renderer(ref["scene"], ref["width"], ref["height"], ref["textures"], ref["cubemap"])
+    gl.draw()
+    img = gl.read_pixels(wrapper.RTX_RGBA32F)
+    gl.stop()
+    _check(name, img, ref)

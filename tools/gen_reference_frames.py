@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Run the REFERENCE's own fragment shader (read from /root/reference at run time) on Mesa llvmpipe for the cases of
+tests/reference_frames.py and write tests/golden/ref_frame_<name>.npz. Build container only (needs /root/reference and
+the Mesa software rasteriser); the fixtures it writes are data: scene blocks + the reference's output pixels.
+
+llvmpipe is asked for its precise paths: GALLIVM_PERF=no_aos_sampling,no_quad_lod (float texture filtering instead of
+8-bit fixed point, per-pixel instead of per-quad level of detail)."""
+import os
+import sys
+
+os.environ.setdefault("GALLIVM_PERF", "no_aos_sampling,no_quad_lod")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import reference_frames as rf  # noqa: E402
+from oracle import oracle  # noqa: E402
+from oracle.ref_gl import ref_gl  # noqa: E402
+from raytracing_opengl_amd.scenes import BLOCK_NAMES  # noqa: E402
+
+
+def main():
+    if not ref_gl.available():
+        sys.exit("needs /root/reference and Mesa's swrast_dri.so (build container only)")
+    print("GL:", ref_gl.renderer())
+    ts = rf.texture_set()
+    only = sys.argv[1:]
+    for name, (build, textured, limits) in rf.CASES.items():
+        if only and name not in only:
+            continue
+        sc = build()
+        ref, inactive = ref_gl.render(sc, rf.W, rf.H, ts["textures"], ts["cubemap"])
+        arrays = dict(width=rf.W, height=rf.H, frame=np.ascontiguousarray(ref[..., :3]), digest=rf.input_digest(sc, ts),
+                      renderer=ref_gl.renderer() + " GALLIVM_PERF=" + os.environ["GALLIVM_PERF"], tex_scale=rf.TEX_SCALE,
+                      defines=np.asarray(sc.defines, dtype=np.float64), inactive_blocks=",".join(sorted(inactive)))
+        for n in BLOCK_NAMES:
+            if sc.blocks.get(n):
+                arrays["block_" + n] = np.frombuffer(sc.blocks[n], dtype=np.uint8)
+        np.savez_compressed(rf.path(name), **arrays)
+        img, _ = oracle.OracleScene(sc, rf.W, rf.H, ts["textures"], ts["cubemap"], texture_lod=1).render(0, rf.H, threads=os.cpu_count() or 1)
+        f4, f2, mx = rf.compare(img, ref[..., :3])
+        assert np.all(ref[..., 3] == 1.0)
+        print(f"{name:34s} oracle vs reference: {100*f4:7.3f}% of pixels > 1e-4, {100*f2:7.3f}% > 1e-2, max {mx:.3g}   "
+              f"(limits {100*limits[0]:.2f}% / {100*limits[1]:.2f}%)  {os.path.getsize(rf.path(name))//1024} KB")
+
+
+if __name__ == "__main__":
+    main()
