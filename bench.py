@@ -9,11 +9,14 @@ tests/test_gpu_parity.py) and is measured once, untimed, with the counting kerne
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into
 interleaved row bands (raytracing_opengl_amd/bands.py), every rank traces its bands, and the frame
-is gathered to rank 0 over RCCL each step -> "scaling": "strong".
+is gathered to rank 0 over RCCL each step -> "scaling": "strong". The gathered frame is RGBA8 by default --
+the format of the reference's framebuffer (GLWrapper.cpp:127,209-222); the trace itself is the same f32
+computation (--target rgba32f gathers the 16 B/pixel parity buffer instead: 4x the xGMI traffic).
 
 Extra objects on the JSON line:
   roofline     HBM-write roofline of the trace kernel: W*H*16 B of RGBA32F per launch / mean kernel
-               time from HIP events on the launch stream, against 8 TB/s.
+               time from HIP events on the launch stream, against 8 TB/s; .valu = the ceiling that actually binds
+               (VALU instructions per launch from profiles/valu.json / live duration vs the chip's issue rate).
   cpu_baseline the oracle (scalar C restatement of the shader, all host cores) timed on one full
                frame of the same workload, rank 0, N = 1 only.
 """
@@ -51,6 +54,9 @@ def main():
     ap.add_argument("--cull", type=int, default=1)
     ap.add_argument("--xcd", type=int, default=0, help="1: XCD-aware super-tile workgroup order; 0: row-major")
     ap.add_argument("--lod", type=int, default=1, help="1: mip chain + quad-derivative LOD (reference texture state); 0: level-0 bilinear")
+    ap.add_argument("--target", choices=("auto", "rgba32f", "rgba8"), default="auto",
+                    help="colour target the bands are traced into and gathered as. auto: rgba32f (the parity buffer) on one GPU, "
+                         "rgba8 -- what the reference's framebuffer holds (GLWrapper.cpp:127,209-222) -- for N > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,13 +84,15 @@ def main():
     gl.set_option(wrapper.RTX_OPT_XCD_REMAP, args.xcd)
 
     band_rows = ((H + 7) // 8) * 8 if world == 1 else bands.choose_band_rows(H, world)
-    gather = bands.FrameGather(H, W, 4, band_rows, torch.float32, device, dst=0)
-    bufs = [gather.new_local(torch.float32, device) for _ in range(2)]
+    target = args.target if args.target != "auto" else ("rgba32f" if world == 1 else "rgba8")
+    tgt_dtype, tgt_format, px_bytes = (torch.float32, wrapper.RTX_RGBA32F, 16) if target == "rgba32f" else (torch.uint8, wrapper.RTX_RGBA8, 4)
+    gather = bands.FrameGather(H, W, 4, band_rows, tgt_dtype, device, dst=0)
+    bufs = [gather.new_local(tgt_dtype, device) for _ in range(2)]
     stream = torch.cuda.current_stream(device).cuda_stream
 
     # exact reference-defined ray count of this rank's bands (untimed, counting kernel variant)
     gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
-    gl.draw_bands(band_rows, rank, world, bufs[0].data_ptr(), wrapper.RTX_RGBA32F, stream)
+    gl.draw_bands(band_rows, rank, world, bufs[0].data_ptr(), tgt_format, stream)
     torch.cuda.synchronize(device)
     st = gl.stats()
     rays_local = st["rays_closest"] + st["rays_shadow"]
@@ -100,7 +108,7 @@ def main():
         if pending[k & 1] is not None:          # the gather that last read this buffer must be done
             gather.frame(pending[k & 1])
             pending[k & 1] = None
-        gl.draw_bands(band_rows, rank, world, buf.data_ptr(), wrapper.RTX_RGBA32F, stream)
+        gl.draw_bands(band_rows, rank, world, buf.data_ptr(), tgt_format, stream)
         pending[k & 1] = gather.gather(buf, k & 1)  # async; overlaps the next step's trace (recv slot k&1 on the root)
 
     def drain(pending):
@@ -140,7 +148,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_frame * args.steps / elapsed / 1e6
-        px_bytes_launch = gather.rows_local * W * 16  # algorithmic HBM bytes of one launch on this rank
+        px_bytes_launch = gather.rows_local * W * px_bytes  # algorithmic HBM bytes of one launch on this rank
         achieved = px_bytes_launch / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mray/s at 3840x2160 depth-4 default scene (reference-defined rays: closest-hit + shadow scans)",
@@ -156,15 +164,15 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.scene} scene (reference main.cpp:43-132, t=0), {W}x{H}, reflection depth {args.depth}, "
-                                   f"RGBA32F target, seeded synthetic textures at reference sizes/{args.texture_scale}",
+                                   f"{target.upper()} target, seeded synthetic textures at reference sizes/{args.texture_scale}",
                        "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
-                       "parallelism": "single GPU" if world == 1 else f"{world} GPUs, interleaved {band_rows}-row bands, RCCL gather to rank 0",
+                       "parallelism": "single GPU" if world == 1 else f"{world} GPUs, interleaved {band_rows}-row bands, RCCL gather of the {target.upper()} frame to rank 0",
                        "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd},
             "ms_per_frame": round(ms_per_step, 4),
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "note": "HBM-write roofline of the RGBA32F frame (16 B/pixel); the path is ALU/divergence-bound, see DESIGN.md"},
+                         "note": f"HBM-write roofline of the {target.upper()} frame ({px_bytes} B/pixel); the path is bound by VALU issue, see roofline.valu and DESIGN.md"},
         }
         # The kernel's real ceiling is VALU issue, which the bound/peak vocabulary above cannot name: report it beside.
         valu_file = os.path.join(ROOT, "profiles", "valu.json")
@@ -200,7 +208,7 @@ def main():
                                    "sample": f"{reps} full {W}x{H} depth-{args.depth} frames of the same workload (mean {cpu_s:.2f} s each), "
                                              f"oracle/rt_oracle.c, OpenMP over rows"}
             # the oracle frame is there anyway: report full-size parity next to the timing
-            img = frame.cpu().numpy() if frame is not None else None
+            img = frame.cpu().numpy() if (frame is not None and target == "rgba32f") else None
             if img is not None:
                 d = np.abs(img - ref)
                 out["parity"] = {"max_abs_diff": float(np.nanmax(d)), "over_1e-4": int((d > 1e-4).sum()),

@@ -18,22 +18,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _reference_frame(h, w):
+def _reference_frame(h, w, dtype=torch.float32):
     g = torch.Generator().manual_seed(5)
+    if dtype == torch.uint8:   # the RGBA8 target the multi-GPU bench gathers (values kept small: the payload is scaled by k+1)
+        return torch.randint(0, 40, (h, w, 4), generator=g, dtype=torch.uint8)
     return torch.rand((h, w, 4), generator=g, dtype=torch.float32)
 
 
-def _worker(rank, world, port, h, w, band_rows, q):
+def _worker(rank, world, port, h, w, band_rows, q, dtype=torch.float32):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        full = _reference_frame(h, w)
-        fg = bands.FrameGather(h, w, 4, band_rows, torch.float32, "cpu", dst=0)
+        full = _reference_frame(h, w, dtype)
+        fg = bands.FrameGather(h, w, 4, band_rows, dtype, "cpu", dst=0)
         ok = True
         # frames k = 0..4 through the double-buffered protocol of bench.py: gather k is issued while
         # frame k-1 is still un-consumed; every frame carries a different payload (full * (k+1))
         pending = [None, None]
-        locals_ = [fg.new_local(torch.float32, "cpu"), fg.new_local(torch.float32, "cpu")]
+        locals_ = [fg.new_local(dtype, "cpu"), fg.new_local(dtype, "cpu")]
 
         def check(handle, k):
             out = fg.frame(handle)
@@ -57,13 +59,14 @@ def _worker(rank, world, port, h, w, band_rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w,band_rows", [(64, 24, 16), (72, 16, 16), (100, 8, 8)])
-def test_two_rank_gather_reassembles_frame(h, w, band_rows):
+@pytest.mark.parametrize("h,w,band_rows,dtype", [(64, 24, 16, torch.float32), (72, 16, 16, torch.float32), (100, 8, 8, torch.float32),
+                                                  (104, 12, 8, torch.uint8)])
+def test_two_rank_gather_reassembles_frame(h, w, band_rows, dtype):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, band_rows, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, band_rows, q, dtype)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]

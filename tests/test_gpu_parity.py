@@ -187,6 +187,27 @@ def test_row_bands_reassemble_the_frame(small_textures):
     gl.stop()
 
 
+def test_rgba8_row_bands_reassemble_the_rgba8_frame(small_textures):
+    """The multi-GPU bench gathers the RGBA8 target: banded RGBA8 draws == the full RGBA8 frame, byte for byte."""
+    import torch
+    from raytracing_opengl_amd import bands
+    w, h, world, band_rows = 328, 200, 4, 8
+    sc = scenes.build_scene("default", w, h, 4)
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.draw()
+    full = torch.from_numpy(gl.read_pixels(wrapper.RTX_RGBA8))
+    parts = []
+    rows_max = bands.max_local_rows(h, band_rows, world)
+    for r in range(world):
+        buf = torch.zeros((rows_max, w, 4), dtype=torch.uint8, device="cuda:0")
+        gl.draw_bands(band_rows, r, world, buf.data_ptr(), wrapper.RTX_RGBA8)
+        gl.finish()
+        parts.append(buf.cpu())
+    frame = bands.unpermute(parts, h, band_rows, world)
+    assert torch.equal(frame, full.view(h, w, 4))
+    gl.stop()
+
+
 def test_full_size_properties(mid_textures):
     """BASELINE size (3840x2160, depth 4): size-independent properties instead of a full oracle frame:
     (1) oracle parity on a set of rows sampled across the frame, (2) exact ray count on those rows is
