@@ -165,6 +165,10 @@ typedef struct glref_tex2d {
     int width, height, channels;
     int clamp_to_edge;         /* 0: GL_REPEAT */
     const unsigned char* texels;
+    /* diagnostic only: n_levels > 0 uploads these RGBA8 levels (level 0 first, sizes halved with floor) instead of
+     * texels + glGenerateMipmap, to separate "which mip texels" from "which level and weights" when comparing samplers */
+    int n_levels;
+    const unsigned char* const* levels;
 } glref_tex2d;
 typedef struct glref_cube {
     int size, channels, gen_mipmap;
@@ -246,8 +250,19 @@ int glref_render(const char* vert_src, const char* frag_src, int w, int h, int n
         const GLenum fmt = tex[k].channels == 1 ? GL_RED : (tex[k].channels == 3 ? GL_RGB : GL_RGBA);
         p_glActiveTexture(GL_TEXTURE0 + tex[k].unit);
         p_glBindTexture(GL_TEXTURE_2D, texid[k]);
-        p_glTexImage2D(GL_TEXTURE_2D, 0, (GLint)fmt, tex[k].width, tex[k].height, 0, fmt, GL_UNSIGNED_BYTE, tex[k].texels);
-        p_glGenerateMipmap(GL_TEXTURE_2D);
+        if (tex[k].n_levels > 0) {
+            int lw = tex[k].width, lh = tex[k].height;
+            p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+            for (int L = 0; L < tex[k].n_levels; L++) {
+                p_glTexImage2D(GL_TEXTURE_2D, L, GL_RGBA8, lw, lh, 0, GL_RGBA, GL_UNSIGNED_BYTE, tex[k].levels[L]);
+                lw = lw > 1 ? lw / 2 : 1; lh = lh > 1 ? lh / 2 : 1;
+            }
+            p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAX_LEVEL, tex[k].n_levels - 1);
+            p_glPixelStorei(GL_UNPACK_ALIGNMENT, 4);
+        } else {
+            p_glTexImage2D(GL_TEXTURE_2D, 0, (GLint)fmt, tex[k].width, tex[k].height, 0, fmt, GL_UNSIGNED_BYTE, tex[k].texels);
+            p_glGenerateMipmap(GL_TEXTURE_2D);
+        }
         const GLint wrap = tex[k].clamp_to_edge ? GL_CLAMP_TO_EDGE : GL_REPEAT;
         p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, wrap);
         p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, wrap);

@@ -21,7 +21,8 @@ BLOCKS = ("scene_buf", "spheres_buf", "planes_buf", "surfaces_buf", "boxes_buf",
 
 class _Tex(ctypes.Structure):
     _fields_ = [("uniform_name", ctypes.c_char_p), ("unit", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int),
-                ("channels", ctypes.c_int), ("clamp_to_edge", ctypes.c_int), ("texels", ctypes.c_void_p)]
+                ("channels", ctypes.c_int), ("clamp_to_edge", ctypes.c_int), ("texels", ctypes.c_void_p),
+                ("n_levels", ctypes.c_int), ("levels", ctypes.POINTER(ctypes.c_void_p))]
 
 
 class _Cube(ctypes.Structure):
@@ -78,7 +79,25 @@ def shader_sources(defines) -> tuple[str, str]:
     return vert, frag
 
 
-def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube_mipmap: bool = False):
+def _oracle_mip_chain(arr):
+    """RGBA8 mip levels as the oracle builds them (diagnostic: see glref_tex2d.levels)."""
+    from oracle import oracle
+    ol = oracle.lib()
+    ol.orc_kat_mip_level.restype = ctypes.c_int
+    ol.orc_kat_mip_level.argtypes = [ctypes.POINTER(oracle.Texture), ctypes.c_int, ctypes.c_void_p]
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    ot = oracle.Texture(arr.shape[1], arr.shape[0], ch, 0, arr.ctypes.data)
+    levels, L = [], 0
+    while True:
+        buf = np.empty(arr.shape[0] * arr.shape[1] * 4, np.uint8)
+        r = ol.orc_kat_mip_level(ctypes.byref(ot), L, buf.ctypes.data)
+        if r == 0:
+            return levels
+        levels.append(np.ascontiguousarray(buf[: (r >> 16) * (r & 0xffff) * 4]))
+        L += 1
+
+
+def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube_mipmap: bool = False, oracle_mips: bool = False):
     """One frame of the reference's program. Returns (H, W, 4) float32, row 0 = bottom row, and the set of block
     names the linked program does not contain (the reference would exit on those)."""
     l = lib()
@@ -103,7 +122,14 @@ def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube
         keep.append(arr)
         nm = uniform.encode()
         keep.append(nm)
-        tarr[k] = _Tex(nm, int(unit), arr.shape[1], arr.shape[0], ch, 0, arr.ctypes.data)
+        n_levels, lv = 0, None
+        if oracle_mips:
+            chain = _oracle_mip_chain(arr)
+            keep.append(chain)
+            lv = (ctypes.c_void_p * len(chain))(*[c.ctypes.data for c in chain])
+            keep.append(lv)
+            n_levels = len(chain)
+        tarr[k] = _Tex(nm, int(unit), arr.shape[1], arr.shape[0], ch, 0, arr.ctypes.data, n_levels, ctypes.cast(lv, ctypes.POINTER(ctypes.c_void_p)) if lv else None)
     cube = None
     if cubemap is not None:
         faces = [None if f is None else np.ascontiguousarray(f, dtype=np.uint8) for f in cubemap]

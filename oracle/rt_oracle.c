@@ -89,7 +89,11 @@ typedef struct {
     const void* lights_direct_buf;
     orc_cubemap skybox;
     orc_texture tex[ORC_TEX_COUNT];
-    int32_t texture_lod; /* 0 = level-0 bilinear everywhere; 1 = mip chain + quad-derivative LOD */
+    int32_t texture_lod; /* 0 = level-0 bilinear everywhere; 1 = mip chain + quad-derivative LOD (DESIGN.md "Texture rule");
+                            2 = as 1, but the implicit level of detail is computed the way Mesa llvmpipe does it,
+                            lambda = 0.5 * L(rho^2) with L(x) = exponent(x) + mantissa(x) - 1 (piecewise-linear log2).
+                            DIAGNOSTIC: used only to show that the residual against the reference's shader run on
+                            llvmpipe is that approximation (tests/test_reference_frames.py) */
 } orc_frame;
 
 typedef struct {
@@ -577,6 +581,12 @@ static void quad_resolve(quad_t* q, const orc_frame* fr)
             const float rx = sqrtf((ddx.x * w) * (ddx.x * w) + (ddx.y * h) * (ddx.y * h));
             const float ry = sqrtf((ddy.x * w) * (ddy.x * w) + (ddy.y * h) * (ddy.y * h));
             lambda = orc_log2(gl_max(rx, ry));
+            if (fr->texture_lod == 2) {
+                const float r2 = gl_max(rx * rx, ry * ry);
+                int e;
+                const float m = frexpf(r2, &e); /* r2 = m * 2^e, m in [0.5,1) */
+                lambda = r2 > 0.0f ? 0.5f * ((float)(e - 1) + (2.0f * m - 1.0f)) : -1000.0f;
+            }
         }
         res[k] = sample2d_lod(t, q->lane[k].uv, lambda);
     }
