@@ -10,8 +10,8 @@
  * fixtures or golden images for this path, but its device half -- the GLSL fragment shader
  * -- runs in the build container on Mesa's llvmpipe software rasteriser, head-less (oracle/ref_gl/glref.c loads
  * swrast_dri.so through the DRI loader interface; the shader text is read from /root/reference at run time).
- * tools/gen_reference_frames.py executes it for eight cases (default scene with and without textures,
- * quadric-heavy, torus-heavy, three trap scenes) and commits the pixels as tests/golden/ref_frame_*.npz;
+ * tools/gen_reference_frames.py executes it for nine cases (default scene with and without textures,
+ * quadric-heavy, torus-heavy, four trap scenes) and commits the pixels as tests/golden/ref_frame_*.npz;
  * tests/test_reference_frames.py compares this oracle, the host build of the product's device code and the HIP
  * kernel with them. Agreement (fraction of pixels beyond 1e-4): 0.000 % on the two trap scenes without
  * implementation-defined ingredients (max difference 3e-5), 0.13 % / 0.17 % on the untextured default and the

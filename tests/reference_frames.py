@@ -51,6 +51,7 @@ CASES = {
     "trap_degenerate_rings_untextured": (lambda: _strip_textures(_trap("degenerate_rings")), False, (0.0005, 0.0)),
     "trap_degenerate_rings": (lambda: _trap("degenerate_rings"), True, (0.12, 0.03)),
     "trap_glass_tir": (lambda: _trap("glass_tir"), False, (0.06, 0.012)),
+    "trap_planes_glass": (lambda: _trap("planes_glass"), False, (0.003, 0.0005)),
 }
 # Diagnostic fixture: the default scene again, but the GL textures were given the ORACLE's mip levels (glTexImage2D per
 # level) instead of glGenerateMipmap, so that only level selection and filtering are compared. Checked with the oracle in

@@ -54,4 +54,25 @@ def quadric_degenerate_and_rings(w, h, depth=4):
         cam_pos=(0.0, 0.5, -2.0))
 
 
-ALL = {"glass_tir": glass_and_tir, "inside_box": camera_inside_box_and_axis_rays, "degenerate_rings": quadric_degenerate_and_rings}
+def planes_lights_and_glass_spheres(w, h, depth=5):
+    """Well-conditioned refraction (two glass spheres in a row: i-- without the box pathology, T2; absorbDistance carried
+    from the first sphere into the second, T12; TIR inside), planes seen from the front and from behind (one-sided and not
+    shadowing, T1), a hollow sphere that shadows like a solid one (T8), a big point-light sphere in view and in mirror
+    rays (closest-hit only, never an occluder; getReflectedColor's light branch, T3), an opaque ring casting a shadow."""
+    glass = material((1, 1, 1), 120, 0.1, 1.33, (0.35, 0.05, 0.2), 1.0)
+    dense = material((1, 1, 1), 60, 0.05, 1.7, (0.05, 0.3, 0.3), 1.0)
+    return make_scene(
+        w, h, depth,
+        spheres=[sphere((-0.9, 0.2, 4.0), 0.8, glass), sphere((-0.7, 0.3, 6.5), 1.0, dense),
+                 sphere((1.8, 0.0, 5.0), 0.9, material((0.9, 0.3, 0.2), 40, 0.0), hollow=True),
+                 sphere((3.2, -0.6, 3.6), 0.5, material((0.2, 0.8, 0.3), 90, 0.6))],
+        planes=[plane((0, 1, 0), (0, -1.2, 0), material((0.7, 0.7, 0.75), 25, 0.25)),      # floor, seen from above
+                plane((0, 1, 0), (0, 3.0, 0), material((1.0, 0.1, 0.1), 10, 0.0)),         # "ceiling" facing up: seen from below -> invisible
+                plane((0.3, 0.2, -1), (0, 0, 12.0), material((0.3, 0.4, 0.8), 15, 0.1))],  # back wall, un-normalised normal
+        rings=[ring((2.6, 1.6, 4.6), 0.3, 0.9, material((0.9, 0.8, 0.1), 30, 0.0), quat=quat_euler(1.2, 0.3, 0.0))],
+        lights_point=[light_point((0.6, 2.2, 3.2), 0.35)], lights_direct=[light_direct((-0.4, -1, 0.5))],
+        cam_pos=(0.2, 0.4, -2.5))
+
+
+ALL = {"glass_tir": glass_and_tir, "inside_box": camera_inside_box_and_axis_rays, "degenerate_rings": quadric_degenerate_and_rings,
+       "planes_glass": planes_lights_and_glass_spheres}
