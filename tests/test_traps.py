@@ -12,6 +12,7 @@ EXPECT = {  # counters that must be non-zero in each scene
     "glass_tir": ("tir_breaks", "refract_segments", "box_inside_hits", "side_miss", "segment_cap_hits"),
     "inside_box": ("box_inside_hits", "box_nan_hits"),
     "degenerate_rings": ("t4_taken", "alpha_pass", "light_hits"),
+    "planes_glass": ("refract_segments", "side_miss", "light_hits"),
 }
 
 
