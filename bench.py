@@ -151,7 +151,7 @@ def main():
         px_bytes_launch = gather.rows_local * W * px_bytes  # algorithmic HBM bytes of one launch on this rank
         achieved = px_bytes_launch / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mray/s at 3840x2160 depth-4 default scene (reference-defined rays: closest-hit + shadow scans)",
+            "metric": f"Mray/s at {W}x{H} depth-{args.depth} {args.scene} scene (reference-defined rays: closest-hit + shadow scans)",
             "value": round(mrays, 2),
             "unit": "Mray/s",
             "n_gpus": world,
@@ -203,8 +203,22 @@ def main():
                 cpu_s += time.perf_counter() - c0
                 reps += 1
             cpu_s /= reps
+            # one thread, on a thin slice of rows spread over the frame (SURVEY section 8(d) asks for both figures)
+            rows = sorted({min(H - 1, (H * (2 * j + 1)) // 32) for j in range(16)})
+            c0 = time.perf_counter()
+            one_rays = 0
+            for y in rows:
+                _r, c1 = o.render(y, y + 1, threads=1)
+                one_rays += c1["rays_closest"] + c1["rays_shadow"]
+            one_s = time.perf_counter() - c0
+            try:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                cpu_model = "unknown"
             out["cpu_baseline"] = {"value": round((cnt["rays_closest"] + cnt["rays_shadow"]) / cpu_s / 1e6, 3), "unit": "Mray/s",
-                                   "cores": cores, "kind": "port",
+                                   "cores": cores, "kind": "port", "cpu": cpu_model,
+                                   "one_thread": {"value": round(one_rays / one_s / 1e6, 4), "unit": "Mray/s",
+                                                  "sample": f"{len(rows)} rows spread over the frame, {one_s:.2f} s"},
                                    "sample": f"{reps} full {W}x{H} depth-{args.depth} frames of the same workload (mean {cpu_s:.2f} s each), "
                                              f"oracle/rt_oracle.c, OpenMP over rows"}
             # the oracle frame is there anyway: report full-size parity next to the timing

@@ -232,9 +232,10 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     p.counters = ctx->d_counters;
     fill_tex_table(ctx, p.tex);
     if (ctx->opt_count) HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), stream));
-    if (ctx->ev_pending == EVENT_RING) {  // ring full: retire the oldest pair
-        st = drain_events(ctx);
-        if (st) return st;
+    if (ctx->ev_pending == EVENT_RING) {  // ring full: retire the oldest pair only (recorded EVENT_RING launches ago, long finished)
+        const int idx = (ctx->ev_head - ctx->ev_pending + EVENT_RING * 2) % EVENT_RING;
+        HIP_TRY(hipEventSynchronize(ctx->ev_stop[idx]));
+        ctx->ev_pending--;
     }
     const int e = ctx->ev_head;
     HIP_TRY(hipEventRecord(ctx->ev_start[e], stream));
