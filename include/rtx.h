@@ -70,9 +70,12 @@ typedef enum rtx_option {
     RTX_OPT_SCENE_LDS = 2,   /* 1: stage the scene tables into LDS per workgroup; 0: scalar (SMEM) loads */
     RTX_OPT_TEXTURE_LOD = 3, /* 1 (default): mip chain + trilinear + quad-derivative LOD, the reference's texture
                                 state (GLWrapper.cpp:337-343, rt.frag:326-338); 0: level-0 bilinear everywhere */
-    RTX_OPT_XCD_REMAP = 4    /* 1: workgroups are dealt to the 8 XCDs in 128x32-pixel super-tiles (texture lines stay in
+    RTX_OPT_XCD_REMAP = 4,   /* 1: workgroups are dealt to the 8 XCDs in 128x32-pixel super-tiles (texture lines stay in
                                 one XCD's L2); 0 (default): plain row-major order. Measured on the 4K default scene:
                                 FETCH_SIZE 96.3 vs 97.5 MB, kernel 0.939 vs 0.902 ms -- no reuse to win, so it is off. */
+    RTX_OPT_HIGH_OCCUPANCY = 5 /* which register budget of the trace kernel runs: 0 = 4 waves/SIMD (no register spills),
+                                1 = 8 waves/SIMD (spills to scratch, hides the scalar table walks of scenes with many
+                                primitives), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
 } rtx_option;
 
 typedef struct rtx_stats {

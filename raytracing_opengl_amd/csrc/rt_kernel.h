@@ -19,5 +19,5 @@ struct RtLaunchParams {
     rtdev::TexTable tex;
 };
 
-hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, hipStream_t stream);
+hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream);
 hipError_t rt_launch_selftest(int* d_result, hipStream_t stream);

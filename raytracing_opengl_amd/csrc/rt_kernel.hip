@@ -54,13 +54,19 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_LAUNCH_BOUNDS __launch_bounds__(256)
-#else
-#define RT_LAUNCH_BOUNDS __launch_bounds__(256, RT_WAVES_PER_EU)
+#define RT_WAVES_PER_EU 4
 #endif
+// Two register budgets of the same code (WPE = waves per SIMD the compiler must make room for):
+//   WPE = RT_WAVES_PER_EU (4: 123 VGPRs, no scratch) -- the default. It keeps the HBM traffic at the frame plus the
+//         texture lines; 5 waves (96 VGPRs, 108 B scratch per lane) is 3 % faster on the default scene but writes 1.1 GB
+//         of spill traffic per 4K frame (WRITE_SIZE 1 136 603 KB vs 129 819 KB), so it is not the default.
+//   WPE = 8 (64 VGPRs, 248 B scratch) -- scenes with many primitives, where every ray walks long tables of scalar loads
+//         and latency hiding is worth more than the spills: quadric-heavy 4K 3.41 -> 2.71 ms, torus-heavy 3.09 -> 2.78 ms
+//         (but default scene 0.60 -> 0.83 ms). Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
+#define RT_WPE_HEAVY 8
 
-template <bool CULL, bool COUNT, bool LDS>
-__global__ RT_LAUNCH_BOUNDS void rt_trace_kernel(const RtLaunchParams p)
+template <bool CULL, bool COUNT, bool LDS, int WPE>
+__global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -174,19 +180,19 @@ __global__ void rt_selftest_kernel(int* result)
 
 }  // namespace
 
-template <bool CULL, bool COUNT, bool LDS>
+template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU>
 static hipError_t launch_variant(const RtLaunchParams& p, dim3 grid, size_t shmem, hipStream_t stream)
 {
     if (LDS && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS, WPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS>), grid, dim3(256), shmem, stream, p);
+    hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE>), grid, dim3(256), shmem, stream, p);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bool lds, hipStream_t stream)
+hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream)
 {
     RtLaunchParams p = p_in;
     dim3 grid((p.fb_w + 31) / 32, (p.rows_local + 7) / 8);
@@ -201,6 +207,7 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
     }
     const size_t shmem = lds ? (size_t)((p.scene_bytes + 15) & ~15) : 0;
     const int sel = (cull ? 4 : 0) | (count ? 2 : 0) | (lds ? 1 : 0);
+    if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY>(p, grid, shmem, stream);  // the product path only
     switch (sel) {
         case 0: return launch_variant<false, false, false>(p, grid, shmem, stream);
         case 1: return launch_variant<false, false, true>(p, grid, shmem, stream);

@@ -90,6 +90,7 @@ struct rtx_context {
     uint32_t* d_fb_u8 = nullptr;
     // options
     int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 1, opt_xcd = 0;
+    int opt_occ = -1;   // RTX_OPT_HIGH_OCCUPANCY: -1 auto (by primitive count), 0 off, 1 on
     unsigned long long* d_counters = nullptr;
     // timing
     hipEvent_t ev_start[EVENT_RING], ev_stop[EVENT_RING];
@@ -239,7 +240,11 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     }
     const int e = ctx->ev_head;
     HIP_TRY(hipEventRecord(ctx->ev_start[e], stream));
-    HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, stream));
+    // long primitive tables (quadric-/torus-heavy scenes): the 8-waves-per-SIMD build of the kernel hides the table walks
+    const rtpack::Defines& df = ctx->defines;
+    const int n_prims = df.sphere_size + df.plane_size + df.surface_size + df.box_size + df.torus_size + df.ring_size;
+    const bool high_occ = ctx->opt_occ < 0 ? n_prims >= 32 : ctx->opt_occ != 0;
+    HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream));
     HIP_TRY(hipEventRecord(ctx->ev_stop[e], stream));
     ctx->ev_head = (ctx->ev_head + 1) % EVENT_RING;
     ctx->ev_pending++;
@@ -478,6 +483,7 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_SCENE_LDS: ctx->opt_lds = value != 0; break;
         case RTX_OPT_TEXTURE_LOD: ctx->opt_lod = value != 0; break;
         case RTX_OPT_XCD_REMAP: ctx->opt_xcd = value != 0; break;
+        case RTX_OPT_HIGH_OCCUPANCY: ctx->opt_occ = value < 0 ? -1 : (value != 0); break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;
@@ -491,6 +497,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_SCENE_LDS: *value = ctx->opt_lds; break;
         case RTX_OPT_TEXTURE_LOD: *value = ctx->opt_lod; break;
         case RTX_OPT_XCD_REMAP: *value = ctx->opt_xcd; break;
+        case RTX_OPT_HIGH_OCCUPANCY: *value = ctx->opt_occ; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;

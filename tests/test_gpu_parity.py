@@ -187,6 +187,23 @@ def test_row_bands_reassemble_the_frame(small_textures):
     gl.stop()
 
 
+def test_high_occupancy_variant_is_bit_identical(small_textures):
+    """RTX_OPT_HIGH_OCCUPANCY selects another register budget of the same kernel (8 waves/SIMD with spills instead of 4
+    without; auto-selected for scenes with >= 32 primitives): the frames must not differ in a single bit."""
+    w, h = 320, 184
+    for name in ("default", "quadric"):
+        sc = scenes.build_scene(name, w, h, 4)
+        gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+        frames = []
+        for mode in (0, 1, -1):
+            gl.set_option(wrapper.RTX_OPT_HIGH_OCCUPANCY, mode)
+            gl.draw()
+            frames.append(gl.read_pixels().copy())
+        gl.stop()
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), name
+        assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32)), name
+
+
 def test_rgba8_row_bands_reassemble_the_rgba8_frame(small_textures):
     """The multi-GPU bench gathers the RGBA8 target: banded RGBA8 draws == the full RGBA8 frame, byte for byte."""
     import torch

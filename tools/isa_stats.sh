@@ -7,7 +7,7 @@ OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
 python3 - "$OUT" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
-i=txt.find('rt_trace_kernelILb1ELb0ELb0EEEv14RtLaunchParams:')
+i=txt.find('rt_trace_kernelILb1ELb0ELb0ELi4EEEv14RtLaunchParams:')
 j=txt.find('.end_amdhsa_kernel',i)
 body=txt[i:j]
 ins=[l.strip() for l in body.split('\n') if l.startswith('\t') and not l.strip().startswith(('.',';'))]
