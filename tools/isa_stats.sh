@@ -7,7 +7,8 @@ OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
 python3 - "$OUT" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
-i=txt.find('rt_trace_kernelILb1ELb0ELb0ELi4EEEv14RtLaunchParams:')
+m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi(\d+)EEEv14RtLaunchParams:', txt) if x.group(1) != '8' or 'RT_WAVES_PER_EU=8' in ' '.join(sys.argv)]
+i=m[0].start()
 j=txt.find('.end_amdhsa_kernel',i)
 body=txt[i:j]
 ins=[l.strip() for l in body.split('\n') if l.startswith('\t') and not l.strip().startswith(('.',';'))]
