@@ -43,15 +43,20 @@ def choose_band_rows(height: int, world: int) -> int:
     return 8
 
 
-def unpermute(gathered: list[torch.Tensor], height: int, band_rows: int, world: int) -> torch.Tensor:
-    """gathered[r]: (max_local_rows, W, C) packed bands of rank r -> (height, W, C) frame."""
+def unpermute(gathered, height: int, band_rows: int, world: int) -> torch.Tensor:
+    """gathered[r]: (max_local_rows, W, C) packed bands of rank r -> (height, W, C) frame. `gathered` is a list of
+    tensors or one (world, max_local_rows, W, C) tensor (FrameGather receives into one, so no stacking copy)."""
     w, c = gathered[0].shape[1], gathered[0].shape[2]
     frame = torch.empty((height, w, c), dtype=gathered[0].dtype, device=gathered[0].device)
     nb = num_bands(height, band_rows)
     if height % band_rows == 0 and nb % world == 0:
         # regular case: one strided copy
         per = nb // world
-        src = torch.stack([g[: per * band_rows] for g in gathered], dim=0).view(world, per, band_rows, w, c)
+        if isinstance(gathered, torch.Tensor):
+            src = gathered[:, : per * band_rows].reshape(world, per, band_rows, w, c) if gathered.shape[1] == per * band_rows \
+                else gathered[:, : per * band_rows].view(world, per, band_rows, w, c)
+        else:
+            src = torch.stack([g[: per * band_rows] for g in gathered], dim=0).view(world, per, band_rows, w, c)
         frame.view(per, world, band_rows, w, c).copy_(src.permute(1, 0, 2, 3, 4))
         return frame
     for r in range(world):
@@ -82,9 +87,11 @@ class FrameGather:
         self.rows_max = max_local_rows(height, band_rows, self.world)
         self.rows_local = local_rows(height, band_rows, self.rank, self.world)
         self.recv = None
+        self.recv_all = None
         if self.world > 1 and self.rank == dst:
-            self.recv = [[torch.empty((self.rows_max, width, channels), dtype=dtype, device=device) for _ in range(self.world)]
-                         for _slot in range(2)]
+            # one (world, rows, W, C) tensor per slot; the gather list are its per-rank slices (contiguous views)
+            self.recv_all = [torch.empty((self.world, self.rows_max, width, channels), dtype=dtype, device=device) for _slot in range(2)]
+            self.recv = [[t[r] for r in range(self.world)] for t in self.recv_all]
 
     def new_local(self, dtype, device) -> torch.Tensor:
         return torch.empty((self.rows_max, self.width, self.channels), dtype=dtype, device=device)
@@ -102,4 +109,4 @@ class FrameGather:
         work.wait()
         if self.rank != self.dst:
             return None
-        return unpermute(self.recv[slot & 1], self.height, self.band_rows, self.world)
+        return unpermute(self.recv_all[slot & 1], self.height, self.band_rows, self.world)
