@@ -1,0 +1,60 @@
+"""Seeded random scenes for fuzz-style parity tests: every primitive class, random rotations (some identity), random
+materials (diffuse / reflective / refractive / alpha-textured rings), 0-2 lights of each kind, camera placed outside or
+inside the cluster. Built only from tests/scene_util.py records, i.e. the same std140 bytes the reference's host writes."""
+import math
+
+import numpy as np
+
+from scene_util import (box, light_direct, light_point, make_scene, material, plane, quat_euler, ring, sphere, surface, torus)
+
+
+def _mat(rng):
+    kind = rng.random()
+    color = tuple(rng.random(3) * 0.9 + 0.1)
+    spec = int(rng.integers(0, 200)) if rng.random() < 0.8 else 0
+    if kind < 0.5:
+        return material(color, spec, 0.0)
+    if kind < 0.85:
+        return material(color, spec, float(rng.random() * 0.6 + 0.05))
+    return material(color, spec, float(rng.random() * 0.3), float(rng.choice([0.7, 1.0, 1.125, 1.33, 1.5, 1.9])), tuple(rng.random(3) * 0.5), 1.0)
+
+
+def _quat(rng):
+    return (0.0, 0.0, 0.0, 1.0) if rng.random() < 0.35 else quat_euler(*(rng.random(3) * 2 * math.pi - math.pi))
+
+
+def _pos(rng, spread=4.0, z0=6.0):
+    return (float(rng.normal() * spread * 0.6), float(rng.normal() * spread * 0.35), float(z0 + rng.normal() * spread * 0.5))
+
+
+def random_scene(seed: int, w: int, h: int):
+    rng = np.random.default_rng(seed)
+    depth = int(rng.integers(1, 6))
+    spheres = [sphere(_pos(rng), float(rng.random() * 0.9 + 0.2), _mat(rng), hollow=bool(rng.random() < 0.3), quat=_quat(rng),
+                      texture=int(rng.choice([0, 0, 1, 2, 3]))) for _ in range(int(rng.integers(0, 5)))]
+    planes = [plane((0, 1, 0), (0, -2.0 - float(rng.random()), 0), _mat(rng))] if rng.random() < 0.5 else []
+    if rng.random() < 0.2:
+        planes.append(plane(tuple(rng.normal(size=3)), _pos(rng, 6.0, 10.0), _mat(rng)))
+    boxes = [box(_pos(rng), tuple(rng.random(3) * 1.2 + 0.2), _mat(rng), quat=_quat(rng), texture=int(rng.choice([0, 0, 5])))
+             for _ in range(int(rng.integers(0, 4)))]
+    toruses = [torus(_pos(rng), float(rng.random() * 0.8 + 0.5), float(rng.random() * 0.3 + 0.1), _mat(rng), quat=_quat(rng))
+               for _ in range(int(rng.integers(0, 3)))]
+    rings = [ring(_pos(rng), float(rng.random() * 0.5 + 0.2), float(rng.random() * 1.0 + 0.9), _mat(rng) if rng.random() < 0.5 else material((0, 0, 0), 0, 0),
+                  quat=_quat(rng), texture=int(rng.choice([0, 4]))) for _ in range(int(rng.integers(0, 3)))]
+    surfaces = []
+    for _ in range(int(rng.integers(0, 4))):
+        p = _pos(rng)
+        kind = int(rng.integers(0, 4))
+        clip = dict(vmin=(p[0] - 1.5, p[1] - 1.5, p[2] - 1.5), vmax=(p[0] + 1.5, p[1] + 1.5, p[2] + 1.5)) if rng.random() < 0.7 else {}
+        coef = [dict(a=1, b=1, c=1, f=-float(rng.random() + 0.3)),            # ellipsoid
+                dict(a=1, b=-1, c=1),                                         # cone
+                dict(a=float(rng.random() + 0.5), b=float(rng.random() + 0.5), f=-0.5),   # elliptic cylinder
+                dict(a=0.5, b=-0.5, d=-1)][kind]                              # saddle
+        surfaces.append(surface(p, _mat(rng), quat=_quat(rng), **coef, **clip))
+    lights_point = [light_point(_pos(rng, 3.0, 3.0), float(rng.random() * 0.3 + 0.05), intensity=float(rng.random() * 30 + 5)) for _ in range(int(rng.integers(0, 3)))]
+    lights_direct = [light_direct(tuple(rng.normal(size=3) + np.array([0, -1.5, 0]))) for _ in range(int(rng.integers(0, 3)))]
+    inside = rng.random() < 0.15 and boxes
+    cam = _pos(rng, 1.0, -3.0) if not inside else (0.0, 0.0, 6.0)
+    cam_quat = quat_euler(float(rng.normal() * 0.15), float(rng.normal() * 0.3), 0.0) if rng.random() < 0.6 else (0.0, 0.0, 0.0, 1.0)
+    return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, rings=rings,
+                      lights_point=lights_point, lights_direct=lights_direct, cam_pos=cam, cam_quat=cam_quat)

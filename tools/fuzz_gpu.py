@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""GPU box: many random scenes (tests/random_scenes.py) through the C ABI against the oracle -- max pixel difference and
+ray counts -- beyond the 40 seeds the test suite runs. usage: tools/fuzz_gpu.py first_seed count [width height]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import random_scenes  # noqa: E402
+from oracle import oracle  # noqa: E402
+from raytracing_opengl_amd import textures, wrapper  # noqa: E402
+
+
+def main():
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (160, 96)
+    ts = textures.default_texture_set(scale=16)
+    worst, bad = 0.0, 0
+    for seed in range(first, first + count):
+        sc = random_scenes.random_scene(seed, w, h)
+        ref, cnt = oracle.OracleScene(sc, w, h, ts["textures"], ts["cubemap"], texture_lod=1).render()
+        gl = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
+        gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+        gl.draw()
+        img = gl.read_pixels()
+        st = gl.stats()
+        gl.stop()
+        nan_bad = int((np.isnan(img) ^ np.isnan(ref)).sum())
+        d = np.where(np.isnan(img) & np.isnan(ref), 0.0, np.abs(img - ref))
+        mx = float(np.nanmax(d))
+        rays_ok = st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
+        worst = max(worst, mx)
+        if nan_bad or mx > 1e-4 or not rays_ok:
+            bad += 1
+            print(f"seed {seed}: max {mx:.3e} nan-mismatch {nan_bad} rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
+    print(f"{count} scenes from seed {first} at {w}x{h}: {bad} outside the bar, worst max-abs difference {worst:.3e}")
+
+
+if __name__ == "__main__":
+    main()
