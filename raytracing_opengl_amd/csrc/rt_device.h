@@ -1379,7 +1379,7 @@ RT_HD f3 ray_dir(const SceneView& S, float frag_x, float frag_y)
 {
     const float cw = (float)S.h->canvas_w, ch = (float)S.h->canvas_h;
     const f3 v = mk3((frag_x - cw / 2.0f) / ch, (frag_y - ch / 2.0f) / ch, 1.0f);
-    return normalize3(quat_rotate(S.h->cam_quat, v));
+    return normalize3(quat_rotate_id(S.h->cam_quat, S.h->cam_ident != 0, v));   // un-rotated camera: exact shortcut
 }
 
 // ------------------------------------------------------------------------------------------

@@ -196,6 +196,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     h.iterations = d.iterations;
     const unsigned char* sc = blocks[BLK_SCENE].data();
     h.cam_quat = rd4(sc, 0);
+    h.cam_ident = quat_is_identity(h.cam_quat) ? 1u : 0u;
     h.cam_pos = rd3(sc, 16, 0.0f);
     h.canvas_w = rdi(sc, 44);
     h.canvas_h = rdi(sc, 48);

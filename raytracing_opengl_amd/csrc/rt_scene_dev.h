@@ -109,7 +109,8 @@ struct alignas(16) DevSceneHeader {
     uint32_t off_surf_cull;    // DevSurfaceCull per quadric
     uint32_t off_torus_bound;  // f4 per torus: centre, inflated bounding radius^2
     uint32_t off_ring_bound;   // f4 per ring:  centre, inflated outer radius^2
-    uint32_t _pad[3];
+    uint32_t cam_ident;        // 1 if cam_quat is the identity (any zero signs): getRayDir's rotation is then v + 0.0f
+    uint32_t _pad[2];
 };
 
 // ---- textures --------------------------------------------------------------------------------
