@@ -45,26 +45,27 @@ def choose_band_rows(height: int, world: int) -> int:
 
 def unpermute(gathered, height: int, band_rows: int, world: int) -> torch.Tensor:
     """gathered[r]: (max_local_rows, W, C) packed bands of rank r -> (height, W, C) frame. `gathered` is a list of
-    tensors or one (world, max_local_rows, W, C) tensor (FrameGather receives into one, so no stacking copy)."""
+    tensors or one (world, max_local_rows, W, C) tensor (FrameGather receives into one, so no stacking copy).
+    All complete rounds of bands (band b of round j belongs to rank b: rows (j*world + b)*band_rows ...) move with ONE
+    strided copy; the at most world-1 bands of the last, incomplete round (the final one may be short) are copied one by
+    one. (A per-band loop for everything costs hundreds of tiny copies per frame -- 270 bands at 2160 rows -- which
+    would dominate the frame time on the root at N = 4 or 8.)"""
     w, c = gathered[0].shape[1], gathered[0].shape[2]
     frame = torch.empty((height, w, c), dtype=gathered[0].dtype, device=gathered[0].device)
     nb = num_bands(height, band_rows)
-    if height % band_rows == 0 and nb % world == 0:
-        # regular case: one strided copy
-        per = nb // world
+    full_bands = height // band_rows          # bands of full height
+    rounds = full_bands // world              # rounds in which every rank has a full band
+    if rounds > 0:
         if isinstance(gathered, torch.Tensor):
-            src = gathered[:, : per * band_rows].reshape(world, per, band_rows, w, c) if gathered.shape[1] == per * band_rows \
-                else gathered[:, : per * band_rows].view(world, per, band_rows, w, c)
+            src = gathered[:, : rounds * band_rows]
         else:
-            src = torch.stack([g[: per * band_rows] for g in gathered], dim=0).view(world, per, band_rows, w, c)
-        frame.view(per, world, band_rows, w, c).copy_(src.permute(1, 0, 2, 3, 4))
-        return frame
-    for r in range(world):
-        off = 0
-        for b in rank_bands(height, band_rows, r, world):
-            y0, y1 = band_span(height, band_rows, b)
-            frame[y0:y1] = gathered[r][off:off + (y1 - y0)]
-            off += y1 - y0
+            src = torch.stack([g[: rounds * band_rows] for g in gathered], dim=0)
+        src = src.unflatten(1, (rounds, band_rows))   # (world, rounds, band_rows, W, C), a view
+        frame[: rounds * world * band_rows].view(rounds, world, band_rows, w, c).copy_(src.permute(1, 0, 2, 3, 4))
+    for b in range(rounds * world, nb):       # last, incomplete round
+        r, j = b % world, b // world
+        y0, y1 = band_span(height, band_rows, b)
+        frame[y0:y1] = gathered[r][j * band_rows: j * band_rows + (y1 - y0)]
     return frame
 
 
