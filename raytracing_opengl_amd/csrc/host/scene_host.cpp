@@ -46,6 +46,18 @@ __attribute__((visibility("default"))) size_t rtxh_scene_build(const char* kind,
     return blob.size();
 }
 
+// The shim's built-in image decoder (PNG / PNM), for tests and Python callers: returns the byte count w*h*channels
+// (0 on failure) and copies min(needed, cap) bytes of interleaved 8-bit texels, row 0 = top row of the file.
+__attribute__((visibility("default"))) size_t rtxh_decode_image(const char* path, int* w, int* h, int* channels, void* out, size_t cap)
+{
+    unsigned char* px = rtx_shim::decode_builtin(path, w, h, channels);
+    if (!px) return 0;
+    const size_t need = static_cast<size_t>(*w) * static_cast<size_t>(*h) * static_cast<size_t>(*channels);
+    if (out && cap) std::memcpy(out, px, need < cap ? need : cap);
+    std::free(px);
+    return need;
+}
+
 __attribute__((visibility("default"))) const char* rtxh_block_name(int binding)
 {
     return (binding >= 0 && binding < 9) ? scene_blob::kBlockNames[binding] : nullptr;
