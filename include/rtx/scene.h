@@ -18,124 +18,88 @@
 
 #include "glm_compat.h"
 
-struct rt_defines {  // reference: src/scene.h:7-20 -- the tracer's specialisation key
-    int sphere_size;
-    int plane_size;
-    int surface_size;
-    int box_size;
-    int torus_size;
-    int ring_size;
-    int light_point_size;
-    int light_direct_size;
+// One line per 16-byte std140 slot: the layout reads off the page.
+
+struct rt_defines {  // reference: src/scene.h:7-20 -- the tracer's specialisation key (nine ints, two colours = 60 B)
+    int sphere_size, plane_size, surface_size, box_size, torus_size, ring_size, light_point_size, light_direct_size;
     int iterations;
-    glm::vec3 ambient_color;
-    glm::vec3 shadow_ambient;
+    glm::vec3 ambient_color, shadow_ambient;
 };
 
-typedef struct {  // 64 B, reference: src/scene.h:22-35
-    glm::vec3 color; float __p1;
-    glm::vec3 absorb;
-    float diffuse;
-    float reflect;
-    float refract;
-    int specular;
-    float kd;
-    float ks;
-    float __padding[3];
-} rt_material;
+struct rt_material {  // 64 B, reference: src/scene.h:22-35
+    glm::vec3 color;  float __p1;
+    glm::vec3 absorb; float diffuse;
+    float reflect, refract; int specular; float kd;
+    float ks, __padding[3];
+};
 
-typedef struct {  // 112 B, reference: src/scene.h:37-44
+struct rt_sphere {  // 112 B, reference: src/scene.h:37-44
     rt_material material;
-    glm::vec4 obj;  // centre xyz + radius
-    glm::quat quat_rotation = glm::quat(1, 0, 0, 0);
-    int textureNum;
-    bool hollow;
-    unsigned char __p0[3] = {0, 0, 0};
-    float __padding[2];
-} rt_sphere;
+    glm::vec4 obj;                                      // centre xyz + radius
+    glm::quat quat_rotation = glm::quat(1, 0, 0, 0);    // rotates the texture lookup only
+    int textureNum; bool hollow; unsigned char __p0[3] = {0, 0, 0}; float __padding[2];
+};
 
-typedef struct {  // 96 B, reference: src/scene.h:46-50
+struct rt_plane {  // 96 B, reference: src/scene.h:46-50
     rt_material material;
-    glm::vec3 pos; float __p1;
+    glm::vec3 pos;    float __p1;
     glm::vec3 normal; float __p2;
-} rt_plane;
+};
 
-typedef struct {  // 112 B, reference: src/scene.h:52-58
+struct rt_box {  // 112 B, reference: src/scene.h:52-58
     rt_material mat;
     glm::quat quat_rotation = glm::quat(1, 0, 0, 0);
-    glm::vec3 pos; float __p1;
-    glm::vec3 form;  // half extents
-    int textureNum;
-} rt_box;
+    glm::vec3 pos;  float __p1;
+    glm::vec3 form; int textureNum;                     // half extents
+};
 
-typedef struct {  // 112 B, reference: src/scene.h:60-65
+struct rt_torus {  // 112 B, reference: src/scene.h:60-65
     rt_material mat;
     glm::quat quat_rotation = glm::quat(1, 0, 0, 0);
-    glm::vec3 pos; float __p1;
-    glm::vec2 form;  // x = major radius, y = tube radius
-    float __p2[2];
-} rt_torus;
+    glm::vec3 pos;  float __p1;
+    glm::vec2 form; float __p2[2];                      // x = major radius, y = tube radius
+};
 
-typedef struct {  // 112 B, reference: src/scene.h:67-73
+struct rt_ring {  // 112 B, reference: src/scene.h:67-73
     rt_material mat;
     glm::quat quat_rotation = glm::quat(1, 0, 0, 0);
     glm::vec3 pos; int textureNum;
-    float r1, r2;  // SQUARED inner / outer radius
-    float __p2[2];
-} rt_ring;
+    float r1, r2, __p2[2];                              // r1, r2: SQUARED inner / outer radius
+};
 
-typedef struct {  // 160 B, reference: src/scene.h:75-95
+struct rt_surface {  // 160 B, reference: src/scene.h:75-95
     rt_material mat;
     glm::quat quat_rotation = glm::quat(1, 0, 0, 0);
-    float xMin = -FLT_MAX;  // clip box, WORLD space
-    float yMin = -FLT_MAX;
-    float zMin = -FLT_MAX;
-    float __p0;
-    float xMax = FLT_MAX;
-    float yMax = FLT_MAX;
-    float zMax = FLT_MAX;
-    float __p1;
-    glm::vec3 pos;
-    float a;  // x^2
-    float b;  // y^2
-    float c;  // z^2
-    float d;  // z
-    float e;  // y
-    float f;  // const
-    float __padding[3];
-} rt_surface;
+    float xMin = -FLT_MAX, yMin = -FLT_MAX, zMin = -FLT_MAX, __p0;   // clip box, WORLD space
+    float xMax = FLT_MAX, yMax = FLT_MAX, zMax = FLT_MAX, __p1;
+    glm::vec3 pos; float a;                             // a x^2 + b y^2 + c z^2 + d z + e y + f = 0 in the local frame
+    float b, c, d, e;
+    float f, __padding[3];
+};
 
-typedef enum { sphere, light } primitiveType;
+enum primitiveType { sphere, light };
 
 struct rt_light_direct {  // 32 B, reference: src/scene.h:99-104
     glm::vec3 direction; float __p1;
-    glm::vec3 color;
-    float intensity;
+    glm::vec3 color;     float intensity;
 };
 
 struct rt_light_point {  // 48 B, reference: src/scene.h:106-114
-    glm::vec4 pos;  // xyz + radius of the visible light sphere
-    glm::vec3 color;
-    float intensity;
-    float linear_k;
-    float quadratic_k;
-    float __padding[2];
+    glm::vec4 pos;                                      // xyz + radius of the visible light sphere
+    glm::vec3 color; float intensity;
+    float linear_k, quadratic_k, __padding[2];
 };
 
-typedef struct {  // 64 B, reference: src/scene.h:116-126
+struct rt_scene {  // 64 B, reference: src/scene.h:116-126
     glm::quat quat_camera_rotation;
     glm::vec3 camera_pos; float __p1;
-    glm::vec3 bg_color;
-    int canvas_width;
-    int canvas_height;
-    int reflect_depth;
-    float __padding[2];
-} rt_scene;
+    glm::vec3 bg_color;   int canvas_width;
+    int canvas_height, reflect_depth; float __padding[2];
+};
 
 struct scene_container {  // reference: src/scene.h:128-154
     rt_scene scene;
-    glm::vec3 ambient_color;
-    glm::vec3 shadow_ambient;
+    glm::vec3 ambient_color, shadow_ambient;
     std::vector<rt_sphere> spheres;
     std::vector<rt_plane> planes;
     std::vector<rt_surface> surfaces;
@@ -145,20 +109,11 @@ struct scene_container {  // reference: src/scene.h:128-154
     std::vector<rt_light_point> lights_point;
     std::vector<rt_light_direct> lights_direct;
 
-    rt_defines get_defines()
+    rt_defines get_defines()   // array sizes + bounce depth + the two colours: what the tracer is specialised on
     {
-        rt_defines d;
-        d.sphere_size = static_cast<int>(spheres.size());
-        d.plane_size = static_cast<int>(planes.size());
-        d.surface_size = static_cast<int>(surfaces.size());
-        d.box_size = static_cast<int>(boxes.size());
-        d.torus_size = static_cast<int>(toruses.size());
-        d.ring_size = static_cast<int>(rings.size());
-        d.light_point_size = static_cast<int>(lights_point.size());
-        d.light_direct_size = static_cast<int>(lights_direct.size());
-        d.iterations = scene.reflect_depth;
-        d.ambient_color = ambient_color;
-        d.shadow_ambient = shadow_ambient;
+        auto n = [](size_t k) { return static_cast<int>(k); };
+        rt_defines d = {n(spheres.size()), n(planes.size()), n(surfaces.size()), n(boxes.size()), n(toruses.size()), n(rings.size()),
+                        n(lights_point.size()), n(lights_direct.size()), scene.reflect_depth, ambient_color, shadow_ambient};
         return d;
     }
 };
