@@ -728,18 +728,22 @@ RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, 
 // (|oc| >> r): its rounding error is bounded by ~1e-6 * a * |oc|^2 (three-term dot products,
 // 2^-24 per operation), so "misses" is only concluded when h is below minus ten times that.
 // NaNs compare false -> "not culled".
+// The culls are conservative predicates, not reference arithmetic: their dot products use explicit fused multiply-adds
+// (half the instructions, smaller rounding error than the margins were derived for) and everything that depends on the
+// ray direction only (dot(rd,rd), the six products of the quadric form) is loop-invariant and hoisted by the compiler.
+RT_HD float dot3_fma(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
 {
     const f3 oc = ro - c;
-    const float d2 = dot3(oc, oc);
+    const float d2 = dot3_fma(oc, oc);
     const float cc = d2 - r2;                 // > 0: origin outside
     if (!(cc > 0.0f)) return false;
-    const float a = dot3(rd, rd);
+    const float a = dot3_fma(rd, rd);
     if (!(a > 0.25f && a < 4.0f)) return false;  // degenerate direction (refract() yields the zero vector on a total
                                                  // reflection it disagrees about with the Fresnel test): never cull
-    const float b = dot3(oc, rd);
+    const float b = dot3_fma(oc, rd);
     if (b >= 0.0f) return true;               // sphere behind the origin
-    const float h = b * b - a * cc;
+    const float h = fmaf(b, b, -(a * cc));
     const float err = 1e-5f * a * d2;
     if (h < -err) return true;                // line misses the sphere, beyond rounding doubt
     const float t_in = (-b - sqrtf(gl_max(h + err, 0.0f))) / a;   // earliest possible entry (a ~ 1)
@@ -862,16 +866,18 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
 RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
 {
     if (!(Q.bound.w >= 0.0f)) return false;
-    const float p2 = Q.sym0.x * rd.x * rd.x + Q.sym0.w * rd.y * rd.y + Q.sym1.y * rd.z * rd.z +
-                     2.0f * (Q.sym0.y * rd.x * rd.y + Q.sym0.z * rd.x * rd.z + Q.sym1.x * rd.y * rd.z);
+    // p2 ~ d^T M d from the six direction products (ray-invariant) and the symmetric M of this quadric
+    const float dxx = rd.x * rd.x, dyy = rd.y * rd.y, dzz = rd.z * rd.z;
+    const float dxy = 2.0f * (rd.x * rd.y), dxz = 2.0f * (rd.x * rd.z), dyz = 2.0f * (rd.y * rd.z);
+    const float p2 = fmaf(Q.sym1.x, dyz, fmaf(Q.sym0.z, dxz, fmaf(Q.sym0.y, dxy, fmaf(Q.sym1.y, dzz, fmaf(Q.sym0.w, dyy, Q.sym0.x * dxx)))));
     if (!(fabsf(p2) > Q.sym1.z)) return false;  // too close to the degenerate branch: run the full test
-    const f3 oc = ro - xyz(Q.bound);
-    const float b = dot3(oc, rd);
-    const float a = dot3(rd, rd);
+    const float a = dot3_fma(rd, rd);
     if (!(a > 0.25f && a < 4.0f)) return false;  // degenerate direction: never cull
-    const float d2 = dot3(oc, oc);
+    const f3 oc = ro - xyz(Q.bound);
+    const float b = dot3_fma(oc, rd);
+    const float d2 = dot3_fma(oc, oc);
     const float cc = d2 - Q.bound.w;
-    return (b * b - a * cc) < -1e-5f * a * d2;  // rounding-safe (see sphere_cull); NaN -> false -> not culled
+    return fmaf(b, b, -(a * cc)) < -1e-5f * a * d2;  // rounding-safe (see sphere_cull); NaN -> false -> not culled
 }
 
 // ------------------------------------------------------------------------------------------
