@@ -1373,6 +1373,21 @@ void orc_kat_sample_cube(const orc_cubemap* c, const float d[3], float out[4])
 }
 float orc_kat_text_round_trip(float v) { return text_round_trip(v); }
 float orc_kat_log2(float v) { return orc_log2(v); }
+/* one pixel with level-0 textures: its colour and its own event counters (debugging aid for count mismatches) */
+int orc_kat_pixel(const orc_frame* fr, int x, int y, float out[4], orc_counters* counters)
+{
+    orc_counters local;
+    memset(&local, 0, sizeof local);
+    inv_t iv;
+    inv_init(&iv, fr, &local);
+    iv.frag_x = (float)x + 0.5f;
+    iv.frag_y = (float)y + 0.5f;
+    iv.step = 0;
+    const vec4 c = shade_pixel(&iv);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+    if (counters) *counters = local;
+    return 0;
+}
 void orc_kat_sample2d_lod(const orc_texture* t, float u, float v, float lambda, float out[4])
 {
     (void)mip_lookup(t, 1);

@@ -786,7 +786,11 @@ RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
     const float q = o.x * o.x + o.y * o.y;
     const float c = q - T.k.z;
     const float err = 1e-5f * (a * q + b * b);
-    if (a > 0.0f) {
+    // a = sin^2 of the angle between ray and torus axis. Below 1e-12 (the ray drifts < 1e-4 radially over the whole
+    // 100-unit range, well inside the puck's inflation) the quadratic is treated as the parallel case: with a in the
+    // denormal range -- a mirror ray with direction (4e-23, 2e-24, -1) did this -- b*b - a*c and the two roots are
+    // rounding noise, and the interval came out empty for a ray that goes straight down through the tube.
+    if (a > 1e-12f) {
         const float h = b * b - a * c;
         if (h < -err) return true;
         const float sh = sqrtf(gl_max(h + err, 0.0f));

@@ -27,6 +27,13 @@ struct harness_frame {
 };
 
 // renders rows [y0,y1) into out (RGBA float, row 0 = bottom); counters[4] = closest, shadow_ref, shadow_cast, torus_solves
+// per-pixel counters of the last harness_render call (4 x uint64 per pixel, row-major over the rendered rows), kept only
+// when harness_keep_pixel_counters(1) was called: a debugging aid for locating count mismatches
+static std::vector<uint64_t> g_pixel_counters;
+static int g_keep_pixel_counters = 0;
+void harness_keep_pixel_counters(int on) { g_keep_pixel_counters = on; }
+const uint64_t* harness_pixel_counters() { return g_pixel_counters.data(); }
+
 int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t* counters)
 {
     std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
@@ -67,6 +74,7 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
         T.sky.face_mask = mask;
     }
     uint64_t tot[4] = {0, 0, 0, 0};
+    if (g_keep_pixel_counters) g_pixel_counters.assign(static_cast<size_t>(y1 - y0) * fr->fb_width * 4, 0);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : tot[:4])
     for (int y = y0; y < y1; y++) {
         for (int x = 0; x < fr->fb_width; x++) {
@@ -77,6 +85,10 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
             float* o = out + (static_cast<size_t>(y - y0) * fr->fb_width + x) * 4;
             o[0] = px.x; o[1] = px.y; o[2] = px.z; o[3] = px.w;
             tot[0] += c.closest; tot[1] += c.shadow_ref; tot[2] += c.shadow_cast; tot[3] += c.torus_solves;
+            if (g_keep_pixel_counters) {
+                uint64_t* pc = g_pixel_counters.data() + (static_cast<size_t>(y - y0) * fr->fb_width + x) * 4;
+                pc[0] = c.closest; pc[1] = c.shadow_ref; pc[2] = c.shadow_cast; pc[3] = c.torus_solves;
+            }
         }
     }
     if (counters) std::memcpy(counters, tot, sizeof tot);

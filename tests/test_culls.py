@@ -41,9 +41,27 @@ def _rays(rng, centre, extent, n):
         yield ro.astype(np.float32), rd.astype(np.float32), tmin
 
 
+def _axis_rays(rng, centre, extent, n):
+    """Rays (almost) parallel to a coordinate axis that pass through or near the primitive: two direction components are
+    exact zeros, denormals or tiny normals (1e-45 ... 1e-12). A mirror ray with direction (4e-23, 2e-24, -1) straight
+    down a torus tube was once culled because sin^2 of its angle to the axis was a denormal."""
+    tiny = [0.0, 1e-45, 3e-42, 1e-38, 4e-23, 2e-24, 1e-18, 1e-12, 1e-7]
+    for _ in range(n):
+        axis = int(rng.integers(3))
+        sign = 1.0 if rng.random() < 0.5 else -1.0
+        rd = np.array([rng.choice(tiny) * rng.choice([-1, 1]) for _ in range(3)], dtype=np.float64)
+        rd[axis] = sign
+        off = rng.normal(size=3) * extent * 0.7
+        off[axis] = -sign * extent * float(10 ** rng.uniform(-0.5, 1.5))
+        ro = np.asarray(centre, dtype=np.float64) + off
+        tmin = 1e6 if rng.random() < 0.5 else float(10 ** rng.uniform(-1, 3))
+        yield ro.astype(np.float32), rd.astype(np.float32), tmin
+
+
 def _check(type_, record, rng, centre, extent, n):
     culled = hits = 0
-    for ro, rd, tmin in _rays(rng, centre, extent, n):
+    import itertools
+    for ro, rd, tmin in itertools.chain(_rays(rng, centre, extent, n), _axis_rays(rng, centre, extent, max(50, n // 4))):
         ohit, ot, _ = _isect(type_, record, ro, rd, tmin)
         dhit, dt, dcull = harness.kat(type_, record, ro, rd, tmin)
         assert dhit == ohit, (ro, rd, tmin)
