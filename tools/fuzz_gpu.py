@@ -16,10 +16,12 @@ from raytracing_opengl_amd import textures, wrapper  # noqa: E402
 
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
-    w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (160, 96)
+    fixed = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else None
+    sizes = [(160, 96), (161, 97), (323, 181), (97, 161), (200, 120)]   # odd sizes: helper invocations, axis-parallel centre rays
     ts = textures.default_texture_set(scale=16)
     worst, bad = 0.0, 0
     for seed in range(first, first + count):
+        w, h = fixed or sizes[seed % len(sizes)]
         sc = random_scenes.random_scene(seed, w, h)
         ref, cnt = oracle.OracleScene(sc, w, h, ts["textures"], ts["cubemap"], texture_lod=1).render()
         gl = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
@@ -36,7 +38,7 @@ def main():
         if nan_bad or mx > 1e-4 or not rays_ok:
             bad += 1
             print(f"seed {seed}: max {mx:.3e} nan-mismatch {nan_bad} rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
-    print(f"{count} scenes from seed {first} at {w}x{h}: {bad} outside the bar, worst max-abs difference {worst:.3e}")
+    print(f"{count} scenes from seed {first} ({'%dx%d' % fixed if fixed else 'mixed sizes'}): {bad} outside the bar, worst max-abs difference {worst:.3e}")
 
 
 if __name__ == "__main__":
