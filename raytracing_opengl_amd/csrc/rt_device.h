@@ -1458,6 +1458,11 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
                     act = ACT_SIDE;
                     sh_pt = dot3(rd, n) < 0.0f ? pt + n * h.bias : pt - n * h.bias;  // n stays unflipped (trap T18)
                     w_s = side_R;
+                } else {
+                    // miss: the shader still executes color += vec3(0) * reflectMultiplier * mask (rt.frag:855). That is
+                    // +0 for a finite mask, but NaN once the mask has overflowed (exp(-absorb * negative distance) inside
+                    // a box, traps T12 + T21) -- and then the pixel must come out NaN like the reference's, not inf.
+                    color = color + (mk3(0.0f, 0.0f, 0.0f) * side_R) * mask;
                 }
                 k_mask = 1.0f - side_R;
                 if (side_R >= 1.0f) finished = true;  // total reflection: checked after the mirror term (rt.frag:865)

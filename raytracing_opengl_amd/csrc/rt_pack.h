@@ -7,6 +7,7 @@
 // kernel would otherwise repeat per ray.
 #pragma once
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -322,6 +323,17 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.k = mk4(4.0f * R2, static_cast<float>(rb * rb), static_cast<float>(rb * rb), hole > 0.0 ? static_cast<float>(hole * hole) : 0.0f);
         s.qinv = quat_inv(s.quat);
         s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), 0.0f, 0.0f, 0.0f);
+        // The culls rest on "a geometric miss makes Durand-Kerner report no root". That holds for tori with a real tube
+        // (validated on random rays), but not for degenerate ones: with tube radius 0 the solver, out of sweeps, can stop
+        // on an iterate whose imaginary part happens to be below 1e-3 far away from the (zero-thickness) torus -- found by
+        // the nasty-scene fuzz. Such tori (tube thinner than 2 % of the major radius, or any non-positive / non-finite
+        // radius) get infinite bounds: never culled, the solver decides like in the reference.
+        const bool real_tube = std::isfinite(R) && std::isfinite(r) && R > 0.0f && r > 0.02f * R;
+        if (!real_tube) {
+            const float inf = std::numeric_limits<float>::infinity();
+            s.k.y = inf; s.k.z = inf; s.k.w = 0.0f;
+            s.cull.x = inf;
+        }
         std::memcpy(reinterpret_cast<DevTorus*>(blob.data() + h.off_torus) + i, &s, sizeof s);
         const f4 tb = mk4(s.pos.x, s.pos.y, s.pos.z, s.k.y);
         std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_torus_bound) + i, &tb, sizeof tb);

@@ -58,3 +58,46 @@ def random_scene(seed: int, w: int, h: int):
     cam_quat = quat_euler(float(rng.normal() * 0.15), float(rng.normal() * 0.3), 0.0) if rng.random() < 0.6 else (0.0, 0.0, 0.0, 1.0)
     return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, rings=rings,
                       lights_point=lights_point, lights_direct=lights_direct, cam_pos=cam, cam_quat=cam_quat)
+
+
+def nasty_scene(seed: int, w: int, h: int):
+    """Degenerate and extreme configurations on purpose: coincident and nested primitives (exact ties), zero and huge radii,
+    far 'planets', self-intersecting tori (r > R), rings with swapped radii, flat boxes, quadrics with vanishing
+    coefficients, refraction index exactly 1, lights inside objects, axis-aligned cameras on integer coordinates."""
+    rng = np.random.default_rng(seed ^ 0x5eed)
+    depth = int(rng.integers(1, 9))
+    grid = lambda: tuple(float(v) for v in rng.integers(-3, 4, 3) + np.array([0, 0, 6]))   # integer lattice positions: exact ties
+    def mat():
+        k = rng.random()
+        color = tuple(rng.choice([0.0, 0.5, 1.0], 3))
+        spec = int(rng.choice([0, 1, 50, 1000]))
+        if k < 0.4: return material(color, spec, 0.0)
+        if k < 0.7: return material(color, spec, float(rng.choice([0.05, 0.5, 1.0])))
+        return material(color, spec, float(rng.choice([0.0, 0.2, 1.0])), float(rng.choice([1.0, 1.0001, 0.5, 1.5, 3.0])), tuple(rng.choice([0.0, 0.3, 5.0], 3)), 1.0)
+    q_choices = [(0.0, 0.0, 0.0, 1.0), quat_euler(math.pi / 2, 0, 0), quat_euler(0, math.pi / 2, 0), quat_euler(0, 0, math.pi), quat_euler(0.3, 0.2, 0.1)]
+    quat = lambda: q_choices[int(rng.integers(len(q_choices)))]
+    spheres = [sphere(grid(), float(rng.choice([0.0, 1e-3, 0.5, 1.0, 2.5])), mat(), hollow=bool(rng.random() < 0.4), quat=quat(), texture=int(rng.choice([0, 1, 7])))
+               for _ in range(int(rng.integers(0, 5)))]
+    if rng.random() < 0.3:
+        spheres.append(sphere((float(rng.normal() * 2e4), float(rng.normal() * 5e3), 3.0e4), float(rng.choice([500.0, 5000.0])), mat(), texture=int(rng.choice([0, 2]))))
+    if spheres and rng.random() < 0.4:
+        spheres.append(spheres[0])                       # exact duplicate: equal t, first wins
+    planes = []
+    if rng.random() < 0.6: planes.append(plane((0, 1, 0), (0, float(rng.choice([-1.0, -2.0, 0.0])), 0), mat()))
+    if rng.random() < 0.2: planes.append(plane((0, 0, -1), (0, 0, 9.0), mat()))
+    boxes = [box(grid(), tuple(float(v) for v in rng.choice([0.0, 0.5, 1.0, 4.0], 3)), mat(), quat=quat(), texture=int(rng.choice([0, 5]))) for _ in range(int(rng.integers(0, 4)))]
+    toruses = [torus(grid(), float(rng.choice([0.3, 1.0, 1.0, 2.0])), float(rng.choice([0.0, 0.25, 1.0, 1.5])), mat(), quat=quat()) for _ in range(int(rng.integers(0, 3)))]
+    rings = [ring(grid(), float(rng.choice([0.0, 0.5, 1.5])), float(rng.choice([0.4, 1.0, 2.0])), mat(), quat=quat(), texture=int(rng.choice([0, 4]))) for _ in range(int(rng.integers(0, 3)))]
+    surfaces = []
+    for _ in range(int(rng.integers(0, 4))):
+        p = grid()
+        coef = dict(a=float(rng.choice([0.0, 1.0, -1.0, 0.02])), b=float(rng.choice([0.0, 1.0, -1.0])), c=float(rng.choice([0.0, 1.0, -1.0])),
+                    d=float(rng.choice([0.0, -1.0])), e=float(rng.choice([0.0, 0.5])), f=float(rng.choice([0.0, -1.0, 1.0])))
+        clip = dict(vmin=(p[0] - 2, p[1] - 2, p[2] - 2), vmax=(p[0] + 2, p[1] + 2, p[2] + 2)) if rng.random() < 0.6 else {}
+        surfaces.append(surface(p, mat(), quat=quat(), **coef, **clip))
+    lights_point = [light_point(grid(), float(rng.choice([0.0, 0.1, 1.0])), intensity=float(rng.choice([0.0, 10.0, 40.0]))) for _ in range(int(rng.integers(0, 3)))]
+    lights_direct = [light_direct(tuple(float(v) for v in rng.choice([0.0, 1.0, -1.0], 3) + np.array([0, -1e-3, 0]))) for _ in range(int(rng.integers(0, 3)))]
+    cam = tuple(float(v) for v in rng.integers(-2, 3, 3) + np.array([0, 0, -3])) if rng.random() < 0.7 else grid()
+    cam_quat = (0.0, 0.0, 0.0, 1.0) if rng.random() < 0.6 else quat_euler(0.0, float(rng.choice([0.0, math.pi / 2, math.pi, 0.3])), 0.0)
+    return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, rings=rings,
+                      lights_point=lights_point, lights_direct=lights_direct, cam_pos=cam, cam_quat=cam_quat)

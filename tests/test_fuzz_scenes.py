@@ -19,6 +19,39 @@ def test_random_scene_bit_exact_on_host(built, small_textures, seed):
         assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)
 
 
+# 1566, 1785: overflowed mask x black mirror miss must give NaN like the shader; 3690: zero-tube torus, spurious solver root
+@pytest.mark.parametrize("seed", list(range(16)) + [1566, 1785, 3690])
+def test_nasty_scene_bit_exact_on_host(built, small_textures, seed):
+    """Degenerate configurations on purpose (tests/random_scenes.py::nasty_scene)."""
+    W, H = [(97, 61), (96, 60), (65, 97), (121, 67)][seed % 4]
+    sc = random_scenes.nasty_scene(seed, W, H)
+    ref, cnt = oracle.OracleScene(sc, W, H, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
+    for cull in (True, False):
+        img, hc = harness.render(sc, W, H, small_textures["textures"], small_textures["cubemap"], cull=cull)
+        same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), (seed, cull, int((~same).sum()))
+        assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 7, 1566, 1785, 3690, 4001, 4002, 4003])
+def test_nasty_scene_on_gpu(built, small_textures, seed):
+    from raytracing_opengl_amd import wrapper
+    w, h = [(97, 61), (96, 60), (65, 97), (121, 67)][seed % 4]
+    sc = random_scenes.nasty_scene(seed, w, h)
+    ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=1).render()
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    gl.draw()
+    img = gl.read_pixels()
+    st = gl.stats()
+    gl.stop()
+    fin = np.isfinite(img) & np.isfinite(ref)
+    assert (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all(), seed
+    assert float(np.abs(np.where(fin, img - ref, 0.0)).max()) <= 1e-4, seed
+    assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"], seed
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(40))
 def test_random_scene_on_gpu(built, small_textures, seed):

@@ -22,7 +22,7 @@ def main():
     worst, bad = 0.0, 0
     for seed in range(first, first + count):
         w, h = fixed or sizes[seed % len(sizes)]
-        sc = random_scenes.random_scene(seed, w, h)
+        sc = random_scenes.nasty_scene(seed, w, h) if os.environ.get("FUZZ_NASTY") else random_scenes.random_scene(seed, w, h)
         ref, cnt = oracle.OracleScene(sc, w, h, ts["textures"], ts["cubemap"], texture_lod=1).render()
         gl = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
         gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
@@ -30,9 +30,9 @@ def main():
         img = gl.read_pixels()
         st = gl.stats()
         gl.stop()
-        nan_bad = int((np.isnan(img) ^ np.isnan(ref)).sum())
-        d = np.where(np.isnan(img) & np.isnan(ref), 0.0, np.abs(img - ref))
-        mx = float(np.nanmax(d))
+        nan_bad = int((np.isnan(img) ^ np.isnan(ref)).sum()) + int((np.isinf(img) ^ np.isinf(ref)).sum())
+        fin = np.isfinite(img) & np.isfinite(ref)
+        mx = float(np.abs(np.where(fin, img - ref, 0.0)).max())
         rays_ok = st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
         worst = max(worst, mx)
         if nan_bad or mx > 1e-4 or not rays_ok:
