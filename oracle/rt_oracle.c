@@ -215,8 +215,14 @@ static inline float dot2(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
 static inline float dot4(vec4 a, vec4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 static inline float length3(vec3 a) { return sqrtf(dot3(a, a)); }
 static inline vec3 normalize3(vec3 a) { return div3s(a, length3(a)); }
-static inline float gl_min(float a, float b) { return b < a ? b : a; }
-static inline float gl_max(float a, float b) { return a < b ? b : a; }
+/* min/max with a NaN operand are undefined in GLSL. Mode 0 (the contract shared with the kernel) follows the specification's
+ * wording: min "returns y if y < x, otherwise x". Mode 1 is DIAGNOSTIC: the SSE minps/maxps behaviour of Mesa llvmpipe
+ * (x < y ? x : y, i.e. the second operand when unordered), used only to show that the reference-on-llvmpipe frames of
+ * degenerate scenes differ from the oracle in nothing but this choice (tools/fuzz_reference.py, orc_set_nan_minmax). */
+static int g_nan_minmax = 0;
+void orc_set_nan_minmax(int mode) { g_nan_minmax = mode; }
+static inline float gl_min(float a, float b) { return g_nan_minmax ? (a < b ? a : b) : (b < a ? b : a); }
+static inline float gl_max(float a, float b) { return g_nan_minmax ? (a > b ? a : b) : (a < b ? b : a); }
 static inline float gl_clamp(float x, float lo, float hi) { return gl_min(gl_max(x, lo), hi); }
 static inline float gl_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 static inline float gl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
