@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(_HERE, "librtx_hip.so")
 RTX_OK = 0
 RTX_RGBA32F, RTX_RGBA8 = 0, 1
 RTX_WRAP_REPEAT, RTX_WRAP_CLAMP_TO_EDGE = 0, 1
-RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY = 0, 1, 2, 3, 4, 5
+RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/rtx.h declares (tests/test_capi_symbols.py checks the .so against this list)
 SYMBOLS = (

@@ -12,6 +12,7 @@ struct RtLaunchParams {
     // each, stored packed (rows_local rows in total) at out_*
     int32_t band_rows, band_first, band_stride, rows_local;
     int32_t xcd_remap;        // 1: XCD-aware super-tile order (see rt_kernel.hip)
+    int32_t hot_row0, hot_rows;  // workgroup rows [hot_row0, hot_row0 + hot_rows) of this launch are dispatched first (0 rows = off)
     int32_t grid_x, grid_y, st_nx, st_ny;  // filled by rt_launch_trace
     float* out_f32;           // RGBA32F, 16 B/pixel, or nullptr
     uint32_t* out_u8;         // RGBA8, 4 B/pixel, or nullptr

@@ -27,6 +27,17 @@ extern "C" __attribute__((visibility("default"))) int rtx_debug_dk_stats(unsigne
     return 0;
 }
 #endif
+#ifdef RT_WG_TIMES
+// diagnostic build: per-workgroup start time and duration (s_memtime ticks) of the last launch, to see which tiles are the
+// long pole of a launch (tools/wg_times.py)
+__device__ unsigned long long g_wg_start[1 << 16], g_wg_dur[1 << 16];
+extern "C" __attribute__((visibility("default"))) int rtx_debug_wg_times(unsigned long long* start, unsigned long long* dur, int n)
+{
+    if (hipMemcpyFromSymbol(start, HIP_SYMBOL(g_wg_start), sizeof(unsigned long long) * n) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(dur, HIP_SYMBOL(g_wg_dur), sizeof(unsigned long long) * n) != hipSuccess) return 1;
+    return 0;
+}
+#endif
 #ifdef RT_PHASE_TIMERS
 __device__ unsigned long long g_phase[PH_COUNT];
 extern "C" __attribute__((visibility("default"))) int rtx_debug_phase_counters(unsigned long long* out, int reset)
@@ -90,9 +101,24 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     } else {
         bx = blockIdx.x;
         by = blockIdx.y;
+        // "Longest first" for small launches: the workgroup rows that show a torus are dispatched before the others.
+        // Workgroups that run the quartic solver in several scans per pixel last ~20x the median (170 us against 9 us in the
+        // 4K default frame, tools/wg_times.py) and sit in the middle rows; when a launch is one GPU's quarter or eighth of
+        // the frame they ARE its tail (one rank's share of 8: 166-205 us in row order, 157-173 us hot rows first, ideal 74).
+        // Not for large launches: there any re-ordering costs more than the tail it saves (593 -> 609-643 us for the whole
+        // frame; neighbouring rows run the same code, mixed rows thrash the instruction cache). Which rows: rtx_capi.cpp.
+        if (p.hot_rows > 0) {
+            const int k = by;
+            by = k < p.hot_rows ? p.hot_row0 + k : (k - p.hot_rows < p.hot_row0 ? k - p.hot_rows : k);
+        }
     }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+#ifdef RT_WG_TIMES
+    const unsigned long long _wg_t0 = clock64();
+    const int _wg_id = (by * (int)gridDim.x + bx) & 0xffff;
+    if (threadIdx.x == 0) { g_wg_start[_wg_id] = _wg_t0; g_wg_dur[_wg_id] = 0ull; }
+#endif
     // 2x2 quads in consecutive lanes: bit0 = x&1, bit1 = y&1, bits 2-3 = quad column, bits 4-5 = quad row
     const int tx = ((lane >> 2) & 3) * 2 + (lane & 1);
     const int ty = ((lane >> 4) & 3) * 2 + ((lane >> 1) & 1);
@@ -158,6 +184,9 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
         atomicAdd(&g_phase[PH_COUNT - 2], (unsigned long long)clock64() - _k0);  // whole wave
         atomicAdd(&g_phase[PH_COUNT - 1], 1ull);                                // waves
     }
+#endif
+#ifdef RT_WG_TIMES
+    if ((threadIdx.x & 63) == 0) atomicMax(&g_wg_dur[_wg_id], (unsigned long long)clock64() - _wg_t0);
 #endif
     if (COUNT) {
         uint32_t v[4] = {cnt.closest, cnt.shadow_ref, cnt.shadow_cast, cnt.torus_solves};

@@ -91,6 +91,7 @@ struct rtx_context {
     // options
     int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 1, opt_xcd = 0;
     int opt_occ = -1;   // RTX_OPT_HIGH_OCCUPANCY: -1 auto (by primitive count), 0 off, 1 on
+    int opt_hot = 1;    // RTX_OPT_HOT_ROWS_FIRST
     unsigned long long* d_counters = nullptr;
     // timing
     hipEvent_t ev_start[EVENT_RING], ev_stop[EVENT_RING];
@@ -200,6 +201,44 @@ int drain_events(rtx_context* ctx)
     return RTX_OK;
 }
 
+// Which workgroup rows of this launch show a torus (the long-running tiles, see rt_kernel.hip): the framebuffer rows covered
+// by the tori's bounding spheres seen from the camera, mapped through the band layout. A scheduling hint only -- computed in
+// double precision from the packed scene, padded, and ignored when a torus reaches behind the camera.
+void hot_rows(rtx_context* ctx, RtLaunchParams& p)
+{
+    p.hot_row0 = p.hot_rows = 0;
+    const DevSceneHeader* h = reinterpret_cast<const DevSceneHeader*>(ctx->blob.data());
+    if (ctx->blob.size() < sizeof(DevSceneHeader) || h->n_torus <= 0) return;
+    const double qx = h->cam_quat.x, qy = h->cam_quat.y, qz = h->cam_quat.z, qw = h->cam_quat.w;
+    const double H = ctx->height;
+    double ylo = 1e30, yhi = -1e30;
+    const DevTorus* tori = reinterpret_cast<const DevTorus*>(ctx->blob.data() + h->off_torus);
+    for (int i = 0; i < h->n_torus; i++) {
+        // camera space: the shader rotates the view vector by q, so a world offset goes back with the conjugate
+        const double vx = tori[i].pos.x - h->cam_pos.x, vy = tori[i].pos.y - h->cam_pos.y, vz = tori[i].pos.z - h->cam_pos.z;
+        const double tx = qw * vx - (qy * vz - qz * vy), ty = qw * vy - (qz * vx - qx * vz), tz = qw * vz - (qx * vy - qy * vx), tw = qx * vx + qy * vy + qz * vz;
+        const double cy = tw * qy + ty * qw + (tz * qx - tx * qz), cz = tw * qz + tz * qw + (tx * qy - ty * qx);   // (conj(q) v) q
+        const double rb = std::fabs(static_cast<double>(tori[i].radii.x)) + std::fabs(static_cast<double>(tori[i].radii.y));
+        if (!(cz - rb > 1e-3) || !(rb < 1e30)) return;   // reaches the camera plane: no useful extent
+        const double a = (cy - rb) / (cz - rb), b = (cy - rb) / (cz + rb), c = (cy + rb) / (cz - rb), d = (cy + rb) / (cz + rb);
+        ylo = std::fmin(ylo, std::fmin(std::fmin(a, b), std::fmin(c, d)));
+        yhi = std::fmax(yhi, std::fmax(std::fmax(a, b), std::fmax(c, d)));
+    }
+    const double r0 = ylo * H + 0.5 * H - 4.0, r1 = yhi * H + 0.5 * H + 4.0;   // framebuffer rows, padded
+    if (!(r1 > 0.0) || !(r0 < H)) return;
+    const int fy0 = r0 < 0.0 ? 0 : static_cast<int>(r0), fy1 = r1 > H ? ctx->height : static_cast<int>(r1) + 1;
+    const int grid_y = (p.rows_local + 7) / 8;
+    int first = -1, last = -1;
+    for (int by = 0; by < grid_y; by++) {   // same mapping as the kernel: local workgroup row -> first framebuffer row
+        const int band_j = (by * 8) / p.band_rows;
+        const int y0 = (p.band_first + band_j * p.band_stride) * p.band_rows + (by * 8 - band_j * p.band_rows);
+        if (y0 + 8 > fy0 && y0 < fy1) { if (first < 0) first = by; last = by; }
+    }
+    if (first < 0 || (last - first + 1) * 2 > grid_y) return;   // nothing, or "hot" is most of the launch: order is moot
+    p.hot_row0 = first;
+    p.hot_rows = last - first + 1;
+}
+
 int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, float* out_f32, uint32_t* out_u8, hipStream_t stream)
 {
     if (!ctx->specialized) return fail(RTX_ERR_ORDER, "draw before init_shaders/rtx_specialize");
@@ -228,6 +267,7 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     p.band_stride = band_stride;
     p.rows_local = rows_local;
     p.xcd_remap = ctx->opt_xcd;
+    if (ctx->opt_hot && !ctx->opt_xcd && band_stride >= 4) hot_rows(ctx, p);   // small launches only, see rt_kernel.hip
     p.out_f32 = out_f32;
     p.out_u8 = out_u8;
     p.counters = ctx->d_counters;
@@ -484,6 +524,7 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_TEXTURE_LOD: ctx->opt_lod = value != 0; break;
         case RTX_OPT_XCD_REMAP: ctx->opt_xcd = value != 0; break;
         case RTX_OPT_HIGH_OCCUPANCY: ctx->opt_occ = value < 0 ? -1 : (value != 0); break;
+        case RTX_OPT_HOT_ROWS_FIRST: ctx->opt_hot = value != 0; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;
@@ -498,6 +539,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_TEXTURE_LOD: *value = ctx->opt_lod; break;
         case RTX_OPT_XCD_REMAP: *value = ctx->opt_xcd; break;
         case RTX_OPT_HIGH_OCCUPANCY: *value = ctx->opt_occ; break;
+        case RTX_OPT_HOT_ROWS_FIRST: *value = ctx->opt_hot; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;
