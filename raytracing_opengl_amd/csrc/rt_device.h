@@ -902,7 +902,9 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
 // primitives at once. The number of solver passes per scan drops from "distinct primitives any lane
 // of the wave needs" to "most candidates of a single lane". Per lane the tests still run in index
 // order with the live tmin, so the closest-hit semantics (strict <, first wins) are unchanged.
+#ifndef RT_LANE_DIVERGENT_MIN
 #define RT_LANE_DIVERGENT_MIN 3   /* classes with fewer primitives keep the wave-uniform path */
+#endif
 RT_HD int lane_pop(unsigned long long& m)
 {
     const int j = __builtin_ctzll(m);
