@@ -5,7 +5,10 @@
 // SceneManager::init(), then the frame loop (update_scene -> scene_manager.update -> bind
 // textures -> draw). What differs from the reference program is only what lies outside the
 // replaced path: no GLFW window/vsync/input (a fixed number of frames driven by a synthetic
-// clock), procedural textures instead of image files, and the last frame is written as a PPM.
+// clock), and the last frame is written as a PPM. Textures: procedural by default, so that the demo needs no files;
+// built with -DDEMO_ASSET_FILES -DASSETS_DIR=\"<reference checkout>/assets\" it loads the reference's own JPEG / PNG
+// files through load_cubemap / load_texture exactly as main.cpp:137-153 does (decoded by include/rtx/jpeg_decode.h and
+// png_decode.h to the same texels stb_image gives the reference).
 //
 // Build (see examples/Makefile):  g++ -std=c++17 -Iinclude examples/demo_main.cpp -L... -lrtx_hip
 #include <chrono>
@@ -24,7 +27,7 @@ static int wind_width = 1280;   // reference main.cpp:7-8
 static int wind_height = 720;
 
 // tiny procedural textures so the demo needs no asset files
-static std::vector<unsigned char> checker(int w, int h, int c, int cell, unsigned char lo, unsigned char hi)
+[[maybe_unused]] static std::vector<unsigned char> checker(int w, int h, int c, int cell, unsigned char lo, unsigned char hi)
 {
     std::vector<unsigned char> t(static_cast<size_t>(w) * h * c);
     for (int y = 0; y < h; y++)
@@ -51,6 +54,18 @@ int main(int argc, char** argv)
     rt_defines defines = scene.get_defines();
     glWrapper.init_shaders(defines);
 
+#ifdef DEMO_ASSET_FILES
+    std::vector<std::string> faces = {   // main.cpp:137-145
+        ASSETS_DIR "/textures/sb_nebula/GalaxyTex_PositiveX.jpg", ASSETS_DIR "/textures/sb_nebula/GalaxyTex_NegativeX.jpg",
+        ASSETS_DIR "/textures/sb_nebula/GalaxyTex_PositiveY.jpg", ASSETS_DIR "/textures/sb_nebula/GalaxyTex_NegativeY.jpg",
+        ASSETS_DIR "/textures/sb_nebula/GalaxyTex_PositiveZ.jpg", ASSETS_DIR "/textures/sb_nebula/GalaxyTex_NegativeZ.jpg"};
+    glWrapper.set_skybox(GLWrapper::load_cubemap(faces, false));
+    auto jupiterTex = glWrapper.load_texture(1, "8k_jupiter.jpg", "texture_sphere_1");
+    auto saturnTex = glWrapper.load_texture(2, "8k_saturn.jpg", "texture_sphere_2");
+    auto marsTex = glWrapper.load_texture(3, "2k_mars.jpg", "texture_sphere_3");
+    auto ringTex = glWrapper.load_texture(4, "8k_saturn_ring_alpha.png", "texture_ring");
+    auto boxTex = glWrapper.load_texture(5, "container.png", "texture_box");
+#else
     std::vector<std::vector<unsigned char>> faces;
     const unsigned char* face_ptr[6];
     for (int f = 0; f < 6; f++) { faces.push_back(checker(256, 256, 3, 32, 5, 40 + 20 * f)); face_ptr[f] = faces.back().data(); }
@@ -63,6 +78,7 @@ int main(int argc, char** argv)
     auto marsTex = glWrapper.load_texture_raw(3, 512, 256, 3, tm.data(), "texture_sphere_3");
     auto ringTex = glWrapper.load_texture_raw(4, 2048, 125, 4, tr.data(), "texture_ring");
     auto boxTex = glWrapper.load_texture_raw(5, 128, 128, 4, tb.data(), "texture_box");
+#endif
 
     SceneManager scene_manager(wind_width, wind_height, &scene, &glWrapper);
     scene_manager.init();

@@ -10,9 +10,10 @@
 //     presentation are outside the replaced path -- SURVEY.md section 8(b),(f));
 //   * enable_SMAA is accepted and ignored (post-process after the tracer; section 8(f1));
 //   * image files: the tracer boundary takes decoded 8-bit texels. load_texture/load_cubemap
-//     decode through a pluggable function (set_image_decoder); the built-in decoder reads PNG (png_decode.h) and binary
-//     PPM/PGM (P6/P5) and PAM (P7, RGB_ALPHA) only. With RTX_WITH_STB_IMAGE defined and
-//     stb_image.h on the include path the reference's decoder (stbi_load) is used instead;
+//     decode through a pluggable function (set_image_decoder); the built-in decoder reads PNG (png_decode.h), JPEG
+//     (jpeg_decode.h; stb_image's arithmetic, so the texels equal the reference's) and binary PPM/PGM (P6/P5) and
+//     PAM (P7, RGB_ALPHA). With RTX_WITH_STB_IMAGE defined and stb_image.h on the include path the reference's
+//     decoder (stbi_load) is used instead;
 //   * extra, non-reference conveniences: load_texture_raw, load_cubemap_raw, read_pixels.
 #pragma once
 
@@ -29,6 +30,7 @@
 #include <stb_image.h>
 #endif
 #include "png_decode.h"
+#include "jpeg_decode.h"
 
 #ifndef ASSETS_DIR
 #define ASSETS_DIR "."
@@ -108,7 +110,8 @@ inline unsigned char* decode_pnm(const char* path, int* w, int* h, int* channels
 #ifdef RTX_WITH_STB_IMAGE
 inline unsigned char* decode_stb(const char* path, int* w, int* h, int* channels) { return stbi_load(path, w, h, channels, 0); }
 #endif
-// built-in: PNG (include/rtx/png_decode.h, stb_image's output convention) or binary PNM/PAM, told apart by the file's first bytes
+// built-in: PNG (png_decode.h), JPEG (jpeg_decode.h) -- both with stb_image's output convention -- or binary PNM/PAM,
+// told apart by the file's first bytes
 inline unsigned char* decode_builtin(const char* path, int* w, int* h, int* channels)
 {
     unsigned char head[2] = {0, 0};
@@ -117,6 +120,7 @@ inline unsigned char* decode_builtin(const char* path, int* w, int* h, int* chan
     const size_t got = std::fread(head, 1, 2, f);
     std::fclose(f);
     if (got == 2 && head[0] == 0x89 && head[1] == 'P') return rtx_png::decode_file(path, w, h, channels);
+    if (got == 2 && head[0] == 0xFF && head[1] == 0xD8) return rtx_jpeg::decode_file(path, w, h, channels);
     return decode_pnm(path, w, h, channels);
 }
 inline image_decoder& decoder()

@@ -226,7 +226,12 @@ inline unsigned char* decode_memory(const uint8_t* d, size_t n, int* w_out, int*
     const int bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
 
     std::vector<uint8_t> raw;
-    raw.reserve((static_cast<size_t>(W) * bits_pp / 8 + 2) * H);
+    if (static_cast<uint64_t>(W) * static_cast<uint64_t>(H) > (1ull << 30)) return nullptr;
+    {   // a damaged header must not size the allocation: DEFLATE cannot expand by more than 1032:1
+        const size_t expect = (static_cast<size_t>(W) * static_cast<size_t>(bits_pp) / 8 + 2) * static_cast<size_t>(H);
+        const size_t ceiling = idat.size() * 1032 + 1024;
+        raw.reserve(expect < ceiling ? expect : ceiling);
+    }
     if (!inflate(idat.data(), idat.size(), raw)) return nullptr;
 
     // output channel count (stb_image: req_comp = 0)

@@ -46,7 +46,7 @@ __attribute__((visibility("default"))) size_t rtxh_scene_build(const char* kind,
     return blob.size();
 }
 
-// The shim's built-in image decoder (PNG / PNM), for tests and Python callers: returns the byte count w*h*channels
+// The shim's built-in image decoder (PNG / JPEG / PNM), for tests and Python callers: returns the byte count w*h*channels
 // (0 on failure) and copies min(needed, cap) bytes of interleaved 8-bit texels, row 0 = top row of the file.
 __attribute__((visibility("default"))) size_t rtxh_decode_image(const char* path, int* w, int* h, int* channels, void* out, size_t cap)
 {

@@ -11,4 +11,4 @@ g++ -std=c++11 -O1 -ffp-contract=off -include cfloat \
     "$HERE/tools/gen_golden_blocks.cpp" "$REF/src/SceneManager.cpp" \
     -Wl,--unresolved-symbols=ignore-all -o "$OUT"
 "$OUT" "$HERE/tests/golden"
-( cd "$HERE/tests/golden" && sha256sum *.rtxb > SHA256SUMS )
+( cd "$HERE/tests/golden" && sha256sum *.rtxb *.npz jpeg/* > SHA256SUMS )
