@@ -1401,19 +1401,51 @@ RT_HD f3 ray_dir(const SceneView& S, float frag_x, float frag_y)
 // -- then at most one shading evaluation. All lanes of a wave walk the loop together; `alive`
 // predicates the work, so texture fetch sites stay in wave-uniform control flow.
 // ------------------------------------------------------------------------------------------
+// Path state that is only touched a few times per bounce-loop trip but would otherwise sit in ~19 VGPRs across the
+// closest-hit scan AND the shadow scans of the shading site: the accumulated colour, the path mask, the next ray, the
+// refracted continuation that waits while a mirror ray runs, the absorb distance. On the device these live in LDS (one
+// dword column per lane, slot k at base[k * RT_PS_STRIDE]: lanes hit consecutive banks), which is what lets the kernel
+// fit the 5-waves-per-SIMD register budget without spilling to scratch memory (the compiler's own spills of the same
+// values went through L2 to HBM: 3x the frame in write traffic). Values round-trip bit for bit, the arithmetic and its
+// order are untouched. The host build keeps them in a plain array.
+// fence(): an ordinary LDS store to a slot whose index the compiler cannot see (a kernel argument): it may alias every
+// slot, so loads after the shading site are not merged with loads before it (which would pin the values in registers
+// across the shadow scans again) -- and, being LDS-only, it leaves the scene tables' scalar loads invariant, unlike a
+// compiler-level memory clobber.
+enum { PS_COLOR = 0, PS_MASK = 3, PS_RO = 6, PS_RD = 9, PS_CONT_RO = 12, PS_CONT_RD = 15, PS_ABSORB = 18, PS_SLOTS = 19 };
+#ifndef RT_PS_STRIDE
+#define RT_PS_STRIDE 256
+#endif
+struct PathStore {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float* base;      // this lane's column in LDS
+    int fence_slot;   // run-time value (= PS_SLOTS): a pad slot
+    RT_HDM float ld(int k) const { return base[k * RT_PS_STRIDE]; }
+    RT_HDM void st(int k, float v) const { base[k * RT_PS_STRIDE] = v; }
+    RT_HDM void fence() const { base[fence_slot * RT_PS_STRIDE] = 0.0f; }
+#else
+    mutable float v[PS_SLOTS];
+    RT_HDM float ld(int k) const { return v[k]; }
+    RT_HDM void st(int k, float x) const { v[k] = x; }
+    RT_HDM void fence() const {}
+#endif
+    RT_HDM f3 ld3(int k) const { return mk3(ld(k), ld(k + 1), ld(k + 2)); }
+    RT_HDM void st3(int k, f3 x) const { st(k, x.x); st(k + 1, x.y); st(k + 2, x.z); }
+};
+
 template <bool CULL, bool COUNT>
-RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
+RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
 {
-    f3 mask = mk3(1.0f, 1.0f, 1.0f);
-    f3 color = mk3(0.0f, 0.0f, 0.0f);
-    f3 ro = xyz(S.h->cam_pos);
-    f3 rd = ray_dir(S, frag_x, frag_y);
-    float absorbDistance = 0.0f;
+    P.st3(PS_MASK, mk3(1.0f, 1.0f, 1.0f));
+    P.st3(PS_COLOR, mk3(0.0f, 0.0f, 0.0f));
+    P.st3(PS_RO, xyz(S.h->cam_pos));
+    P.st3(PS_RD, ray_dir(S, frag_x, frag_y));
+    P.st(PS_ABSORB, 0.0f);
     const int iterations = S.h->iterations;
     int i = 0;          // the shader's loop variable
     int segments = 0;   // main-loop trips taken (cap, trap T2)
-    bool side = false;  // the NEXT trip traces getReflectedColor's ray
-    f3 cont_ro = ro, cont_rd = rd;  // refracted continuation of the main path while the side ray runs
+    bool side = false;  // the NEXT trip traces getReflectedColor's ray; the refracted continuation of the main path waits
+                        // in PS_CONT_RO / PS_CONT_RD while it runs
     float side_R = 0.0f;
 
     alive = alive && iterations > 0;
@@ -1423,6 +1455,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         RT_PH_ADD(cnt, PH_TRIPS, 1);
         const bool is_side = side;  // what THIS trip traces
         if (alive && !is_side) segments++;
+        const f3 ro = P.ld3(PS_RO), rd = P.ld3(PS_RD);
 
         // ---- one closest-hit ray per live lane ----
         int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
@@ -1449,13 +1482,12 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         float k_mask = 1.0f;  // mask factor applied AFTER the shaded term was weighted with the old mask
         bool finished = false;  // lane leaves the loop after this trip
         bool sky = false;
-        f3 new_ro = ro, new_rd = rd;
 
         if (alive) {
             if (is_side) {
                 // getReflectedColor: light sphere -> its colour; miss -> BLACK (trap T3); else one shade
                 if (type == TYPE_POINT_LIGHT) {
-                    color = color + (xyz(S.lights_point()[num].color_intensity) * side_R) * mask;
+                    P.st3(PS_COLOR, P.ld3(PS_COLOR) + (xyz(S.lights_point()[num].color_intensity) * side_R) * P.ld3(PS_MASK));
                 } else if (hit) {
                     act = ACT_SIDE;
                     sh_pt = dot3(rd, n) < 0.0f ? pt + n * h.bias : pt - n * h.bias;  // n stays unflipped (trap T18)
@@ -1464,18 +1496,18 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
                     // miss: the shader still executes color += vec3(0) * reflectMultiplier * mask (rt.frag:855). That is
                     // +0 for a finite mask, but NaN once the mask has overflowed (exp(-absorb * negative distance) inside
                     // a box, traps T12 + T21) -- and then the pixel must come out NaN like the reference's, not inf.
-                    color = color + (mk3(0.0f, 0.0f, 0.0f) * side_R) * mask;
+                    P.st3(PS_COLOR, P.ld3(PS_COLOR) + (mk3(0.0f, 0.0f, 0.0f) * side_R) * P.ld3(PS_MASK));
                 }
                 k_mask = 1.0f - side_R;
                 if (side_R >= 1.0f) finished = true;  // total reflection: checked after the mirror term (rt.frag:865)
-                new_ro = cont_ro;
-                new_rd = cont_rd;
+                P.st3(PS_RO, P.ld3(PS_CONT_RO));
+                P.st3(PS_RD, P.ld3(PS_CONT_RD));
                 side = false;
             } else if (!hit) {
                 sky = true;
                 finished = true;
             } else if (type == TYPE_POINT_LIGHT) {
-                color = color + xyz(S.lights_point()[num].color_intensity) * mask;
+                P.st3(PS_COLOR, P.ld3(PS_COLOR) + xyz(S.lights_point()[num].color_intensity) * P.ld3(PS_MASK));
                 finished = true;
             } else {
                 const bool outside = dot3(rd, n) < 0.0f;
@@ -1489,22 +1521,23 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
                     const f3 next_ro = pt - n * h.bias;
                     const f3 next_rd = gl_refract(rd, n, outside ? 1.0f / h.refraction : h.refraction);
                     if (outside && h.reflection > 0.0f) {
-                        // next trip: the mirror ray; the refracted ray waits in cont_*
+                        // next trip: the mirror ray; the refracted ray waits in the continuation slots
                         side = true;
                         side_R = R;
-                        cont_ro = next_ro;
-                        cont_rd = next_rd;
-                        new_ro = pt + n * h.bias;
-                        new_rd = gl_reflect(rd, n);
+                        P.st3(PS_CONT_RO, next_ro);
+                        P.st3(PS_CONT_RD, next_rd);
+                        P.st3(PS_RO, pt + n * h.bias);
+                        P.st3(PS_RD, gl_reflect(rd, n));
                     } else {
                         if (!outside) {
-                            absorbDistance += tm;  // accumulates over all inside segments (trap T12)
-                            mask = mask * mk3(expf(-h.absorb.x * absorbDistance), expf(-h.absorb.y * absorbDistance),
-                                              expf(-h.absorb.z * absorbDistance));
+                            const float absorbDistance = P.ld(PS_ABSORB) + tm;  // accumulates over all inside segments (trap T12)
+                            P.st(PS_ABSORB, absorbDistance);
+                            P.st3(PS_MASK, P.ld3(PS_MASK) * mk3(expf(-h.absorb.x * absorbDistance), expf(-h.absorb.y * absorbDistance),
+                                                                 expf(-h.absorb.z * absorbDistance)));
                         }
                         if (R >= 1.0f) finished = true;
-                        new_ro = next_ro;
-                        new_rd = next_rd;
+                        P.st3(PS_RO, next_ro);
+                        P.st3(PS_RD, next_rd);
                     }
                     // i is not advanced: "i--" cancels the loop increment (rt.frag:870-872, trap T2)
                 } else if (h.reflection > 0.0f) {  // reflective, rt.frag:874-880
@@ -1512,15 +1545,15 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
                     sh_pt = pt + n * h.bias;
                     w_s = 1.0f - R;
                     k_mask = R;
-                    new_ro = sh_pt;
-                    new_rd = gl_reflect(rd, n);
+                    P.st3(PS_RO, sh_pt);
+                    P.st3(PS_RD, gl_reflect(rd, n));
                     i++;
                 } else {  // diffuse, rt.frag:881-890
                     act = ACT_DIFFUSE;
                     sh_pt = pt + n * h.bias;
                     w_s = h.alpha;
                     if (h.alpha < 1.0f) {  // alpha pass-through keeps rd, costs an iteration (trap T13)
-                        new_ro = pt - n * h.bias;
+                        P.st3(PS_RO, pt - n * h.bias);
                         k_mask = 1.0f - h.alpha;
                         i++;
                     } else {
@@ -1535,28 +1568,31 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, bool alive, float fr
         if (RT_ANY(sky)) {
             if (sky) {
                 const f4 c = sample_cube(T.sky, rd);
-                color = color + mk3(c.x, c.y, c.z) * mask;
+                P.st3(PS_COLOR, P.ld3(PS_COLOR) + mk3(c.x, c.y, c.z) * P.ld3(PS_MASK));
             }
         }
 
         RT_PH_LAP(cnt, PH_SKY);
         // ---- the single shading site ----
         f3 col = mk3(0.0f, 0.0f, 0.0f);
-        if (RT_ANY(act != ACT_NONE)) col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
+        if (RT_ANY(act != ACT_NONE)) {
+            P.fence();
+            col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
+        }
         RT_PH_LAP(cnt, PH_SHADE);
 
         // ---- apply + advance ----
         if (alive) {
-            if (act == ACT_DIFFUSE) color = color + (col * mask) * w_s;          // calcShade * mask * alpha
-            else if (act != ACT_NONE) color = color + (col * w_s) * mask;        // calcShade * R|T * mask
-            mask = mask * k_mask;  // x * 1.0f == x: lanes without a mask change are untouched
-            ro = new_ro;
-            rd = new_rd;
+            const f3 mask = P.ld3(PS_MASK);
+            if (act == ACT_DIFFUSE) P.st3(PS_COLOR, P.ld3(PS_COLOR) + (col * mask) * w_s);          // calcShade * mask * alpha
+            else if (act != ACT_NONE) P.st3(PS_COLOR, P.ld3(PS_COLOR) + (col * w_s) * mask);        // calcShade * R|T * mask
+            P.st3(PS_MASK, mask * k_mask);  // x * 1.0f == x: lanes without a mask change are untouched
             // loop condition of the shader's for(), evaluated before the next MAIN trip
             if (finished || (!side && (i >= iterations || segments >= RT_SEGMENT_CAP))) alive = false;
         }
         RT_PH_LAP(cnt, PH_APPLY);
     }
+    const f3 color = P.ld3(PS_COLOR);
     return mk4(color.x, color.y, color.z, 1.0f);
 }
 

@@ -65,16 +65,19 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4
+#define RT_WAVES_PER_EU 5
 #endif
-// Two register budgets of the same code (WPE = waves per SIMD the compiler must make room for):
-//   WPE = RT_WAVES_PER_EU (4: 123 VGPRs, no scratch) -- the default. It keeps the HBM traffic at the frame plus the
-//         texture lines; 5 waves (96 VGPRs, 108 B scratch per lane) is 3 % faster on the default scene but writes 1.1 GB
-//         of spill traffic per 4K frame (WRITE_SIZE 1 136 603 KB vs 129 819 KB), so it is not the default.
-//   WPE = 8 (64 VGPRs, 248 B scratch) -- scenes with many primitives, where every ray walks long tables of scalar loads
-//         and latency hiding is worth more than the spills: quadric-heavy 4K 3.41 -> 2.71 ms, torus-heavy 3.09 -> 2.78 ms
-//         (but default scene 0.60 -> 0.83 ms). Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
-#define RT_WPE_HEAVY 8
+#ifndef RT_WPE_HEAVY
+#define RT_WPE_HEAVY 7
+#endif
+// Two register budgets of the same code (WPE = waves per SIMD the compiler must make room for; numbers for 4K frames,
+// built with -mllvm -disable-machine-licm, see the Makefile):
+//   WPE = RT_WAVES_PER_EU (5: 96 VGPRs, 56 B of scratch per lane, touched at the shading site once per bounce-loop trip,
+//         not per primitive) -- the default: 535 us on the default scene against 579 us for the spill-free 4-wave build
+//         (113 VGPRs). The price is spill traffic through L2 (profiles/: WRITE_SIZE / FETCH_SIZE).
+//   WPE = RT_WPE_HEAVY (7: 72 VGPRs) -- scenes with many primitives, where every ray walks long tables of scalar loads
+//         and latency hiding is worth more than the spills: quadric-heavy 4K 2708 -> 2477 us, torus-heavy 2778 -> 2668 us
+//         against the 5-wave build. Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
 
 template <bool CULL, bool COUNT, bool LDS, int WPE>
 __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams p)
@@ -156,7 +159,14 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
 #ifdef RT_PHASE_TIMERS
     const unsigned long long _k0 = clock64();
 #endif
-    const f4 px = trace_pixel<CULL, COUNT>(S, p.tex, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
+    // path state in LDS: PS_SLOTS dword columns of 256 lanes + one pad column for PathStore::fence (20 KB per workgroup)
+    __shared__ float path_lds[(rtdev::PS_SLOTS + 1) * RT_PS_STRIDE];
+    rtdev::PathStore path;
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of this file sees the array-backed PathStore of the host build)
+    path.base = path_lds + threadIdx.x;
+    path.fence_slot = p.ps_fence_slot;
+#endif
+    const f4 px = trace_pixel<CULL, COUNT>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
 
     // The pixel's coordinates are needed again only here. They are RE-DERIVED from the thread index
     // (laundered through an empty asm so the compiler cannot keep the first copy alive) instead of
@@ -228,6 +238,7 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
     if (grid.x == 0 || grid.y == 0) return hipSuccess;
     p.grid_x = (int)grid.x;
     p.grid_y = (int)grid.y;
+    p.ps_fence_slot = rtdev::PS_SLOTS;
     if (p.xcd_remap) {
         p.st_nx = (p.grid_x + 3) / 4;
         p.st_ny = (p.grid_y + 3) / 4;

@@ -80,8 +80,9 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
         for (int x = 0; x < fr->fb_width; x++) {
             LaneCounters c = {0, 0, 0, 0};
             f4 px;
-            if (fr->cull) px = trace_pixel<true, true>(S, T, true, (float)x + 0.5f, (float)y + 0.5f, c);
-            else px = trace_pixel<false, true>(S, T, true, (float)x + 0.5f, (float)y + 0.5f, c);
+            PathStore path;
+            if (fr->cull) px = trace_pixel<true, true>(S, T, path, true, (float)x + 0.5f, (float)y + 0.5f, c);
+            else px = trace_pixel<false, true>(S, T, path, true, (float)x + 0.5f, (float)y + 0.5f, c);
             float* o = out + (static_cast<size_t>(y - y0) * fr->fb_width + x) * 4;
             o[0] = px.x; o[1] = px.y; o[2] = px.z; o[3] = px.w;
             tot[0] += c.closest; tot[1] += c.shadow_ref; tot[2] += c.shadow_cast; tot[3] += c.torus_solves;

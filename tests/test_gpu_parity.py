@@ -275,6 +275,43 @@ def test_full_size_stress_configs(small_textures, kind, depth, rows):
     gl.stop()
 
 
+def test_config4_8k_frame_from_eight_band_shares(small_textures):
+    """BASELINE.json configs[4] (default scene, 7680x4320, depth 4, 8 ranks) on one GPU: each of the 8 ranks' interleaved
+    8-row band shares is traced exactly as bench.py traces it (RGBA8 target), the root's un-permute gives the full RGBA8
+    frame byte for byte, the shares' ray counts add up to the frame's, and the float frame matches the oracle on rows
+    sampled across the image."""
+    import torch
+    from raytracing_opengl_amd import bands
+    w, h, depth, world, band_rows = 7680, 4320, 4, 8, 8
+    sc = scenes.build_scene("default", w, h, depth)
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    gl.draw()
+    gl.finish()
+    st = gl.stats()
+    total = (st["rays_closest"], st["rays_shadow"])
+    full8 = torch.from_numpy(gl.read_pixels(wrapper.RTX_RGBA8)).view(h, w, 4)
+    full32 = gl.read_pixels()
+    rows_max = bands.max_local_rows(h, band_rows, world)
+    parts, got = [], [0, 0]
+    for r in range(world):
+        buf = torch.zeros((rows_max, w, 4), dtype=torch.uint8, device="cuda:0")
+        gl.draw_bands(band_rows, r, world, buf.data_ptr(), wrapper.RTX_RGBA8)
+        gl.finish()
+        st = gl.stats()
+        got[0] += st["rays_closest"]
+        got[1] += st["rays_shadow"]
+        parts.append(buf.cpu())
+    assert tuple(got) == total
+    assert torch.equal(bands.unpermute(parts, h, band_rows, world), full8)
+    o = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    for y0 in (0, 1072, 2000, 2160, 2608, 4312):
+        ref, _ = o.render(y0, y0 + 8)
+        mx, nbad, nanbad = _compare(full32[y0:y0 + 8], ref)
+        assert nanbad == 0 and mx <= TOL, (y0, mx)
+    gl.stop()
+
+
 def _golden_ids():
     import golden_frames
     import os

@@ -1,19 +1,20 @@
 #!/bin/bash
 # Static facts about the product kernel <CULL=1,COUNT=0,LDS=0>: instruction mix, registers, spills.
-# usage: tools/isa_stats.sh [extra hipcc flags]
+# usage: [ISA_WPE=7] tools/isa_stats.sh [extra hipcc flags]     (ISA_WPE: which waves-per-SIMD instantiation; default 5 = the light one)
 cd "$(dirname "$0")/.."
 OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
-/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=4 --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
+/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=5 -DRT_WPE_HEAVY=7 --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -disable-machine-licm -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
 python3 - "$OUT" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
-m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi(\d+)EEEv14RtLaunchParams:', txt) if x.group(1) != '8' or 'RT_WAVES_PER_EU=8' in ' '.join(sys.argv)]
+import os
+m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi(\d+)EEEv14RtLaunchParams:', txt) if x.group(1) == os.environ.get('ISA_WPE', '5')]
 i=m[0].start()
 j=txt.find('.end_amdhsa_kernel',i)
 body=txt[i:j]
 ins=[l.strip() for l in body.split('\n') if l.startswith('\t') and not l.strip().startswith(('.',';'))]
 valu=[l for l in ins if l.startswith('v_')]
 c=lambda p: sum(l.startswith(p) for l in ins)
-print('instrs',len(ins),'valu',len(valu),'pk',c('v_pk_'),'writelane',c('v_writelane'),'readlane',c('v_readlane'),'s_load',c('s_load'),'scratch',c('scratch_'), 'div',c('v_div_fixup'))
+print('instrs',len(ins),'ds',c('ds_'),'valu',len(valu),'pk',c('v_pk_'),'writelane',c('v_writelane'),'readlane',c('v_readlane'),'s_load',c('s_load'),'scratch',c('scratch_'), 'div',c('v_div_fixup'))
 print(re.findall(r'; (?:NumVgprs|ScratchSize|NumSgprs|Occupancy): \d+', txt[j:j+4000])[:4])
 PY

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: kernel time of ONE rank's share of the 4K default frame for N = 1, 2, 4, 8 ranks (interleaved 8-row bands,
-RGBA8 target) -- what each GPU of a multi-GPU run traces, measured on one GPU. Shows how far per-rank work is from 1/N."""
+"""GPU box: kernel time of ONE rank's share of the default frame (4K, or `time_bands.py W H`) for N = 1, 2, 4, 8 ranks
+(interleaved 8-row bands, RGBA8 target) -- what each GPU of a multi-GPU run traces, measured on one GPU. Shows how far
+per-rank work is from 1/N."""
 import os
 import sys
 
@@ -12,7 +13,7 @@ from raytracing_opengl_amd import bands, scenes, textures, wrapper  # noqa: E402
 
 
 def main():
-    w, h = 3840, 2160
+    w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
     sc = scenes.build_scene("default", w, h, 4)
     if os.environ.get("NO_TORUS"):   # ablation: is the per-rank floor the torus solver's long waves?
         d = list(sc.defines); d[4] = 0
