@@ -280,7 +280,7 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     }
     const int e = ctx->ev_head;
     HIP_TRY(hipEventRecord(ctx->ev_start[e], stream));
-    // long primitive tables (quadric-/torus-heavy scenes): the 8-waves-per-SIMD build of the kernel hides the table walks
+    // long primitive tables (quadric-/torus-heavy scenes): the 7-waves-per-SIMD build of the kernel hides the table walks
     const rtpack::Defines& df = ctx->defines;
     const int n_prims = df.sphere_size + df.plane_size + df.surface_size + df.box_size + df.torus_size + df.ring_size;
     const bool high_occ = ctx->opt_occ < 0 ? n_prims >= 32 : ctx->opt_occ != 0;
