@@ -76,7 +76,7 @@ typedef enum rtx_option {
     RTX_OPT_HOT_ROWS_FIRST = 6, /* 1 (default): in rtx_draw_bands launches that cover a quarter of the frame or less (band_stride >= 4)
                                 the workgroup rows that show a torus -- tiles that run ~20x the median -- are dispatched first, so
                                 that they do not form the tail of the launch; 0: plain row order. Same results either way. */
-    RTX_OPT_HIGH_OCCUPANCY = 5 /* which register budget of the trace kernel runs: 0 = 5 waves/SIMD (no register spills),
+    RTX_OPT_HIGH_OCCUPANCY = 5 /* which register budget of the trace kernel runs: 0 = 6 waves/SIMD,
                                 1 = 7 waves/SIMD (spills to scratch, hides the scalar table walks of scenes with many
                                 primitives), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
 } rtx_option;

@@ -1404,49 +1404,67 @@ RT_HD f3 ray_dir(const SceneView& S, float frag_x, float frag_y)
 // Path state that is only touched a few times per bounce-loop trip but would otherwise sit in ~19 VGPRs across the
 // closest-hit scan AND the shadow scans of the shading site: the accumulated colour, the path mask, the next ray, the
 // refracted continuation that waits while a mirror ray runs, the absorb distance. On the device these live in LDS (one
-// dword column per lane, slot k at base[k * RT_PS_STRIDE]: lanes hit consecutive banks), which is what lets the kernel
-// fit the 5-waves-per-SIMD register budget without spilling to scratch memory (the compiler's own spills of the same
-// values went through L2 to HBM: 3x the frame in write traffic). Values round-trip bit for bit, the arithmetic and its
+// dword column per lane, slot k at base[k * RT_PS_STRIDE]: lanes hit consecutive banks), which is what makes 5 and 6 waves
+// per SIMD affordable: at 5 the kernel fits its 96 VGPRs without any scratch, where the compiler's own spills of the same
+// values went through L2 to HBM (3x the frame in write traffic). Values round-trip bit for bit, the arithmetic and its
 // order are untouched. The host build keeps them in a plain array.
 // fence(): an ordinary LDS store to a slot whose index the compiler cannot see (a kernel argument): it may alias every
 // slot, so loads after the shading site are not merged with loads before it (which would pin the values in registers
 // across the shadow scans again) -- and, being LDS-only, it leaves the scene tables' scalar loads invariant, unlike a
 // compiler-level memory clobber.
-enum { PS_COLOR = 0, PS_MASK = 3, PS_RO = 6, PS_RD = 9, PS_CONT_RO = 12, PS_CONT_RD = 15, PS_ABSORB = 18, PS_SLOTS = 19 };
+// The four loop scalars behind PS_SCALARS (mirror weight, shaded-term weight, mask factor, the two trip counters packed
+// into one word) join them only in the WIDE layout: 23 + 1 slots = 24 KB per workgroup fit six workgroups per CU (6
+// waves/SIMD) into the 160 KB of LDS but not seven, so the build for 7 waves/SIMD keeps them in registers (19 + 1 slots).
+enum { PS_COLOR = 0, PS_MASK = 3, PS_RO = 6, PS_RD = 9, PS_CONT_RO = 12, PS_CONT_RD = 15, PS_ABSORB = 18, PS_SLOTS_NARROW = 19,
+       PS_SCALARS = 19, QS_SIDE_R = 0, QS_W = 1, QS_K = 2, QS_COUNT = 3, PS_SLOTS_WIDE = 23 };
+constexpr int path_slots(bool wide) { return wide ? PS_SLOTS_WIDE : PS_SLOTS_NARROW; }
 #ifndef RT_PS_STRIDE
 #define RT_PS_STRIDE 256
 #endif
 struct PathStore {
 #if defined(__HIP_DEVICE_COMPILE__)
     float* base;      // this lane's column in LDS
-    int fence_slot;   // run-time value (= PS_SLOTS): a pad slot
+    int fence_slot;   // run-time value (= path_slots(wide)): a pad slot
     RT_HDM float ld(int k) const { return base[k * RT_PS_STRIDE]; }
     RT_HDM void st(int k, float v) const { base[k * RT_PS_STRIDE] = v; }
     RT_HDM void fence() const { base[fence_slot * RT_PS_STRIDE] = 0.0f; }
 #else
-    mutable float v[PS_SLOTS];
+    mutable float v[PS_SLOTS_WIDE];
     RT_HDM float ld(int k) const { return v[k]; }
     RT_HDM void st(int k, float x) const { v[k] = x; }
     RT_HDM void fence() const {}
 #endif
+    RT_HDM int ldi(int k) const { return __builtin_bit_cast(int, ld(k)); }
+    RT_HDM void sti(int k, int x) const { st(k, __builtin_bit_cast(float, x)); }
     RT_HDM f3 ld3(int k) const { return mk3(ld(k), ld(k + 1), ld(k + 2)); }
     RT_HDM void st3(int k, f3 x) const { st(k, x.x); st(k + 1, x.y); st(k + 2, x.z); }
 };
 
-template <bool CULL, bool COUNT>
+template <bool IN_LDS>
+struct PathScalars {   // the four loop scalars: LDS slots PS_SCALARS.. (WIDE layout) or registers
+    float r[4];
+    RT_HDM float ld(const PathStore& P, int k) const { return IN_LDS ? P.ld(PS_SCALARS + k) : r[k]; }
+    RT_HDM void st(const PathStore& P, int k, float v) { if (IN_LDS) P.st(PS_SCALARS + k, v); else r[k] = v; }
+    RT_HDM int ldi(const PathStore& P, int k) const { return __builtin_bit_cast(int, ld(P, k)); }
+    RT_HDM void sti(const PathStore& P, int k, int v) { st(P, k, __builtin_bit_cast(float, v)); }
+};
+
+template <bool CULL, bool COUNT, bool WIDE = false>
 RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
 {
+    PathScalars<WIDE> Q;
     P.st3(PS_MASK, mk3(1.0f, 1.0f, 1.0f));
     P.st3(PS_COLOR, mk3(0.0f, 0.0f, 0.0f));
     P.st3(PS_RO, xyz(S.h->cam_pos));
     P.st3(PS_RD, ray_dir(S, frag_x, frag_y));
     P.st(PS_ABSORB, 0.0f);
+    Q.st(P, QS_SIDE_R, 0.0f);
+    Q.st(P, QS_W, 0.0f);
+    Q.st(P, QS_K, 1.0f);
+    Q.sti(P, QS_COUNT, 0);   // low half: i, the shader's loop variable; high half: segments = main-loop trips taken (cap, trap T2)
     const int iterations = S.h->iterations;
-    int i = 0;          // the shader's loop variable
-    int segments = 0;   // main-loop trips taken (cap, trap T2)
     bool side = false;  // the NEXT trip traces getReflectedColor's ray; the refracted continuation of the main path waits
                         // in PS_CONT_RO / PS_CONT_RD while it runs
-    float side_R = 0.0f;
 
     alive = alive && iterations > 0;
     RT_PH_DECL;
@@ -1454,7 +1472,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
     while (RT_ANY(alive)) {
         RT_PH_ADD(cnt, PH_TRIPS, 1);
         const bool is_side = side;  // what THIS trip traces
-        if (alive && !is_side) segments++;
+        if (alive && !is_side) Q.sti(P, QS_COUNT, Q.ldi(P, QS_COUNT) + 0x10000);   // segments++
         const f3 ro = P.ld3(PS_RO), rd = P.ld3(PS_RD);
 
         // ---- one closest-hit ray per live lane ----
@@ -1485,6 +1503,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
 
         if (alive) {
             if (is_side) {
+                const float side_R = Q.ld(P, QS_SIDE_R);
                 // getReflectedColor: light sphere -> its colour; miss -> BLACK (trap T3); else one shade
                 if (type == TYPE_POINT_LIGHT) {
                     P.st3(PS_COLOR, P.ld3(PS_COLOR) + (xyz(S.lights_point()[num].color_intensity) * side_R) * P.ld3(PS_MASK));
@@ -1523,7 +1542,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
                     if (outside && h.reflection > 0.0f) {
                         // next trip: the mirror ray; the refracted ray waits in the continuation slots
                         side = true;
-                        side_R = R;
+                        Q.st(P, QS_SIDE_R, R);
                         P.st3(PS_CONT_RO, next_ro);
                         P.st3(PS_CONT_RD, next_rd);
                         P.st3(PS_RO, pt + n * h.bias);
@@ -1547,7 +1566,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
                     k_mask = R;
                     P.st3(PS_RO, sh_pt);
                     P.st3(PS_RD, gl_reflect(rd, n));
-                    i++;
+                    Q.sti(P, QS_COUNT, Q.ldi(P, QS_COUNT) + 1);   // i++
                 } else {  // diffuse, rt.frag:881-890
                     act = ACT_DIFFUSE;
                     sh_pt = pt + n * h.bias;
@@ -1555,7 +1574,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
                     if (h.alpha < 1.0f) {  // alpha pass-through keeps rd, costs an iteration (trap T13)
                         P.st3(PS_RO, pt - n * h.bias);
                         k_mask = 1.0f - h.alpha;
-                        i++;
+                        Q.sti(P, QS_COUNT, Q.ldi(P, QS_COUNT) + 1);   // i++
                     } else {
                         finished = true;
                     }
@@ -1576,6 +1595,8 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- the single shading site ----
         f3 col = mk3(0.0f, 0.0f, 0.0f);
         if (RT_ANY(act != ACT_NONE)) {
+            Q.st(P, QS_W, w_s);
+            Q.st(P, QS_K, k_mask);
             P.fence();
             col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
         }
@@ -1584,6 +1605,9 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- apply + advance ----
         if (alive) {
             const f3 mask = P.ld3(PS_MASK);
+            if (act != ACT_NONE) { w_s = Q.ld(P, QS_W); k_mask = Q.ld(P, QS_K); }
+            const int counts = Q.ldi(P, QS_COUNT);
+            const int i = counts & 0xffff, segments = counts >> 16;
             if (act == ACT_DIFFUSE) P.st3(PS_COLOR, P.ld3(PS_COLOR) + (col * mask) * w_s);          // calcShade * mask * alpha
             else if (act != ACT_NONE) P.st3(PS_COLOR, P.ld3(PS_COLOR) + (col * w_s) * mask);        // calcShade * R|T * mask
             P.st3(PS_MASK, mask * k_mask);  // x * 1.0f == x: lanes without a mask change are untouched

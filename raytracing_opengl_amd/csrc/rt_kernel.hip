@@ -65,19 +65,20 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 5
+#define RT_WAVES_PER_EU 6
 #endif
 #ifndef RT_WPE_HEAVY
 #define RT_WPE_HEAVY 7
 #endif
 // Two register budgets of the same code (WPE = waves per SIMD the compiler must make room for; numbers for 4K frames,
 // built with -mllvm -disable-machine-licm, see the Makefile):
-//   WPE = RT_WAVES_PER_EU (5: 96 VGPRs, 56 B of scratch per lane, touched at the shading site once per bounce-loop trip,
-//         not per primitive) -- the default: 535 us on the default scene against 579 us for the spill-free 4-wave build
-//         (113 VGPRs). The price is spill traffic through L2 (profiles/: WRITE_SIZE / FETCH_SIZE).
-//   WPE = RT_WPE_HEAVY (7: 72 VGPRs) -- scenes with many primitives, where every ray walks long tables of scalar loads
-//         and latency hiding is worth more than the spills: quadric-heavy 4K 2708 -> 2477 us, torus-heavy 2778 -> 2668 us
-//         against the 5-wave build. Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
+//   WPE = RT_WAVES_PER_EU (6: 80 VGPRs, path state in LDS, 44 B of scratch per lane around the torus solver's register
+//         peak) -- the default: 500 us on the default scene (5 waves, no scratch at all: 523 us; 4 waves: 585 us).
+//   WPE = RT_WPE_HEAVY (7: 72 VGPRs, 96 B) -- scenes with many primitives, where every ray walks long tables of scalar
+//         loads and latency hiding is worth more than the spills: quadric-heavy 4K 2530 -> 2440 us, torus-heavy
+//         2710 -> 2650 us against the 6-wave build. Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
+
+constexpr bool ps_wide(int wpe) { return wpe <= 6; }   // 6 workgroups x 24 KB fit the CU's 160 KB of LDS, 7 do not
 
 template <bool CULL, bool COUNT, bool LDS, int WPE>
 __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams p)
@@ -159,14 +160,16 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
 #ifdef RT_PHASE_TIMERS
     const unsigned long long _k0 = clock64();
 #endif
-    // path state in LDS: PS_SLOTS dword columns of 256 lanes + one pad column for PathStore::fence (20 KB per workgroup)
-    __shared__ float path_lds[(rtdev::PS_SLOTS + 1) * RT_PS_STRIDE];
+    // path state in LDS: dword columns of 256 lanes + one pad column for PathStore::fence -- 24 KB per workgroup in the WIDE
+    // layout (up to 6 waves/SIMD), 20 KB otherwise (rt_device.h)
+    constexpr bool WIDE = ps_wide(WPE);
+    __shared__ float path_lds[(rtdev::path_slots(WIDE) + 1) * RT_PS_STRIDE];
     rtdev::PathStore path;
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of this file sees the array-backed PathStore of the host build)
     path.base = path_lds + threadIdx.x;
     path.fence_slot = p.ps_fence_slot;
 #endif
-    const f4 px = trace_pixel<CULL, COUNT>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
+    const f4 px = trace_pixel<CULL, COUNT, WIDE>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
 
     // The pixel's coordinates are needed again only here. They are RE-DERIVED from the thread index
     // (laundered through an empty asm so the compiler cannot keep the first copy alive) instead of
@@ -220,8 +223,10 @@ __global__ void rt_selftest_kernel(int* result)
 }  // namespace
 
 template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU>
-static hipError_t launch_variant(const RtLaunchParams& p, dim3 grid, size_t shmem, hipStream_t stream)
+static hipError_t launch_variant(const RtLaunchParams& p_in, dim3 grid, size_t shmem, hipStream_t stream)
 {
+    RtLaunchParams p = p_in;
+    p.ps_fence_slot = rtdev::path_slots(ps_wide(WPE));   // the pad column behind this variant's path-state slots
     if (LDS && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS, WPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -238,7 +243,6 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
     if (grid.x == 0 || grid.y == 0) return hipSuccess;
     p.grid_x = (int)grid.x;
     p.grid_y = (int)grid.y;
-    p.ps_fence_slot = rtdev::PS_SLOTS;
     if (p.xcd_remap) {
         p.st_nx = (p.grid_x + 3) / 4;
         p.st_ny = (p.grid_y + 3) / 4;

@@ -188,8 +188,8 @@ def test_row_bands_reassemble_the_frame(small_textures):
 
 
 def test_high_occupancy_variant_is_bit_identical(small_textures):
-    """RTX_OPT_HIGH_OCCUPANCY selects another register budget of the same kernel (7 waves/SIMD with spills instead of 5
-    without; auto-selected for scenes with >= 32 primitives): the frames must not differ in a single bit."""
+    """RTX_OPT_HIGH_OCCUPANCY selects another register budget of the same kernel (7 waves/SIMD instead of 6;
+    auto-selected for scenes with >= 32 primitives): the frames must not differ in a single bit."""
     w, h = 320, 184
     for name in ("default", "quadric"):
         sc = scenes.build_scene(name, w, h, 4)
