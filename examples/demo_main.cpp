@@ -5,7 +5,7 @@
 // SceneManager::init(), then the frame loop (update_scene -> scene_manager.update -> bind
 // textures -> draw). What differs from the reference program is only what lies outside the
 // replaced path: no GLFW window/vsync/input (a fixed number of frames driven by a synthetic
-// clock), and the last frame is written as a PPM. Textures: procedural by default, so that the demo needs no files;
+// clock), and the last frame is written as a PNG (demo_frame.png). Textures: procedural by default, so that the demo needs no files;
 // built with -DDEMO_ASSET_FILES -DASSETS_DIR=\"<reference checkout>/assets\" it loads the reference's own JPEG / PNG
 // files through load_cubemap / load_texture exactly as main.cpp:137-153 does (decoded by include/rtx/jpeg_decode.h and
 // png_decode.h to the same texels stb_image gives the reference).
@@ -102,13 +102,8 @@ int main(int argc, char** argv)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("FPS: %.1f (%d frames, %dx%d, depth 5)\n", frames / secs, frames, glWrapper.getWidth(), glWrapper.getHeight());
 
-    FILE* f = std::fopen("demo_frame.ppm", "wb");
-    if (f) {
-        std::fprintf(f, "P6\n%d %d\n255\n", glWrapper.getWidth(), glWrapper.getHeight());
-        for (int y = glWrapper.getHeight() - 1; y >= 0; y--)  // row 0 is the bottom row
-            for (int x = 0; x < glWrapper.getWidth(); x++) std::fwrite(&rgba[(static_cast<size_t>(y) * glWrapper.getWidth() + x) * 4], 1, 3, f);
-        std::fclose(f);
-    }
+    if (!rtx_png::write_file("demo_frame.png", rgba.data(), glWrapper.getWidth(), glWrapper.getHeight(), 4, /*bottom_up=*/true))
+        std::fprintf(stderr, "could not write demo_frame.png\n");
     glWrapper.stop();
     return 0;
 }

@@ -14,7 +14,8 @@
 //     (jpeg_decode.h; stb_image's arithmetic, so the texels equal the reference's) and binary PPM/PGM (P6/P5) and
 //     PAM (P7, RGB_ALPHA). With RTX_WITH_STB_IMAGE defined and stb_image.h on the include path the reference's
 //     decoder (stbi_load) is used instead;
-//   * extra, non-reference conveniences: load_texture_raw, load_cubemap_raw, read_pixels.
+//   * extra, non-reference conveniences: load_texture_raw, load_cubemap_raw, read_pixels, save_png (the frame as a file,
+//     in place of the window the reference presents it in).
 #pragma once
 
 #include <cstdio>
@@ -31,6 +32,7 @@
 #endif
 #include "png_decode.h"
 #include "jpeg_decode.h"
+#include "png_write.h"
 
 #ifndef ASSETS_DIR
 #define ASSETS_DIR "."
@@ -256,6 +258,12 @@ public:
 
     // glReadPixels stand-in: RTX_RGBA32F -> w*h*4 floats, RTX_RGBA8 -> w*h*4 bytes; row 0 = bottom
     void read_pixels(int format, void* dst, size_t bytes) { rtx_shim::check(rtx_read_pixels(ctx, format, dst, bytes), "read_pixels"); }
+    bool save_png(const char* path)   // the current frame (RGBA8, what the reference's framebuffer holds), top row first
+    {
+        std::vector<unsigned char> rgba(static_cast<size_t>(width) * static_cast<size_t>(height) * 4);
+        read_pixels(RTX_RGBA8, rgba.data(), rgba.size());
+        return rtx_png::write_file(path, rgba.data(), width, height, 4, /*bottom_up=*/true);
+    }
 
 private:
     rtx_context* ctx;

@@ -58,6 +58,12 @@ __attribute__((visibility("default"))) size_t rtxh_decode_image(const char* path
     return need;
 }
 
+// include/rtx/png_write.h for tests: 1 on success
+__attribute__((visibility("default"))) int rtxh_write_png(const char* path, const unsigned char* pixels, int w, int h, int channels, int bottom_up)
+{
+    return rtx_png::write_file(path, pixels, w, h, channels, bottom_up != 0) ? 1 : 0;
+}
+
 __attribute__((visibility("default"))) const char* rtxh_block_name(int binding)
 {
     return (binding >= 0 && binding < 9) ? scene_blob::kBlockNames[binding] : nullptr;

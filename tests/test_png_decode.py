@@ -160,3 +160,22 @@ def test_reference_png_assets(built):
         want = np.asarray(PIL.open(os.path.join(root, n)))
         got = _decode(os.path.join(root, n))
         assert got is not None and got.shape == want.shape and np.array_equal(got, want), n
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (300, 200)])   # 300x200x4 > 65535 bytes: several stored blocks
+@pytest.mark.parametrize("bottom_up", [False, True])
+def test_png_writer_round_trips(built, tmp_path, ch, size, bottom_up):
+    """include/rtx/png_write.h: Pillow and the shim's own reader get the pixels back; bottom_up flips
+    rtx_read_pixels' row order (row 0 = bottom) into the file's (row 0 = top)."""
+    lib = scenes._host_lib()
+    lib.rtxh_write_png.restype = ctypes.c_int
+    lib.rtxh_write_png.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(size[0] * 7 + ch)
+    arr = rng.integers(0, 256, (size[1], size[0], ch), dtype=np.uint8)
+    p = tmp_path / "w.png"
+    assert lib.rtxh_write_png(str(p).encode(), arr.ctypes.data, size[0], size[1], ch, int(bottom_up)) == 1
+    want = arr[::-1] if bottom_up else arr
+    assert np.array_equal(np.asarray(PIL.open(p)), want)
+    assert np.array_equal(_decode(p), want)
+    assert lib.rtxh_write_png(str(p).encode(), arr.ctypes.data, size[0], size[1], 2, 0) == 0   # unsupported channel count
