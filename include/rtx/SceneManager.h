@@ -119,6 +119,25 @@ public:
         yaw = yaw_deg;
         pitch = pitch_deg > 89.0f ? 89.0f : (pitch_deg < -89.0f ? -89.0f : pitch_deg);  // SceneManager.cpp:131-134
     }
+    void mouse_moved(double xpos, double ypos)  // SceneManager.cpp:110-135 (glfw_mouse_callback): 0.05 degrees per pixel
+    {
+        if (firstMouse) {
+            lastX = xpos;
+            lastY = ypos;
+            firstMouse = false;
+        }
+        float xoffset = static_cast<float>(xpos - lastX);
+        float yoffset = static_cast<float>(lastY - ypos);
+        lastX = xpos;
+        lastY = ypos;
+        const float sensitivity = 0.05f;
+        xoffset *= sensitivity;
+        yoffset *= sensitivity;
+        yaw += xoffset;
+        pitch += yoffset;
+        if (pitch > 89.0f) pitch = 89.0f;
+        if (pitch < -89.0f) pitch = -89.0f;
+    }
     enum Key { W, A, S, D, SPACE, CTRL, SHIFT, ALT };
     void press(Key k, bool down)
     {
@@ -141,6 +160,8 @@ private:
     glm::vec3 world_up = glm::vec3(0, 1, 0);
     float yaw = 0;
     float pitch = 0;
+    bool firstMouse = true;
+    double lastX = 0, lastY = 0;
 
     GLuint sceneUbo = 0, sphereUbo = 0, planeUbo = 0, surfaceUbo = 0, boxUbo = 0, torusUbo = 0, ringUbo = 0, lightPointUbo = 0,
            lightDirectUbo = 0;
