@@ -86,3 +86,46 @@ def test_hip_kernel_matches_reference_shader(built, name):
     img = gl.read_pixels(wrapper.RTX_RGBA32F)
     gl.stop()
     _check(name, img, ref)
+
+
+def test_default_scene_with_the_reference_asset_files(built):
+    """Build container only, end to end on the reference's own inputs: its five texture files and six sky-box faces
+    (JPEG + PNG), decoded by the shim's readers (include/rtx/jpeg_decode.h, png_decode.h -- byte-identical to the
+    reference's stb_image, tests/test_jpeg_decode.py), go to (a) the reference's fragment shader on llvmpipe and (b) the
+    oracle. Same limits as the procedurally textured 'default' case: what differs is llvmpipe's mip rounding / LOD / atan
+    on textured pixels and the silhouettes."""
+    import ctypes
+    from oracle import oracle
+    from oracle.ref_gl import ref_gl
+    from raytracing_opengl_amd import scenes, textures
+    tex_dir = "/root/reference/assets/textures"
+    if not ref_gl.available() or not os.path.isdir(tex_dir):
+        pytest.skip("needs /root/reference and Mesa llvmpipe (build container only)")
+    os.environ.setdefault("GALLIVM_PERF", "no_aos_sampling,no_quad_lod")
+    lib = scenes._host_lib()
+    lib.rtxh_decode_image.restype = ctypes.c_size_t
+    lib.rtxh_decode_image.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                      ctypes.c_void_p, ctypes.c_size_t]
+
+    def decode(path):
+        w, h, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        need = lib.rtxh_decode_image(path.encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(c), None, 0)
+        assert need, path
+        out = np.empty(need, np.uint8)
+        lib.rtxh_decode_image(path.encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(c), out.ctypes.data, need)
+        return out.reshape(h.value, w.value, c.value)
+    tex = []
+    for (name, uniform, unit, w, h, c) in textures.REFERENCE_TEXTURES:      # main.cpp:149-153
+        img = decode(os.path.join(tex_dir, name))
+        assert img.shape == (h, w, c), (name, img.shape)
+        tex.append((uniform, unit, img))
+    faces = [decode(os.path.join(tex_dir, "sb_nebula", f"GalaxyTex_{s}{a}.jpg")) for a in "XYZ" for s in ("Positive", "Negative")]  # main.cpp:137-145
+    assert all(f.shape == (textures.CUBEMAP_FACE, textures.CUBEMAP_FACE, 3) for f in faces)
+    w, h = rf.W, rf.H
+    sc = scenes.build_scene("default", w, h, 4)
+    ref, missing = ref_gl.render(sc, w, h, tex, faces)
+    assert not missing
+    img, _ = oracle.OracleScene(sc, w, h, tex, faces, texture_lod=1).render()
+    f4, f2, _mx = rf.compare(img, ref[..., :3])
+    lim4, lim2 = rf.CASES["default"][2]
+    assert f4 <= lim4 and f2 <= lim2, (f4, f2)
