@@ -749,8 +749,16 @@ RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
     const float t_in = (-b - sqrtf(gl_max(h + err, 0.0f))) / a;   // earliest possible entry (a ~ 1)
     return t_in > tlimit * 1.001f + 0.01f + 1e-5f * sqrtf(d2);
 }
+// The premise above holds for UNIT directions only. The shader's Durand-Kerner update divides by the product of root
+// differences but not by the quartic's leading coefficient dot(rd,rd)^2, so for a direction of length L its steps are L^4
+// times too long: for L^4 >= 2 the iteration does not converge at all, runs out of its 60 sweeps and reports whatever
+// iterate happens to have a small imaginary part -- also for rays that miss the torus by a wide margin (found by the
+// degenerate-scene fuzz: a ray refracted with a non-unit normal, |rd| = 1.29, going away from a torus 2 units to its side,
+// "hit" it at t = 1.18). Such directions are never culled: the solver has to run to reproduce its own garbage.
+RT_HD bool unit_direction(float dd) { return fabsf(dd - 1.0f) <= 1e-3f; }   // false for NaN
 RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd, float tlimit)
 {
+    if (!unit_direction(dot3_fma(rd, rd))) return false;
     return sphere_cull(xyz(bound), bound.w, ro, rd, gl_min(tlimit, 100.0f));
 }
 // A ring hit lies within sqrt(r2) of the ring centre (p < r2, rt.frag:384) and needs 0 < t < tmin;
@@ -768,7 +776,7 @@ RT_HD bool ring_cull(f4 bound, f3 ro, f3 rd, float tlimit)
 RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
 {
     const float dd = dot3(d, d);
-    if (!(dd > 0.25f && dd < 4.0f)) return false;  // degenerate direction: never cull
+    if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
     float t0 = 0.0f, t1 = gl_min(tlimit, 100.0f) * 1.001f + 0.01f;
     // slab |z| <= hz
     const float hz = T.cull.x;

@@ -58,10 +58,20 @@ def _axis_rays(rng, centre, extent, n):
         yield ro.astype(np.float32), rd.astype(np.float32), tmin
 
 
+def _scaled_rays(rng, centre, extent, n):
+    """Non-unit directions (what refract() returns for a non-unit normal, or a rotation by a non-unit quaternion). For a
+    torus the shader's Durand-Kerner update is only right for unit directions: with |rd|^4 >= 2 it does not converge and
+    reports garbage roots for rays that miss -- a ray with |rd| = 1.29 going AWAY from a torus "hit" it at t = 1.18 in the
+    degenerate-scene fuzz, and the bounding-sphere cull had skipped it. Torus culls now stand aside for such rays."""
+    for ro, rd, tmin in _rays(rng, centre, extent, n):
+        yield ro, (rd * np.float32(rng.choice([0.3, 0.7, 0.9, 0.99, 1.01, 1.1, 1.2, 1.29, 1.5, 2.0, 3.0]))).astype(np.float32), tmin
+
+
 def _check(type_, record, rng, centre, extent, n):
     culled = hits = 0
     import itertools
-    for ro, rd, tmin in itertools.chain(_rays(rng, centre, extent, n), _axis_rays(rng, centre, extent, max(50, n // 4))):
+    for ro, rd, tmin in itertools.chain(_rays(rng, centre, extent, n), _axis_rays(rng, centre, extent, max(50, n // 4)),
+                                        _scaled_rays(rng, centre, extent, max(50, n // 2))):
         ohit, ot, _ = _isect(type_, record, ro, rd, tmin)
         dhit, dt, dcull = harness.kat(type_, record, ro, rd, tmin)
         assert dhit == ohit, (ro, rd, tmin)
@@ -85,6 +95,35 @@ def test_torus_cull_and_solver(built):
         total_c += c
         total_h += h
     assert total_c > 200 and total_h > 100
+
+
+def test_torus_culls_stand_aside_for_non_unit_directions(built):
+    """Structural half of the non-unit-direction finding (see _scaled_rays): no torus cull may fire when |rd|^2 is not 1
+    within 1e-3, because the reference's solver result is then not a function of the geometry. Also shows the phenomenon
+    itself: among rays whose LINE misses the torus' bounding sphere the reference still reports hits."""
+    rng = np.random.default_rng(77)
+    pos = np.array([-2.0, -1.0, 3.0])
+    R, r = 1.0, 0.25
+    rec = _mat() + struct.pack("<4f", 0, 0, 1, 6.123234e-17) + struct.pack("<3f f 2f 2f", *pos, 0, R, r, 0, 0)
+    for ro, rd, tmin in _scaled_rays(rng, pos, R + r, 3000):
+        ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, ro, rd, tmin)
+        dhit, dt, dcull = harness.kat(oracle.TYPE_TORUS, rec, ro, rd, tmin)
+        assert not dcull, (ro, rd)
+        assert dhit == ohit and (not ohit or dt == ot), (ro, rd, tmin)
+    # the four rays of the finding (nasty_scene seed 201072, 323x181): they leave the lattice point (0,-1,4) downwards,
+    # 2 units to the side of the torus, and the reference's solver -- out of sweeps -- reports a root all the same
+    found = [((-0.00100000005, -1.00100005, 3.99900007), (0.0736296177, 0.0736296177, -1.28851676), 1.25501573, 1.18431139),
+             ((-0.00100000005, -0.999000013, 3.99900007), (0.0736296177, -0.0736296177, -1.28851676), 1.25501573, 1.18431139),
+             ((0.0, -1.00100005, 3.99900007), (0.364633799, -0.170804322, -1.12673616), 1.43732691, 0.475216985),
+             ((0.0, -0.999000013, 3.99900007), (0.364633799, 0.170804322, -1.12673616), 1.43732691, 0.475216985)]
+    for ro, rd, tmin, t in found:
+        ro, rd = np.asarray(ro, np.float32), np.asarray(rd, np.float32)
+        oc = ro.astype(np.float64) - pos
+        d = rd.astype(np.float64) / np.linalg.norm(rd)
+        assert np.dot(oc, oc) - np.dot(oc, d) ** 2 > (R + r) ** 2 * 1.5       # the line passes far outside the bounding sphere
+        ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, ro, rd, tmin)
+        dhit, dt, dcull = harness.kat(oracle.TYPE_TORUS, rec, ro, rd, tmin)
+        assert ohit and abs(ot - t) < 1e-6 and dhit and dt == ot and not dcull
 
 
 def test_ring_cull(built):
