@@ -23,7 +23,7 @@ def main(out_dir, log):
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     cases, cur = [], None
     for d in disp.values():
-        if "<true, true, false>" in d["name"]:
+        if "<true, true, false" in d["name"]:
             cur = []
             cases.append(cur)
         elif cur is not None:
