@@ -109,6 +109,7 @@ RTX_API int rtx_get_size(rtx_context* ctx, int* width, int* height); /* getWidth
  * Fixes array sizes, bounce depth and the two colour constants. The two colours take the same
  * "%f" text round trip as the reference's shader templating (GLWrapper.cpp:246-247,279-282).
  * Must precede block/texture calls, like the reference (names are looked up in the program). */
+#define RTX_MAX_ITERATIONS 256 /* larger bounce depths are refused with RTX_ERR_INVALID (the per-pixel trip bound) */
 RTX_API int rtx_specialize(rtx_context* ctx, const rtx_defines* defines);
 
 /* GLWrapper::init_buffer(ubo,name,bindingPoint,size,data)  [GLWrapper.cpp:365-379]
@@ -134,7 +135,8 @@ RTX_API int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels,
  * texture_sphere_1..4, texture_ring, texture_box (rt.frag:136-143). */
 RTX_API int rtx_sampler_unit(rtx_context* ctx, const char* sampler_name, int unit);
 /* glActiveTexture(GL_TEXTURE0+unit); glBindTexture(target, handle)  [main.cpp:178-187,
- * GLWrapper.cpp:139-140]. */
+ * GLWrapper.cpp:139-140]. The target is the texture's own kind; handle 0 clears both the 2-D and
+ * the cube binding of the unit. */
 RTX_API int rtx_bind_texture(rtx_context* ctx, int unit, uint32_t handle);
 RTX_API int rtx_texture_destroy(rtx_context* ctx, uint32_t handle);
 

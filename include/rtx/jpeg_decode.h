@@ -207,6 +207,12 @@ private:
             if (c.h > hmax) hmax = c.h;
             if (c.v > vmax) vmax = c.v;
         }
+        // every component's sampling factors must divide the maxima: the up-sampler works with the integer ratios hmax/h,
+        // vmax/v, and e.g. H = (3,2,1) would make it read `width` samples from plane rows that are narrower than that.
+        // (stb_image v2.25, the reference's decoder, accepts such frames and does read across the row ends; there is no
+        // defined output to reproduce, so this reader refuses them, as later stb_image releases do.)
+        for (int i = 0; i < ncomp; ++i)
+            if (hmax % comp[i].h != 0 || vmax % comp[i].v != 0) return false;
         mcus_x = (width + 8 * hmax - 1) / (8 * hmax);
         mcus_y = (height + 8 * vmax - 1) / (8 * vmax);
         for (int i = 0; i < ncomp; ++i) {

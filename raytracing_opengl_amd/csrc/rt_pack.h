@@ -329,7 +329,15 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         // the nasty-scene fuzz. Such tori (tube thinner than 2 % of the major radius, or any non-positive / non-finite
         // radius) get infinite bounds: never culled, the solver decides like in the reference.
         const bool real_tube = std::isfinite(R) && std::isfinite(r) && R > 0.0f && r > 0.02f * R;
-        if (!real_tube) {
+        // rotate() (rt.frag:306-311) multiplies by q and conj(q), not by the inverse: a quaternion of squared norm n2 also
+        // SCALES the ray by n2, so in world space the torus is 1/n2 times as large as its radii say and, worse, the
+        // direction the solver sees is not a unit vector (its roots are then not geometric, rt_device.h unit_direction).
+        // Bounds are only valid for unit quaternions; any other torus is never culled. (The fuzzers used to draw unit
+        // quaternions only; q = (0,0,0,0.9) changed 540 pixels of a 96x64 frame between culls on and off.)
+        const double qn2 = static_cast<double>(s.quat.x) * s.quat.x + static_cast<double>(s.quat.y) * s.quat.y +
+                           static_cast<double>(s.quat.z) * s.quat.z + static_cast<double>(s.quat.w) * s.quat.w;
+        const bool unit_quat = std::fabs(qn2 - 1.0) <= 1e-4;   // false for NaN; 1e-4 is far inside the 1 % inflation
+        if (!real_tube || !unit_quat) {
             const float inf = std::numeric_limits<float>::infinity();
             s.k.y = inf; s.k.z = inf; s.k.w = 0.0f;
             s.cull.x = inf;
@@ -345,7 +353,12 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.quat = rd4(p, 64);
         s.pos_tex = rd3(p, 80, int_bits(rdi(p, 92)));
         const float r1 = rdf(p, 96), r2 = rdf(p, 100);
-        const double ring_rb = std::sqrt(static_cast<double>(r2)) * 1.001 + 0.01;  // NaN for a negative r2: never culled
+        // rotate() scales by the quaternion's squared norm n2 (see the torus above): a local squared radius r2 is a world
+        // radius sqrt(r2)/n2. NaN for a negative r2 or a zero / non-finite quaternion: never culled.
+        const double ring_qn2 = static_cast<double>(s.quat.x) * s.quat.x + static_cast<double>(s.quat.y) * s.quat.y +
+                                static_cast<double>(s.quat.z) * s.quat.z + static_cast<double>(s.quat.w) * s.quat.w;
+        double ring_rb = std::sqrt(static_cast<double>(r2)) / ring_qn2 * 1.001 + 0.01;
+        if (!(ring_qn2 > 1e-12) || !std::isfinite(ring_qn2) || !std::isfinite(ring_rb) || ring_rb > 1e15) ring_rb = std::numeric_limits<double>::quiet_NaN();
         s.radii = mk4(r1, r2, r2 - r1, static_cast<float>(ring_rb * ring_rb));
         const f3 nrm = quat_rotate(quat_inv(s.quat), mk3(0.0f, 0.0f, -1.0f));
         s.normal = mk4(nrm.x, nrm.y, nrm.z, int_bits(quat_is_identity(s.quat) ? 1 : 0));

@@ -79,6 +79,11 @@ struct rtx_context {
     char* d_scene = nullptr;
     size_t d_scene_cap = 0;
     int scene_bytes = 0;
+    // cross-stream ordering of the single device scene (rtx_draw_bands may bring its own stream): the stream of the last
+    // upload / launch and an event after the last launch; a draw on another stream waits for both (upload_scene, draw_impl)
+    hipStream_t upload_stream = nullptr, launch_stream = nullptr;
+    int last_stage = -1;
+    hipEvent_t launch_done = nullptr;
     // textures
     std::map<uint32_t, Texture> textures;
     uint32_t next_handle = 1;
@@ -145,12 +150,16 @@ int upload_scene(rtx_context* ctx, hipStream_t stream)
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_scene), cap));
         ctx->d_scene_cap = cap;
     }
+    // the device scene is about to be overwritten: a kernel still reading it on ANOTHER stream has to finish first
+    if (ctx->launch_stream && ctx->launch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->launch_done, 0));
     const int k = ctx->stage_next;
     ctx->stage_next ^= 1;
     HIP_TRY(hipEventSynchronize(ctx->stage_done[k]));  // staging buffer k is free again
     std::memcpy(ctx->h_stage[k], ctx->blob.data(), n);
     HIP_TRY(hipMemcpyAsync(ctx->d_scene, ctx->h_stage[k], n, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(ctx->stage_done[k], stream));
+    ctx->upload_stream = stream;
+    ctx->last_stage = k;
     ctx->scene_bytes = static_cast<int>(n);
     ctx->scene_dirty = false;
     return RTX_OK;
@@ -249,6 +258,9 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
         st = upload_scene(ctx, stream);  // same stream as the launch: ordered before it, and after earlier draws on it
         if (st) return st;
     }
+    else if (ctx->last_stage >= 0 && ctx->upload_stream != stream) {
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->stage_done[ctx->last_stage], 0));  // the scene was uploaded on another stream
+    }
     const int n_bands_total = (ctx->height + band_rows - 1) / band_rows;
     int rows_local = 0;
     for (int b = band_first; b < n_bands_total; b += band_stride) {
@@ -286,6 +298,8 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     const bool high_occ = ctx->opt_occ < 0 ? n_prims >= 32 : ctx->opt_occ != 0;
     HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream));
     HIP_TRY(hipEventRecord(ctx->ev_stop[e], stream));
+    HIP_TRY(hipEventRecord(ctx->launch_done, stream));
+    ctx->launch_stream = stream;
     ctx->ev_head = (ctx->ev_head + 1) % EVENT_RING;
     ctx->ev_pending++;
     ctx->launches++;
@@ -328,6 +342,7 @@ int rtx_create(int width, int height, int device, rtx_context** out)
     if ((e = hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
     for (int k = 0; k < 2; k++)
         if ((e = hipEventCreateWithFlags(&ctx->stage_done[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&ctx->launch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     for (int k = 0; k < EVENT_RING; k++) {
         if ((e = hipEventCreate(&ctx->ev_start[k])) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&ctx->ev_stop[k])) != hipSuccess) return bail(e, "hipEventCreate");
@@ -352,6 +367,7 @@ void rtx_destroy(rtx_context* ctx)
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
     }
+    if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
     if (ctx->d_fb_f32) (void)hipFree(ctx->d_fb_f32);
     if (ctx->d_fb_u8) (void)hipFree(ctx->d_fb_u8);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -393,6 +409,11 @@ int rtx_specialize(rtx_context* ctx, const rtx_defines* d)
     const int32_t* c = &d->sphere_size;
     for (int k = 0; k < 9; k++)
         if (c[k] < 0 || c[k] > (1 << 20)) return fail(RTX_ERR_INVALID, "rtx_specialize: count %d out of range", k);
+    // The trace loop is bounded by RT_SEGMENT_CAP main-loop trips per pixel (refraction does i--, so the shader's own loop has
+    // no bound: trap T2) and keeps i in 16 bits: a bounce depth beyond the cap could not be honoured and is refused rather
+    // than silently truncated. (The reference's default is 5, SceneManager.cpp:233.)
+    if (d->iterations > RTX_MAX_ITERATIONS) return fail(RTX_ERR_INVALID, "rtx_specialize: %d iterations exceed the supported maximum of %d", d->iterations, RTX_MAX_ITERATIONS);
+    static_assert(RTX_MAX_ITERATIONS == RT_SEGMENT_CAP, "rtx.h documents the kernel's segment cap");
     std::memcpy(&ctx->defines, d, sizeof *d);
     ctx->specialized = true;
     ctx->scene_dirty = true;
@@ -489,7 +510,7 @@ int rtx_bind_texture(rtx_context* ctx, int unit, uint32_t handle)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "rtx_bind_texture: no current context");
     if (unit < 0 || unit >= UNIT_COUNT) return fail(RTX_ERR_INVALID, "texture unit %d out of range", unit);
-    if (handle == 0) { ctx->unit_texture_2d[unit] = 0; return RTX_OK; }  // glBindTexture(target, 0)
+    if (handle == 0) { ctx->unit_texture_2d[unit] = 0; ctx->unit_texture_cube[unit] = 0; return RTX_OK; }  // glBindTexture(target, 0): there is no target argument here, so both bindings of the unit are cleared
     auto it = ctx->textures.find(handle);
     if (it == ctx->textures.end()) return fail(RTX_ERR_HANDLE, "unknown texture handle %u", handle);
     if (it->second.cube) ctx->unit_texture_cube[unit] = handle;

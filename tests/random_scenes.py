@@ -101,3 +101,33 @@ def nasty_scene(seed: int, w: int, h: int):
     cam_quat = (0.0, 0.0, 0.0, 1.0) if rng.random() < 0.6 else quat_euler(0.0, float(rng.choice([0.0, math.pi / 2, math.pi, 0.3])), 0.0)
     return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, rings=rings,
                       lights_point=lights_point, lights_direct=lights_direct, cam_pos=cam, cam_quat=cam_quat)
+
+
+# byte offset of quat_rotation inside each record (include/rtx/scene.h) and the record size
+_QUAT_AT = {"spheres_buf": (80, 112), "surfaces_buf": (64, 160), "boxes_buf": (64, 112), "toruses_buf": (64, 112), "rings_buf": (64, 112)}
+
+
+def scaled_quat_scene(seed: int, w: int, h: int):
+    """random_scene(seed) with about half of its rotation quaternions (and sometimes the camera's) scaled to a norm other
+    than 1. rt.frag's rotate() is q v conj(q) (rt.frag:306-311), so such a quaternion also scales the primitive's local
+    frame by |q|^2: spheres keep their shape (only their texture lookup rotates), boxes / tori / rings / quadrics change
+    size in world space and see non-unit ray directions. Nothing in the reference normalises the field, so the result is
+    defined and has to be reproduced (advisor finding, round 1: cull bounds had assumed unit quaternions)."""
+    import struct
+    sc = random_scene(seed, w, h)
+    rng = np.random.default_rng(seed ^ 0x9a7)
+    blocks = dict(sc.blocks)
+    for name, (off, size) in _QUAT_AT.items():
+        buf = bytearray(blocks[name])
+        for i in range(len(buf) // size):
+            if rng.random() < 0.5:
+                k = float(rng.choice([0.6, 0.8, 0.9, 0.97, 0.9995, 1.0005, 1.05, 1.2, 1.5]))
+                q = [np.float32(v) * np.float32(k) for v in struct.unpack_from("<4f", buf, i * size + off)]
+                struct.pack_into("<4f", buf, i * size + off, *q)
+        blocks[name] = bytes(buf)
+    if rng.random() < 0.25:
+        buf = bytearray(blocks["scene_buf"])
+        q = [np.float32(v) * np.float32(rng.choice([0.8, 1.25])) for v in struct.unpack_from("<4f", buf, 0)]
+        struct.pack_into("<4f", buf, 0, *q)
+        blocks["scene_buf"] = bytes(buf)
+    return type(sc)(defines=sc.defines, blocks=blocks)

@@ -22,6 +22,18 @@ def _rand_quat(rng):
     return struct.pack("<4f", *q)
 
 
+def _scaled_quat(rng):
+    """Non-unit quaternion: rt.frag's rotate() (q v conj(q), rt.frag:306-311) then also scales by |q|^2, so the primitive is
+    1/|q|^2 times as large in world space as its radii say (advisor finding, round 1: bounds assumed unit quaternions and
+    q = (0,0,0,0.9) changed 540 pixels between culls on and off)."""
+    q = rng.normal(size=4)
+    q *= float(rng.choice([0.5, 0.7, 0.9, 0.97, 0.999, 1.001, 1.03, 1.1, 1.4, 2.0])) / np.linalg.norm(q)
+    if rng.random() < 0.3:
+        q = np.array([0.0, 0.0, 0.0, q[3] if q[3] != 0 else 0.9])
+        q = q / abs(q[3]) * float(rng.choice([0.7, 0.9, 1.1]))
+    return struct.pack("<4f", *q)
+
+
 def _rays(rng, centre, extent, n):
     """Rays aimed near the primitive from a wide range of distances, plus some that miss widely."""
     for _ in range(n):
@@ -124,6 +136,23 @@ def test_torus_culls_stand_aside_for_non_unit_directions(built):
         ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, ro, rd, tmin)
         dhit, dt, dcull = harness.kat(oracle.TYPE_TORUS, rec, ro, rd, tmin)
         assert ohit and abs(ot - t) < 1e-6 and dhit and dt == ot and not dcull
+
+
+def test_culls_with_non_unit_quaternions(built):
+    """Torus and ring bounds for quaternions of norm != 1 (see _scaled_quat): a cull may never skip a ray the oracle hits."""
+    rng = np.random.default_rng(21)
+    hits = 0
+    for _ in range(16):
+        R, r = rng.uniform(0.5, 3.0), rng.uniform(0.1, 0.9)
+        pos = rng.uniform(-20, 20, 3)
+        q = _scaled_quat(rng)
+        n2 = float(np.sum(np.square(struct.unpack("<4f", q))))
+        rec = _mat() + q + struct.pack("<3f f 2f 2f", *pos, 0, R, r, 0, 0)
+        hits += _check(oracle.TYPE_TORUS, rec, rng, pos, (R + r) / n2, 120)[1]
+        r_in, r_out = sorted(rng.uniform(0.5, 20.0, 2))
+        rec = _mat() + q + struct.pack("<3fi2f2f", *pos, 4, r_in ** 2, r_out ** 2, 0, 0)
+        hits += _check(oracle.TYPE_RING, rec, rng, pos, r_out / n2, 120)[1]
+    assert hits > 300
 
 
 def test_ring_cull(built):

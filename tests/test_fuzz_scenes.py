@@ -71,3 +71,16 @@ def test_random_scene_on_gpu(built, small_textures, seed):
     assert not (np.isnan(img) ^ np.isnan(ref)).any(), seed
     assert np.nanmax(d) <= 1e-4, (seed, float(np.nanmax(d)))
     assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"], seed
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_scaled_quaternion_scene_bit_exact_on_host(built, small_textures, seed):
+    """Rotation quaternions of norm != 1 (tests/random_scenes.py::scaled_quat_scene): culls on == culls off == oracle."""
+    W, H = [(112, 64), (113, 65)][seed % 2]
+    sc = random_scenes.scaled_quat_scene(seed, W, H)
+    ref, cnt = oracle.OracleScene(sc, W, H, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
+    for cull in (True, False):
+        img, hc = harness.render(sc, W, H, small_textures["textures"], small_textures["cubemap"], cull=cull)
+        same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), (seed, cull, int((~same).sum()))
+        assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)

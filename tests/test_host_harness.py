@@ -46,3 +46,28 @@ def test_unbound_samplers_and_missing_faces(built, small_textures):
     ref, _ = oracle.OracleScene(sc, 160, 90, tex, faces, texture_lod=0).render()
     img, _ = harness.render(sc, 160, 90, tex, faces, cull=True)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+def test_percent_f_round_trip_is_applied(built, small_textures):
+    """T9 on the product side (GLWrapper.cpp:246-247,279-282: the two colour constants go through std::to_string = "%f"):
+    with colours that the 6-decimal text CHANGES (0.1234567 -> 0.123457, 1e-7 -> 0, 0.0999999 -> 0.100000) the packer's frame
+    must equal the oracle's bit for bit, and must equal the frame of the pre-rounded colours -- i.e. the digits beyond the
+    sixth decimal cannot reach a pixel."""
+    import ctypes
+    import dataclasses
+    w, h = 160, 90
+    sc = scenes.build_scene("default", w, h, 3)
+    raw = (0.1234567, 0.05000004, 1e-7, 0.3333333, 0.0999999, 0.2500001)
+    rt = oracle.lib().orc_kat_text_round_trip
+    pre = tuple(float(rt(ctypes.c_float(v))) for v in raw)
+    assert [np.float32(a) != np.float32(b) for a, b in zip(raw, pre)].count(True) >= 5
+    frames = []
+    for cols in (raw, pre):
+        s2 = dataclasses.replace(sc, defines=tuple(sc.defines[:9]) + cols)
+        ref, _ = oracle.OracleScene(s2, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
+        img, _ = harness.render(s2, w, h, small_textures["textures"], small_textures["cubemap"], cull=True)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+        frames.append(img)
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    plain, _ = harness.render(sc, w, h, small_textures["textures"], small_textures["cubemap"], cull=True)
+    assert not np.array_equal(plain.view(np.uint32), frames[0].view(np.uint32))

@@ -93,6 +93,23 @@ def test_bad_files_are_rejected_not_crashed(built, tmp_path, damage):
     assert got is None
 
 
+@pytest.mark.parametrize("factors", [(0x32, 0x21, 0x11), (0x23, 0x12, 0x11), (0x31, 0x21, 0x11), (0x41, 0x31, 0x11), (0x14, 0x13, 0x11)])
+def test_sampling_factors_that_do_not_divide_the_maximum_are_refused(built, tmp_path, factors):
+    """SOF with H or V factors that do not divide hmax / vmax, e.g. H = (3,2,1): accepting them made the up-sampler read past the end of the narrower plane rows (advisor finding, round 1:
+    heap-buffer-overflow under ASan with this very file patched to (3,2,1))."""
+    data = bytearray(open(os.path.join(GOLD, "pil_RGB_420_48x32_base_q35_r0.jpg"), "rb").read())
+    sof = data.index(b"\xff\xc0")
+    assert data[sof + 9] == 3                      # three components: id, HV, Tq each from sof + 10
+    for i, hv in enumerate(factors):
+        data[sof + 11 + 3 * i] = hv
+    p = tmp_path / "badhv.jpg"
+    p.write_bytes(bytes(data))
+    # A deliberate divergence from the reference's stb_image v2.25, which only checks 1 <= H,V <= 4 (stb_image.h:3193-3194),
+    # accepts these files and up-samples `width` samples out of plane rows that are narrower than that -- it reads across
+    # row ends (past the buffer on the last rows) and returns garbage. Later stb_image releases refuse such files; so do we.
+    assert _decode(p) is None
+
+
 def _stb():
     if not os.path.exists(STBREF):
         pytest.skip("oracle/_ref/libstbref.so not built (needs the reference checkout)")
