@@ -84,3 +84,61 @@ def test_scaled_quaternion_scene_bit_exact_on_host(built, small_textures, seed):
         same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
         assert same.all(), (seed, cull, int((~same).sum()))
         assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_scaled_quaternion_scene_on_gpu(built, small_textures, seed):
+    from raytracing_opengl_amd import wrapper
+    w, h = [(160, 96), (161, 97)][seed % 2]
+    sc = random_scenes.scaled_quat_scene(seed, w, h)
+    ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=1).render()
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    gl.draw()
+    img = gl.read_pixels()
+    st = gl.stats()
+    gl.stop()
+    fin = np.isfinite(img) & np.isfinite(ref)
+    assert (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all(), seed
+    assert float(np.abs(np.where(fin, img - ref, 0.0)).max()) <= 1e-4, seed
+    assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"], seed
+
+
+SWEEP = 500   # seeds per generator in the -m gpu suite (milliseconds each; tools/fuzz_gpu.py runs the 10^4-scale sweeps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gen", ["random_scene", "nasty_scene", "scaled_quat_scene"])
+def test_fuzz_sweep_on_gpu(built, small_textures, gen):
+    """500 seeds of each generator through ONE context per frame size (re-specialised per scene, as a program that swaps scenes
+    would): culls on (the product path) against the un-culled oracle -- max 1e-4, NaN/inf in the same places, identical ray counts."""
+    from raytracing_opengl_amd import wrapper
+    make = getattr(random_scenes, gen)
+    sizes = [(96, 64), (97, 65)]
+    ctx = {}
+    bad = []
+    for seed in range(20000, 20000 + SWEEP):
+        w, h = sizes[seed % 2]
+        sc = make(seed, w, h)
+        ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=1).render()
+        gl = ctx.get((w, h))
+        if gl is None:
+            gl = ctx[(w, h)] = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+            gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+        else:
+            gl.init_shaders(sc.defines)
+            gl.uploader = wrapper.SceneUploader(sc, gl)
+            gl.uploader.init()
+        gl.draw()
+        img = gl.read_pixels()
+        st = gl.stats()
+        fin = np.isfinite(img) & np.isfinite(ref)
+        ok = (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all()
+        ok = ok and float(np.abs(np.where(fin, img - ref, 0.0)).max()) <= 1e-4
+        ok = ok and st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
+        if not ok:
+            bad.append(seed)
+    for gl in ctx.values():
+        gl.stop()
+    assert not bad, f"{gen}: {len(bad)} of {SWEEP} scenes differ from the oracle, seeds {bad[:20]}"
