@@ -58,8 +58,8 @@ class Counters(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with oracle/Makefile (gcc, -ffp-contract=off)."""
-    src = os.path.join(_HERE, "rt_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("rt_oracle.c", "smaa_oracle.c"))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

@@ -323,3 +323,100 @@ int glref_render(const char* vert_src, const char* frag_src, int w, int h, int n
     if (e != GL_NO_ERROR) FAIL("GL error 0x%x", e);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * one generic full-screen pass: the reference's post-process (SMAA) programs
+ * ----------------------------------------------------------------------------------------------------------
+ * What GLWrapper::draw does three times after the tracer (GLWrapper.cpp:173-204): bind a program, bind its input
+ * textures (all 2-D, GL_LINEAR, CLAMP_TO_EDGE: gen_framebuffer GLWrapper.cpp:209-230 and SMAA_Builder.h:52-83), clear the
+ * target to 0 and draw the full-screen quad (GLWrapper.cpp:101-122: position + texture coordinate attributes).
+ * Inputs and the target are 8-bit UNORM like the reference's: channels 1 -> GL_R8, 2 -> GL_RG8, 4 -> GL_RGBA8. */
+typedef struct glref_pass_tex {
+    const char* uniform_name;
+    int unit;
+    int width, height, channels;   /* 1, 2 or 4 */
+    const unsigned char* texels;   /* tightly packed, row 0 = t 0 */
+} glref_pass_tex;
+
+int glref_pass(const char* vert_src, const char* frag_src, int w, int h, int n_tex, const glref_pass_tex* tex, int out_channels,
+               unsigned char* out)
+{
+    if (!g_ctx) FAIL("glref_init first");
+    char log[3000] = "";
+    GLuint vs = compile(GL_VERTEX_SHADER, vert_src, log, sizeof log);
+    if (!vs) FAIL("vertex shader: %s", log);
+    GLuint fs = compile(GL_FRAGMENT_SHADER, frag_src, log, sizeof log);
+    if (!fs) FAIL("fragment shader: %s", log);
+    GLuint prog = p_glCreateProgram();
+    p_glAttachShader(prog, vs);
+    p_glAttachShader(prog, fs);
+    p_glLinkProgram(prog);
+    GLint ok = 0;
+    p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (!ok) { p_glGetProgramInfoLog(prog, sizeof log, NULL, log); FAIL("link: %s", log); }
+    p_glUseProgram(prog);
+    if (n_tex > 8) FAIL("too many textures");
+    static const GLenum ifmt[5] = {0, GL_R8, GL_RG8, 0, GL_RGBA8}, fmt[5] = {0, GL_RED, GL_RG, 0, GL_RGBA};
+    GLuint texid[8] = {0};
+    p_glGenTextures(n_tex, texid);
+    p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+    for (int k = 0; k < n_tex; k++) {
+        const int c = tex[k].channels;
+        if (c != 1 && c != 2 && c != 4) FAIL("pass texture with %d channels", c);
+        p_glActiveTexture(GL_TEXTURE0 + tex[k].unit);
+        p_glBindTexture(GL_TEXTURE_2D, texid[k]);
+        p_glTexImage2D(GL_TEXTURE_2D, 0, (GLint)ifmt[c], tex[k].width, tex[k].height, 0, fmt[c], GL_UNSIGNED_BYTE, tex[k].texels);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+        const GLint loc = p_glGetUniformLocation(prog, tex[k].uniform_name);
+        if (loc >= 0) p_glUniform1i(loc, tex[k].unit);
+    }
+    p_glPixelStorei(GL_UNPACK_ALIGNMENT, 4);
+    if (out_channels != 2 && out_channels != 4) FAIL("pass target with %d channels", out_channels);
+    GLuint fbo = 0, color = 0, vao = 0, vbo = 0;
+    p_glActiveTexture(GL_TEXTURE0 + 15);
+    p_glGenTextures(1, &color);
+    p_glBindTexture(GL_TEXTURE_2D, color);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, (GLint)ifmt[out_channels], w, h, 0, fmt[out_channels], GL_UNSIGNED_BYTE, NULL);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+    p_glGenFramebuffers(1, &fbo);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, color, 0);
+    if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) FAIL("framebuffer incomplete");
+    p_glBindTexture(GL_TEXTURE_2D, 0);
+    static const float quad[] = {-1, -1, 0, 0, 1, -1, 1, 0, 1, 1, 1, 1, -1, -1, 0, 0, 1, 1, 1, 1, -1, 1, 0, 1};
+    p_glGenVertexArrays(1, &vao);
+    p_glGenBuffers(1, &vbo);
+    p_glBindVertexArray(vao);
+    p_glBindBuffer(GL_ARRAY_BUFFER, vbo);
+    p_glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
+    p_glEnableVertexAttribArray(0);
+    p_glVertexAttribPointer(0, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void*)0);
+    p_glEnableVertexAttribArray(1);
+    p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void*)(2 * sizeof(float)));
+    p_glViewport(0, 0, w, h);
+    p_glDisable(GL_DEPTH_TEST);
+    p_glDisable(GL_BLEND);
+    p_glClearColor(0, 0, 0, 0);
+    p_glClear(GL_COLOR_BUFFER_BIT);
+    p_glDrawArrays(GL_TRIANGLES, 0, 6);
+    p_glFinish();
+    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glReadPixels(0, 0, w, h, fmt[out_channels], GL_UNSIGNED_BYTE, out);
+    const GLenum e = p_glGetError();
+    p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+    p_glBindVertexArray(0);
+    p_glDeleteFramebuffers(1, &fbo);
+    p_glDeleteTextures(1, &color);
+    p_glDeleteTextures(n_tex, texid);
+    p_glDeleteBuffers(1, &vbo);
+    p_glUseProgram(0);
+    p_glDeleteProgram(prog);
+    p_glDeleteShader(vs);
+    p_glDeleteShader(fs);
+    if (e != GL_NO_ERROR) FAIL("GL error 0x%x", e);
+    return 0;
+}
