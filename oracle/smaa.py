@@ -58,7 +58,7 @@ def blend_pass(edges_rg8: np.ndarray, preset, area, search) -> np.ndarray:
     return out
 
 
-def blend_pass_jitter(edges_rg8: np.ndarray, preset, area, search, jx: float, jy: float) -> np.ndarray:
+def blend_pass_jitter(edges_rg8: np.ndarray, preset, area, search, jx: float, jy: float, slack_lo: float = 0.0, slack_hi: float = 0.0) -> np.ndarray:
     """Diagnostic: pass 2 with every pixel's position displaced by (jx, jy) texels (see smaa_oracle.c)."""
     edges = np.ascontiguousarray(edges_rg8, np.uint8)
     h, w = edges.shape[:2]
@@ -66,8 +66,8 @@ def blend_pass_jitter(edges_rg8: np.ndarray, preset, area, search, jx: float, jy
     out = np.empty((h, w, 4), np.uint8)
     l = _lib()
     l.smaa_oracle_blend_pass_jitter.restype = ctypes.c_int
-    l.smaa_oracle_blend_pass_jitter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
-    if l.smaa_oracle_blend_pass_jitter(edges.ctypes.data, w, h, _preset(preset), area.ctypes.data, search.ctypes.data, jx, jy, out.ctypes.data) != 0:
+    l.smaa_oracle_blend_pass_jitter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    if l.smaa_oracle_blend_pass_jitter(edges.ctypes.data, w, h, _preset(preset), area.ctypes.data, search.ctypes.data, jx, jy, slack_lo, slack_hi, out.ctypes.data) != 0:
         raise RuntimeError("smaa_oracle_blend_pass_jitter failed")
     return out
 

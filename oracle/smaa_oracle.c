@@ -347,14 +347,18 @@ static void corner_v(const blend_ctx* C, v2* weights, float ax, float ay, float 
 }
 
 /* SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) with the varyings of ...VS (SMAA.h:656-668) */
-static void blend_pixel_at(const blend_ctx* C, float X, float Y, uint8_t out[4])
+static void blend_pixel_at(const blend_ctx* C, float X, float Y, float slack_lo, float slack_hi, uint8_t out[4])
 {
     const float S = (float)C->P->max_steps;
     /* offset[0] = (X - 0.25, Y - 0.125, X + 1.25, Y - 0.125); offset[1] = (X - 0.125, Y - 0.25, X - 0.125, Y + 1.25);
      * offset[2] = rt.xxyy * ((-2, 2, -2, 2) * steps) + (offset[0].xz, offset[1].yw) */
     const float o0x = X - 0.25f, o0y = Y - 0.125f, o0z = X + 1.25f, o0w = Y - 0.125f;
     const float o1x = X - 0.125f, o1y = Y - 0.25f, o1z = X - 0.125f, o1w = Y + 1.25f;
-    const float o2x = (-2.0f * S) * 1.0f + o0x, o2y = (2.0f * S) * 1.0f + o0z, o2z = (-2.0f * S) * 1.0f + o1y, o2w = (2.0f * S) * 1.0f + o1w;
+    /* slack_lo / slack_hi (diagnostic, normally 0): offset[2] is a varying of its own; a GL implementation interpolates each of its
+     * components with noise that is independent of offset[0/1]'s, and after SMAA_MAX_SEARCH_STEPS steps `texcoord > end` compares two
+     * numbers that are equal in exact arithmetic -- one more or one fewer search step, per direction, is the implementation's choice. */
+    const float o2x = (-2.0f * S) * 1.0f + o0x - slack_lo, o2y = (2.0f * S) * 1.0f + o0z + slack_hi, o2z = (-2.0f * S) * 1.0f + o1y - slack_lo,
+                o2w = (2.0f * S) * 1.0f + o1w + slack_hi;
     v4 weights = {0.0f, 0.0f, 0.0f, 0.0f};
     const v4 es = sample(C->edges, X, Y);
     v2 e = {es.x, es.y};
@@ -406,7 +410,7 @@ static void blend_pixel_at(const blend_ctx* C, float X, float Y, uint8_t out[4])
     out[0] = to_unorm8(weights.x); out[1] = to_unorm8(weights.y); out[2] = to_unorm8(weights.z); out[3] = to_unorm8(weights.w);
 }
 
-static void blend_pixel(const blend_ctx* C, int x, int y, uint8_t out[4]) { blend_pixel_at(C, (float)x, (float)y, out); }
+static void blend_pixel(const blend_ctx* C, int x, int y, uint8_t out[4]) { blend_pixel_at(C, (float)x, (float)y, 0.0f, 0.0f, out); }
 
 /* ---- pass 3: SMAANeighborhoodBlendingPS (SMAA.h:1252-1300) -------------------------------------------------- */
 static void neighborhood_pixel(const tex_t* color, const tex_t* blend, int x, int y, uint8_t out[4])
@@ -498,13 +502,13 @@ int smaa_oracle_neighborhood_pass(const uint8_t* color, const uint8_t* blend, in
  * bilinear fetch against exactly 0 (SMAA.h:1155,1205: e.g > 0.0, e.r > 0.0) that noise decides. A pixel whose result changes
  * under such a displacement is one where the reference's own output is implementation-defined. */
 int smaa_oracle_blend_pass_jitter(const uint8_t* edges, int w, int h, int preset, const uint8_t* area_tex, const uint8_t* search_tex, float jx,
-                                  float jy, uint8_t* blend_out)
+                                  float jy, float slack_lo, float slack_hi, uint8_t* blend_out)
 {
     if (!edges || !area_tex || !search_tex || !blend_out || w <= 0 || h <= 0 || preset < 0 || preset > 3) return -1;
     const tex_t te = {w, h, 2, edges}, ta = {160, 560, 2, area_tex}, ts = {64, 16, 1, search_tex};
     const blend_ctx C = {&te, &ta, &ts, &k_presets[preset]};
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) blend_pixel_at(&C, (float)x + jx, (float)y + jy, blend_out + ((size_t)y * w + x) * 4);
+        for (int x = 0; x < w; x++) blend_pixel_at(&C, (float)x + jx, (float)y + jy, slack_lo, slack_hi, blend_out + ((size_t)y * w + x) * 4);
     return 0;
 }
