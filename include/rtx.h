@@ -57,9 +57,16 @@ typedef struct rtx_defines {
 
 typedef enum rtx_format {
     RTX_RGBA32F = 0, /* 16 B/pixel, unclamped -- the parity buffer (FragColor before write-out) */
-    RTX_RGBA8 = 1    /* 4 B/pixel, clamp [0,1] + round-to-nearest -- what GL_RGBA8 fboColor holds
+    RTX_RGBA8 = 1,   /* 4 B/pixel, clamp [0,1] + round-to-nearest -- what GL_RGBA8 fboColor holds
                         (GLWrapper.cpp:127,209-222) */
+    RTX_SCREEN_RGBA8 = 2,       /* 4 B/pixel: what the reference's WINDOW shows -- the SMAA output when SMAA is enabled
+                                   (GLWrapper.cpp:195-204), else the same bytes as RTX_RGBA8. rtx_read_pixels only. */
+    RTX_SMAA_EDGES_RG8 = 3,     /* 2 B/pixel: fboTexEdge after the last resolve (GLWrapper.cpp:173-180); rtx_read_pixels only */
+    RTX_SMAA_WEIGHTS_RGBA8 = 4  /* 4 B/pixel: fboTexBlend after the last resolve (GLWrapper.cpp:182-193); rtx_read_pixels only */
 } rtx_format;
+
+/* enum SMAA_PRESET (src/SMAA_Builder.h:9-12) */
+typedef enum rtx_smaa_preset { RTX_SMAA_OFF = -1, RTX_SMAA_LOW = 0, RTX_SMAA_MEDIUM = 1, RTX_SMAA_HIGH = 2, RTX_SMAA_ULTRA = 3 } rtx_smaa_preset;
 
 typedef enum rtx_wrap { RTX_WRAP_REPEAT = 0, RTX_WRAP_CLAMP_TO_EDGE = 1 } rtx_wrap;
 
@@ -88,6 +95,8 @@ typedef struct rtx_stats {
     uint64_t rays_shadow;      /*   (reference-defined rays: calcInter / inShadow invocations) */
     uint64_t rays_shadow_cast; /*   shadow scans the kernel actually executed (dp > 0 only) */
     uint64_t torus_solves;     /*   Durand-Kerner solves actually run */
+    float last_smaa_ms;        /* HIP-event time of the last SMAA resolve (all of its kernels), 0 if none ran */
+    uint32_t smaa_edge_pixels; /* pixels with an edge in the last resolve (the sparse passes' work list) */
 } rtx_stats;
 
 RTX_API const char* rtx_last_error(void);
@@ -155,6 +164,22 @@ RTX_API int rtx_draw(rtx_context* ctx);
 RTX_API int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride,
                            void* dst_device, int format, void* stream);
 RTX_API int rtx_finish(rtx_context* ctx);
+
+/* ---- SMAA post-process: the three passes GLWrapper::draw runs after the tracer (GLWrapper.cpp:173-204) ----
+ * GLWrapper::enable_SMAA(preset)  [GLWrapper.cpp:149-153]. With a preset >= 0 every rtx_draw is followed by the resolve of the
+ * RGBA8 colour target into the screen buffer (RTX_SCREEN_RGBA8); RTX_SMAA_OFF switches it off again. Unlike the reference
+ * (which must be told before init_window) this may be called at any time. */
+RTX_API int rtx_enable_smaa(rtx_context* ctx, int preset);
+/* SMAA_Builder::load_area_texture / load_search_texture  [SMAA_Builder.h:52-83]: the two look-up tables as the caller's
+ * bytes -- area: 160 x 560 texels of RG8, search: 64 x 16 texels of R8, row 0 first (the arrays of the reference's AreaTex.h /
+ * SearchTex.h have exactly this form). The library holds no copy of its own; a resolve without tables is RTX_ERR_ORDER. */
+RTX_API int rtx_smaa_set_tables(rtx_context* ctx, const uint8_t* area_rg8, int area_w, int area_h,
+                                const uint8_t* search_r8, int search_w, int search_h);
+/* The post-process alone, on whatever the RGBA8 colour target holds (GLWrapper.cpp:173-204 without :155-165). */
+RTX_API int rtx_smaa_resolve(rtx_context* ctx);
+/* glTexSubImage2D on fboTexColor: replace the RGBA8 colour target by W*H*4 caller bytes, row 0 = bottom row (tests and
+ * post-process-only use; the tracer overwrites it at the next rtx_draw). */
+RTX_API int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host, size_t src_bytes);
 /* glReadPixels equivalent for tests/tools: copy the colour target to host memory. */
 RTX_API int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_bytes);
 /* Device pointer of the colour target (W*H pixels of `format`), for zero-copy consumers. */

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(_HERE, "librtx_hip.so")  # RTX_HIP_LIB: A/B builds of the same library
 
 RTX_OK = 0
-RTX_RGBA32F, RTX_RGBA8 = 0, 1
+RTX_RGBA32F, RTX_RGBA8, RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_WEIGHTS_RGBA8 = 0, 1, 2, 3, 4
+RTX_SMAA_OFF, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_HIGH, RTX_SMAA_ULTRA = -1, 0, 1, 2, 3
 RTX_WRAP_REPEAT, RTX_WRAP_CLAMP_TO_EDGE = 0, 1
 RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST = 0, 1, 2, 3, 4, 5, 6
 
@@ -23,6 +24,7 @@ SYMBOLS = (
     "rtx_sampler_unit", "rtx_bind_texture", "rtx_texture_destroy", "rtx_set_option", "rtx_get_option", "rtx_draw",
     "rtx_draw_bands", "rtx_finish", "rtx_read_pixels", "rtx_framebuffer_device", "rtx_get_stats",
     "rtx_sum_recent_draw_ms", "rtx_selftest",
+    "rtx_enable_smaa", "rtx_smaa_set_tables", "rtx_smaa_resolve", "rtx_write_pixels",
 )
 
 
@@ -34,7 +36,8 @@ class Defines(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("last_draw_ms", ctypes.c_float), ("launches", ctypes.c_uint32), ("rays_closest", ctypes.c_uint64),
-                ("rays_shadow", ctypes.c_uint64), ("rays_shadow_cast", ctypes.c_uint64), ("torus_solves", ctypes.c_uint64)]
+                ("rays_shadow", ctypes.c_uint64), ("rays_shadow_cast", ctypes.c_uint64), ("torus_solves", ctypes.c_uint64),
+                ("last_smaa_ms", ctypes.c_float), ("smaa_edge_pixels", ctypes.c_uint32)]
 
 
 _lib = None
@@ -86,6 +89,10 @@ def load():
     lib.rtx_get_stats.argtypes = [vp, P(Stats)]
     lib.rtx_sum_recent_draw_ms.argtypes = [vp, i, P(c.c_float)]
     lib.rtx_selftest.argtypes = [vp, P(i)]
+    lib.rtx_enable_smaa.argtypes = [vp, i]
+    lib.rtx_smaa_set_tables.argtypes = [vp, vp, i, i, vp, i, i]
+    lib.rtx_smaa_resolve.argtypes = [vp]
+    lib.rtx_write_pixels.argtypes = [vp, i, vp, c.c_size_t]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is c.c_int and name not in ("rtx_last_error", "rtx_version", "rtx_current", "rtx_destroy"):

@@ -18,6 +18,7 @@
 #include "rtx.h"
 #include "rt_kernel.h"
 #include "rt_pack.h"
+#include "smaa_kernel.h"
 
 using namespace rtdev;
 
@@ -98,6 +99,19 @@ struct rtx_context {
     int opt_occ = -1;   // RTX_OPT_HIGH_OCCUPANCY: -1 auto (by primitive count), 0 off, 1 on
     int opt_hot = 1;    // RTX_OPT_HOT_ROWS_FIRST
     unsigned long long* d_counters = nullptr;
+    // SMAA post-process (GLWrapper::enable_SMAA + the three passes of GLWrapper.cpp:173-204): smaa_preset < 0 = off
+    int smaa_preset = -1;
+    bool smaa_tables = false;
+    unsigned smaa_frame = 0;
+    uint32_t* d_screen = nullptr;    // RGBA8: what the reference shows in its window
+    uint16_t* d_edges = nullptr;     // RG8, zero outside the listed pixels
+    uint32_t* d_blend = nullptr;     // RGBA8, zero outside the listed pixels
+    uint32_t* d_list = nullptr;      // edge pixels of the current frame
+    uint32_t* d_smaa_count = nullptr;  // two alternating counters
+    uint16_t* d_area = nullptr;
+    uint8_t* d_search = nullptr;
+    hipEvent_t smaa_start = nullptr, smaa_stop = nullptr;
+    bool smaa_timed = false;
     // timing
     hipEvent_t ev_start[EVENT_RING], ev_stop[EVENT_RING];
     int ev_head = 0, ev_pending = 0;
@@ -306,6 +320,50 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     return RTX_OK;
 }
 
+int smaa_alloc(rtx_context* ctx)
+{
+    if (ctx->d_screen) return RTX_OK;
+    const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_screen), px * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_edges), px * 2));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_blend), px * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_list), px * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(ctx->d_edges, 0, px * 2, ctx->stream));      // the sparse passes keep both textures zero outside the
+    HIP_TRY(hipMemsetAsync(ctx->d_blend, 0, px * 4, ctx->stream));      // current frame's edge pixels (smaa_kernel.hip)
+    HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipEventCreate(&ctx->smaa_start));
+    HIP_TRY(hipEventCreate(&ctx->smaa_stop));
+    ctx->smaa_frame = 0;
+    return RTX_OK;
+}
+
+// The three passes after the tracer (GLWrapper.cpp:173-204) on the context's RGBA8 colour target, into the screen buffer.
+int smaa_resolve(rtx_context* ctx, hipStream_t stream)
+{
+    if (!ctx->smaa_tables) return fail(RTX_ERR_ORDER, "SMAA is enabled but rtx_smaa_set_tables has not supplied the area / search tables");
+    int st = smaa_alloc(ctx);
+    if (st) return st;
+    if (stream != ctx->stream) return fail(RTX_ERR_INVALID, "the SMAA resolve runs on the context's own stream");
+    SmaaBuffers b;
+    b.w = ctx->width;
+    b.h = ctx->height;
+    b.color = ctx->d_fb_u8;
+    b.screen = ctx->d_screen;
+    b.edges = ctx->d_edges;
+    b.blend = ctx->d_blend;
+    b.list = ctx->d_list;
+    b.count = ctx->d_smaa_count;
+    b.area = ctx->d_area;
+    b.search = ctx->d_search;
+    HIP_TRY(hipEventRecord(ctx->smaa_start, stream));
+    HIP_TRY(smaa_launch(b, ctx->smaa_preset, ctx->smaa_frame, stream));
+    HIP_TRY(hipEventRecord(ctx->smaa_stop, stream));
+    ctx->smaa_frame++;
+    ctx->smaa_timed = true;
+    return RTX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -371,6 +429,11 @@ void rtx_destroy(rtx_context* ctx)
     if (ctx->d_fb_f32) (void)hipFree(ctx->d_fb_f32);
     if (ctx->d_fb_u8) (void)hipFree(ctx->d_fb_u8);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (void* p : {static_cast<void*>(ctx->d_screen), static_cast<void*>(ctx->d_edges), static_cast<void*>(ctx->d_blend), static_cast<void*>(ctx->d_list),
+                    static_cast<void*>(ctx->d_smaa_count), static_cast<void*>(ctx->d_area), static_cast<void*>(ctx->d_search)})
+        if (p) (void)hipFree(p);
+    if (ctx->smaa_start) (void)hipEventDestroy(ctx->smaa_start);
+    if (ctx->smaa_stop) (void)hipEventDestroy(ctx->smaa_stop);
     for (int k = 0; k < EVENT_RING; k++) {
         if (ctx->ev_start[k]) (void)hipEventDestroy(ctx->ev_start[k]);
         if (ctx->ev_stop[k]) (void)hipEventDestroy(ctx->ev_stop[k]);
@@ -570,7 +633,62 @@ int rtx_draw(rtx_context* ctx)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "null context");
     const int band = ((ctx->height + 7) / 8) * 8;
-    return draw_impl(ctx, band, 0, 1, ctx->d_fb_f32, ctx->d_fb_u8, ctx->stream);
+    int st = draw_impl(ctx, band, 0, 1, ctx->d_fb_f32, ctx->d_fb_u8, ctx->stream);
+    if (st == RTX_OK && ctx->smaa_preset >= 0) st = smaa_resolve(ctx, ctx->stream);   // GLWrapper.cpp:168-204: the passes follow the tracer
+    return st;
+}
+
+/* ---- SMAA ---- */
+int rtx_smaa_set_tables(rtx_context* ctx, const uint8_t* area_rg8, int area_w, int area_h, const uint8_t* search_r8, int search_w, int search_h)
+{
+    if (!ctx || !area_rg8 || !search_r8) return fail(RTX_ERR_INVALID, "rtx_smaa_set_tables: null argument");
+    if (area_w != 160 || area_h != 560 || search_w != 64 || search_h != 16)
+        return fail(RTX_ERR_INVALID, "SMAA tables must be 160x560 (RG8) and 64x16 (R8), the sizes SMAA.h addresses (SMAA.h:519-522); got %dx%d and %dx%d",
+                    area_w, area_h, search_w, search_h);
+    int st = use_device(ctx);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_area) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_area), 160 * 560 * 2));
+    if (!ctx->d_search) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_search), 64 * 16));
+    HIP_TRY(hipMemcpy(ctx->d_area, area_rg8, 160 * 560 * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_search, search_r8, 64 * 16, hipMemcpyHostToDevice));
+    ctx->smaa_tables = true;
+    return RTX_OK;
+}
+
+int rtx_enable_smaa(rtx_context* ctx, int preset)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "null context");
+    if (preset < -1 || preset > RTX_SMAA_ULTRA) return fail(RTX_ERR_INVALID, "unknown SMAA preset %d", preset);
+    ctx->smaa_preset = preset;
+    if (preset >= 0) {
+        int st = use_device(ctx);
+        if (st) return st;
+        return smaa_alloc(ctx);
+    }
+    return RTX_OK;
+}
+
+int rtx_smaa_resolve(rtx_context* ctx)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "null context");
+    if (ctx->smaa_preset < 0) return fail(RTX_ERR_ORDER, "rtx_smaa_resolve: SMAA is not enabled (rtx_enable_smaa)");
+    int st = use_device(ctx);
+    if (st) return st;
+    return smaa_resolve(ctx, ctx->stream);
+}
+
+int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host, size_t src_bytes)
+{
+    if (!ctx || !src_host) return fail(RTX_ERR_INVALID, "rtx_write_pixels: null argument");
+    if (format != RTX_RGBA8) return fail(RTX_ERR_INVALID, "rtx_write_pixels: only the RGBA8 colour target can be written");
+    const size_t need = static_cast<size_t>(ctx->width) * ctx->height * 4;
+    if (src_bytes < need) return fail(RTX_ERR_INVALID, "source holds %zu bytes, %zu needed", src_bytes, need);
+    int st = use_device(ctx);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->d_fb_u8, src_host, need, hipMemcpyHostToDevice));
+    return RTX_OK;
 }
 
 int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride, void* dst_device, int format, void* stream)
@@ -597,11 +715,20 @@ int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_byt
     int st = use_device(ctx);
     if (st) return st;
     const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
-    const size_t need = px * (format == RTX_RGBA32F ? 16 : 4);
-    if (format != RTX_RGBA32F && format != RTX_RGBA8) return fail(RTX_ERR_INVALID, "unknown format %d", format);
+    const void* src = nullptr;
+    size_t need = 0;
+    switch (format) {
+        case RTX_RGBA32F: src = ctx->d_fb_f32; need = px * 16; break;
+        case RTX_RGBA8: src = ctx->d_fb_u8; need = px * 4; break;
+        case RTX_SCREEN_RGBA8: src = (ctx->smaa_preset >= 0 && ctx->d_screen) ? ctx->d_screen : ctx->d_fb_u8; need = px * 4; break;
+        case RTX_SMAA_EDGES_RG8: src = ctx->d_edges; need = px * 2; break;
+        case RTX_SMAA_WEIGHTS_RGBA8: src = ctx->d_blend; need = px * 4; break;
+        default: return fail(RTX_ERR_INVALID, "unknown format %d", format);
+    }
+    if (!src) return fail(RTX_ERR_ORDER, "format %d needs SMAA to be enabled (rtx_enable_smaa)", format);
     if (dst_bytes < need) return fail(RTX_ERR_INVALID, "destination holds %zu bytes, %zu needed", dst_bytes, need);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(dst_host, format == RTX_RGBA32F ? static_cast<void*>(ctx->d_fb_f32) : static_cast<void*>(ctx->d_fb_u8), need, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst_host, src, need, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
@@ -610,6 +737,7 @@ int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr)
     if (!ctx || !device_ptr) return fail(RTX_ERR_INVALID, "null argument");
     if (format == RTX_RGBA32F) *device_ptr = ctx->d_fb_f32;
     else if (format == RTX_RGBA8) *device_ptr = ctx->d_fb_u8;
+    else if (format == RTX_SCREEN_RGBA8) *device_ptr = (ctx->smaa_preset >= 0 && ctx->d_screen) ? ctx->d_screen : ctx->d_fb_u8;
     else return fail(RTX_ERR_INVALID, "unknown format %d", format);
     return RTX_OK;
 }
@@ -624,6 +752,13 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
     std::memset(out, 0, sizeof *out);
     out->last_draw_ms = ctx->last_ms;
     out->launches = ctx->launches;
+    if (ctx->smaa_timed) {
+        HIP_TRY(hipEventSynchronize(ctx->smaa_stop));
+        HIP_TRY(hipEventElapsedTime(&out->last_smaa_ms, ctx->smaa_start, ctx->smaa_stop));
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpy(&n, ctx->d_smaa_count + ((ctx->smaa_frame - 1u) & 1u), sizeof n, hipMemcpyDeviceToHost));
+        out->smaa_edge_pixels = n;
+    }
     if (ctx->opt_count) {
         unsigned long long c[4];
         HIP_TRY(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));

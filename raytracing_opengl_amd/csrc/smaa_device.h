@@ -1,0 +1,369 @@
+// smaa_device.h -- per-pixel arithmetic of the SMAA post-process, shared by the HIP kernels
+// (smaa_kernel.hip) and the host build used by the CPU-side logic tests (tests/host_harness).
+//
+// Replaces the three programs the reference runs after the tracer (src/GLWrapper.cpp:173-204, assembled by
+// src/SMAA_Builder.h:17-113 from assets/shaders/SMAA.h): luma edge detection (SMAA.h:689-741), blending-weight calculation
+// (SMAA.h:835-1243) and neighbourhood blending (SMAA.h:1252-1300); presets SMAA.h:304-324; SMAA 1x, no predication, no
+// reprojection (what SMAA_Builder compiles in).
+//
+// Arithmetic contract ("SMAA"): float32, no contraction, IEEE divide / sqrt, round = round-half-even; all textures
+// are 8-bit UNORM, LINEAR, CLAMP_TO_EDGE; positions are carried in TEXEL space, where the pixel the shader runs for sits at
+// exactly (x, y) and every offset SMAA adds is a dyadic fraction of a texel -- the values a sampler with exact varying
+// interpolation and unlimited sub-texel precision returns. Because the positions are exact, most fetches here are known at
+// compile time to fall on a texel centre or on a texel row / column, and are written as one- or two-tap fetches; that is the
+// SAME value as the general four-tap form (the dropped taps have weight exactly 0, and x + 0 = x), not an approximation.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define SM_HD __host__ __device__ __forceinline__
+#define SM_HDM __host__ __device__ __forceinline__   // member functions
+#else
+#define SM_HD static inline
+#define SM_HDM inline
+#endif
+
+namespace smaa {
+
+struct Preset {            // SMAA.h:304-324
+    float threshold;       // SMAA_THRESHOLD
+    int max_steps;         // SMAA_MAX_SEARCH_STEPS
+    int max_steps_diag;    // SMAA_MAX_SEARCH_STEPS_DIAG, 0 = SMAA_DISABLE_DIAG_DETECTION
+    int corner_rounding;   // SMAA_CORNER_ROUNDING, < 0 = SMAA_DISABLE_CORNER_DETECTION
+};
+SM_HD Preset preset_of(int id)
+{
+    switch (id) {
+        case 0: return Preset{0.15f, 4, 0, -1};
+        case 1: return Preset{0.1f, 8, 0, -1};
+        case 2: return Preset{0.1f, 16, 8, 25};
+        default: return Preset{0.05f, 32, 16, 25};
+    }
+}
+
+enum { AREA_W = 160, AREA_H = 560, SEARCH_W = 64, SEARCH_H = 16 };   // SMAA.h:519-522, AreaTex.h / SearchTex.h sizes
+
+struct Views {             // device (or host) pointers of one frame's textures
+    int w, h;
+    const uint32_t* color;   // RGBA8, R in bits 0..7
+    const uint16_t* edges;   // RG8,   R in bits 0..7
+    const uint32_t* blend;   // RGBA8
+    const uint16_t* area;    // RG8, AREA_W x AREA_H
+    const uint8_t* search;   // R8,  SEARCH_W x SEARCH_H
+};
+
+struct F2 { float x, y; };
+struct F4 { float x, y, z, w; };
+
+SM_HD float unorm8(uint32_t b) { return (float)b / 255.0f; }
+SM_HD uint32_t to_unorm8(float v)
+{
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    if (!(v == v)) v = 0.0f;
+    return (uint32_t)(v * 255.0f + 0.5f);
+}
+SM_HD float step_(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+SM_HD float max_(float a, float b) { return a < b ? b : a; }
+SM_HD float sat_(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+SM_HD int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// ---- samplers -----------------------------------------------------------------------------------------------
+// General LINEAR + CLAMP_TO_EDGE fetch of an RG8 texture at texel-space (tx, ty) plus an integer texel offset.
+SM_HD F2 sample_rg(const uint16_t* t, int w, int h, float tx, float ty, int ox = 0, int oy = 0)
+{
+    const float fx = floorf(tx), fy = floorf(ty);
+    const float a = tx - fx, b = ty - fy;
+    const int i0 = clampi((int)fx + ox, w - 1), i1 = clampi((int)fx + ox + 1, w - 1);
+    const int j0 = clampi((int)fy + oy, h - 1), j1 = clampi((int)fy + oy + 1, h - 1);
+    const uint32_t p00 = t[(size_t)j0 * w + i0], p10 = t[(size_t)j0 * w + i1], p01 = t[(size_t)j1 * w + i0], p11 = t[(size_t)j1 * w + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    F2 r;
+    r.x = w00 * unorm8(p00 & 255u) + w10 * unorm8(p10 & 255u) + w01 * unorm8(p01 & 255u) + w11 * unorm8(p11 & 255u);
+    r.y = w00 * unorm8(p00 >> 8) + w10 * unorm8(p10 >> 8) + w01 * unorm8(p01 >> 8) + w11 * unorm8(p11 >> 8);
+    return r;
+}
+// Texel-centre fetch (integer position): one tap.
+SM_HD F2 texel_rg(const uint16_t* t, int w, int h, int i, int j)
+{
+    const uint32_t p = t[(size_t)clampi(j, h - 1) * w + clampi(i, w - 1)];
+    F2 r;
+    r.x = unorm8(p & 255u);
+    r.y = unorm8(p >> 8);
+    return r;
+}
+SM_HD F4 unpack4(uint32_t p) { F4 r; r.x = unorm8(p & 255u); r.y = unorm8((p >> 8) & 255u); r.z = unorm8((p >> 16) & 255u); r.w = unorm8(p >> 24); return r; }
+SM_HD F4 sample_rgba(const uint32_t* t, int w, int h, float tx, float ty)
+{
+    const float fx = floorf(tx), fy = floorf(ty);
+    const float a = tx - fx, b = ty - fy;
+    const int i0 = clampi((int)fx, w - 1), i1 = clampi((int)fx + 1, w - 1);
+    const int j0 = clampi((int)fy, h - 1), j1 = clampi((int)fy + 1, h - 1);
+    const F4 t00 = unpack4(t[(size_t)j0 * w + i0]), t10 = unpack4(t[(size_t)j0 * w + i1]), t01 = unpack4(t[(size_t)j1 * w + i0]), t11 = unpack4(t[(size_t)j1 * w + i1]);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    F4 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.w = w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w;
+    return r;
+}
+SM_HD float sample_r8(const uint8_t* t, int w, int h, float tx, float ty)
+{
+    const float fx = floorf(tx), fy = floorf(ty);
+    const float a = tx - fx, b = ty - fy;
+    const int i0 = clampi((int)fx, w - 1), i1 = clampi((int)fx + 1, w - 1);
+    const int j0 = clampi((int)fy, h - 1), j1 = clampi((int)fy + 1, h - 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return w00 * unorm8(t[j0 * w + i0]) + w10 * unorm8(t[j0 * w + i1]) + w01 * unorm8(t[j1 * w + i0]) + w11 * unorm8(t[j1 * w + i1]);
+}
+
+// ---- pass 1: luma edges (SMAA.h:689-741) ----------------------------------------------------------------------
+SM_HD float luma_of(uint32_t rgba)
+{
+    return unorm8(rgba & 255u) * 0.2126f + unorm8((rgba >> 8) & 255u) * 0.7152f + unorm8((rgba >> 16) & 255u) * 0.0722f;
+}
+// Lumas: L centre, Ll / Lll one / two texels to the left, Lr right, Lt / Ltt one / two rows below in memory ("top" in the
+// shader's texture space: offset (0,-1)), Lb the row above. Returns the RG8 texel (0 = discarded fragment).
+SM_HD uint32_t edge_from_lumas(float threshold, float L, float Ll, float Lt, float Lr, float Lb, float Lll, float Ltt)
+{
+    const float dx = fabsf(L - Ll), dy = fabsf(L - Lt);
+    float ex = step_(threshold, dx), ey = step_(threshold, dy);
+    if (ex * 1.0f + ey * 1.0f == 0.0f) return 0u;
+    float dz = fabsf(L - Lr), dw = fabsf(L - Lb);
+    float mx = max_(dx, dz), my = max_(dy, dw);
+    dz = fabsf(Ll - Lll);
+    dw = fabsf(Lt - Ltt);
+    mx = max_(mx, dz);
+    my = max_(my, dw);
+    const float fin = max_(mx, my);
+    ex *= step_(fin, 2.0f * dx);   // SMAA_LOCAL_CONTRAST_ADAPTATION_FACTOR
+    ey *= step_(fin, 2.0f * dy);
+    return to_unorm8(ex) | (to_unorm8(ey) << 8);
+}
+
+// ---- pass 2: blending weights (SMAA.h:835-1243) --------------------------------------------------------------
+struct Blend {
+    const Views& V;
+    const Preset& P;
+
+    SM_HDM F2 edges_at(float tx, float ty, int ox = 0, int oy = 0) const { return sample_rg(V.edges, V.w, V.h, tx, ty, ox, oy); }
+
+    SM_HDM static float decode1(float r) { return rintf(r * fabsf(5.0f * r - 3.75f)); }   // SMAADecodeDiagBilinearAccess, red channel
+
+    // SMAASearchDiag1 / 2 (SMAA.h:861-892): steps of one texel along (dirx, diry); returns (steps, last weight); e = last edges
+    SM_HDM F2 search_diag1(float tx, float ty, float dirx, float diry, F2& e) const
+    {
+        float n = -1.0f, wgt = 1.0f;
+        while (n < (float)(P.max_steps_diag - 1) && wgt > 0.9f) {
+            tx = 1.0f * dirx + tx;
+            ty = 1.0f * diry + ty;
+            n = 1.0f * 1.0f + n;
+            e = edges_at(tx, ty);
+            wgt = e.x * 0.5f + e.y * 0.5f;
+        }
+        return F2{n, wgt};
+    }
+    SM_HDM F2 search_diag2(float tx, float ty, float dirx, float diry, F2& e) const
+    {
+        float n = -1.0f, wgt = 1.0f;
+        tx += 0.25f;
+        while (n < (float)(P.max_steps_diag - 1) && wgt > 0.9f) {
+            tx = 1.0f * dirx + tx;
+            ty = 1.0f * diry + ty;
+            n = 1.0f * 1.0f + n;
+            const F2 s = edges_at(tx, ty);
+            e.x = decode1(s.x);
+            e.y = rintf(s.y);
+            wgt = e.x * 0.5f + e.y * 0.5f;
+        }
+        return F2{n, wgt};
+    }
+    SM_HDM F2 area_diag(float d1, float d2, float e1, float e2) const   // SMAAAreaDiag, offset 0: diagonal half starts at column 80
+    {
+        return sample_rg(V.area, AREA_W, AREA_H, (20.0f * e1 + d1) + 80.0f, 20.0f * e2 + d2);
+    }
+    SM_HDM F2 diag_weights(float X, float Y, F2 e) const   // SMAACalculateDiagWeights (SMAA.h:918-985)
+    {
+        F2 wts{0.0f, 0.0f};
+        F2 end{0.0f, 0.0f};
+        float dx, dy, dz, dw;
+        if (e.x > 0.0f) {
+            const F2 r = search_diag1(X, Y, -1.0f, 1.0f, end);
+            dx = r.x + ((end.y > 0.9f) ? 1.0f : 0.0f);
+            dz = r.y;
+        } else {
+            dx = 0.0f;
+            dz = 0.0f;
+        }
+        {
+            const F2 r = search_diag1(X, Y, 1.0f, -1.0f, end);
+            dy = r.x;
+            dw = r.y;
+        }
+        if (dx + dy > 2.0f) {
+            const F2 s0 = edges_at((-dx + 0.25f) * 1.0f + X, dx * 1.0f + Y, -1, 0), s1 = edges_at(dy * 1.0f + X, (-dy - 0.25f) * 1.0f + Y, 1, 0);
+            // c.yxwz = decode(c.xyzw): decoded red of each fetch lands in c.y / c.w, rounded green in c.x / c.z
+            const float cy = decode1(s0.x), cx = rintf(s0.y), cw = decode1(s1.x), cz = rintf(s1.y);
+            float c1 = 2.0f * cx + cy, c2 = 2.0f * cz + cw;
+            if (step_(0.9f, dz) != 0.0f) c1 = 0.0f;
+            if (step_(0.9f, dw) != 0.0f) c2 = 0.0f;
+            const F2 a = area_diag(dx, dy, c1, c2);
+            wts.x += a.x;
+            wts.y += a.y;
+        }
+        {
+            const F2 r = search_diag2(X, Y, -1.0f, -1.0f, end);
+            dx = r.x;
+            dz = r.y;
+        }
+        if (edges_at(X, Y, 1, 0).x > 0.0f) {
+            const F2 r = search_diag2(X, Y, 1.0f, 1.0f, end);
+            dy = r.x + ((end.y > 0.9f) ? 1.0f : 0.0f);
+            dw = r.y;
+        } else {
+            dy = 0.0f;
+            dw = 0.0f;
+        }
+        if (dx + dy > 2.0f) {
+            const float ax = -dx * 1.0f + X, ay = -dx * 1.0f + Y, bx = dy * 1.0f + X, by = dy * 1.0f + Y;
+            const float cx = edges_at(ax, ay, -1, 0).y, cy = edges_at(ax, ay, 0, -1).x;
+            const F2 s = edges_at(bx, by, 1, 0);
+            float c1 = 2.0f * cx + cy, c2 = 2.0f * s.y + s.x;
+            if (step_(0.9f, dz) != 0.0f) c1 = 0.0f;
+            if (step_(0.9f, dw) != 0.0f) c2 = 0.0f;
+            const F2 a = area_diag(dx, dy, c1, c2);
+            wts.x += a.y;
+            wts.y += a.x;
+        }
+        return wts;
+    }
+
+    // SMAASearchLength (SMAA.h:998-1015): texel (32 e.x + 66 offset, 32 - 32 e.y) of the 64 x 16 table
+    SM_HDM float search_length(float ex, float ey, float offset) const
+    {
+        return sample_r8(V.search, SEARCH_W, SEARCH_H, 32.0f * ex + 66.0f * offset, -32.0f * ey + 32.0f);
+    }
+    // SMAASearchXLeft / XRight / YUp / YDown (SMAA.h:1020-1077): two texels per step from (tx, ty) towards `end`
+    SM_HDM float search_x(float tx, float ty, float end, float dir) const
+    {
+        F2 e{0.0f, 1.0f};
+        while ((dir < 0.0f ? tx > end : tx < end) && e.y > 0.8281f && e.x == 0.0f) {
+            e = edges_at(tx, ty);
+            tx = (dir * 2.0f) * 1.0f + tx;
+        }
+        const float off = -(255.0f / 127.0f) * search_length(e.x, e.y, dir < 0.0f ? 0.0f : 0.5f) + 3.25f;
+        return (-dir) * off + tx;
+    }
+    SM_HDM float search_y(float tx, float ty, float end, float dir) const
+    {
+        F2 e{1.0f, 0.0f};
+        while ((dir < 0.0f ? ty > end : ty < end) && e.x > 0.8281f && e.y == 0.0f) {
+            e = edges_at(tx, ty);
+            ty = (dir * 2.0f) * 1.0f + ty;
+        }
+        const float off = -(255.0f / 127.0f) * search_length(e.y, e.x, dir < 0.0f ? 0.0f : 0.5f) + 3.25f;
+        return (-dir) * off + ty;
+    }
+    SM_HDM F2 area(float d1, float d2, float e1, float e2) const   // SMAAArea (SMAA.h:1083-1095), offset 0
+    {
+        return sample_rg(V.area, AREA_W, AREA_H, 16.0f * rintf(4.0f * e1) + d1, 16.0f * rintf(4.0f * e2) + d2);
+    }
+    // SMAADetectHorizontalCornerPattern / Vertical (SMAA.h:1100-1140). horizontal: red of the rows above / two below the line at both
+    // ends; vertical: green of the columns right / two left.
+    SM_HDM void corners(F2& wts, float ax, float ay, float bx, float by, float d1, float d2, bool horizontal) const
+    {
+        if (P.corner_rounding < 0) return;
+        const float lx = step_(d1, d2), ly = step_(d2, d1);
+        const float keep = 1.0f - (float)P.corner_rounding / 100.0f;
+        float rx = keep * lx, ry = keep * ly;
+        rx /= lx + ly;
+        ry /= lx + ly;
+        float fx = 1.0f, fy = 1.0f;
+        if (horizontal) {
+            fx -= rx * edges_at(ax, ay, 0, 1).x;
+            fx -= ry * edges_at(bx, by, 1, 1).x;
+            fy -= rx * edges_at(ax, ay, 0, -2).x;
+            fy -= ry * edges_at(bx, by, 1, -2).x;
+        } else {
+            fx -= rx * edges_at(ax, ay, 1, 0).y;
+            fx -= ry * edges_at(bx, by, 1, 1).y;
+            fy -= rx * edges_at(ax, ay, -2, 0).y;
+            fy -= ry * edges_at(bx, by, -2, 1).y;
+        }
+        wts.x *= sat_(fx);
+        wts.y *= sat_(fy);
+    }
+
+    // SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) for the pixel at (x, y); returns the RGBA8 texel
+    SM_HDM uint32_t weights(int x, int y) const
+    {
+        const float X = (float)x, Y = (float)y, S = (float)P.max_steps;
+        F4 out{0.0f, 0.0f, 0.0f, 0.0f};
+        F2 e = texel_rg(V.edges, V.w, V.h, x, y);
+        if (e.y > 0.0f) {
+            bool hv = true;
+            if (P.max_steps_diag > 0) {
+                const F2 dwt = diag_weights(X, Y, e);
+                out.x = dwt.x;
+                out.y = dwt.y;
+                hv = (out.x == -out.y);
+            }
+            if (hv) {
+                const float cx = search_x(X - 0.25f, Y - 0.125f, (-2.0f * S) * 1.0f + (X - 0.25f), -1.0f);
+                const float cy = Y - 0.25f;
+                const float e1 = edges_at(cx, cy).x;
+                const float cz = search_x(X + 1.25f, Y - 0.125f, (2.0f * S) * 1.0f + (X + 1.25f), 1.0f);
+                const float d1 = fabsf(rintf(cx - X)), d2 = fabsf(rintf(cz - X));
+                const float e2 = edges_at(cz, cy, 1, 0).x;
+                F2 wgt = area(sqrtf(d1), sqrtf(d2), e1, e2);
+                corners(wgt, cx, Y, cz, Y, d1, d2, true);
+                out.x = wgt.x;
+                out.y = wgt.y;
+            } else {
+                e.x = 0.0f;
+            }
+        }
+        if (e.x > 0.0f) {
+            const float cy = search_y(X - 0.125f, Y - 0.25f, (-2.0f * S) * 1.0f + (Y - 0.25f), -1.0f);
+            const float cx = X - 0.25f;
+            const float e1 = edges_at(cx, cy).y;
+            const float cz = search_y(X - 0.125f, Y + 1.25f, (2.0f * S) * 1.0f + (Y + 1.25f), 1.0f);
+            const float d1 = fabsf(rintf(cy - Y)), d2 = fabsf(rintf(cz - Y));
+            const float e2 = edges_at(cx, cz, 0, 1).y;
+            F2 wgt = area(sqrtf(d1), sqrtf(d2), e1, e2);
+            corners(wgt, X, cy, X, cz, d1, d2, false);
+            out.z = wgt.x;
+            out.w = wgt.y;
+        }
+        return to_unorm8(out.x) | (to_unorm8(out.y) << 8) | (to_unorm8(out.z) << 16) | (to_unorm8(out.w) << 24);
+    }
+};
+
+// ---- pass 3: neighbourhood blending (SMAA.h:1252-1300) ---------------------------------------------------------
+// Returns true and the new RGBA8 texel when pixel (x, y) is blended; false when its four weights are all zero (the output is then the
+// input texel, which the dense pass has already copied).
+SM_HD bool neighborhood(const Views& V, int x, int y, uint32_t& out)
+{
+    const int xr = clampi(x + 1, V.w - 1), yt = clampi(y + 1, V.h - 1);
+    const uint32_t own = V.blend[(size_t)y * V.w + x], right = V.blend[(size_t)y * V.w + xr], top = V.blend[(size_t)yt * V.w + x];
+    const float ax = unorm8(right >> 24), ay = unorm8((top >> 8) & 255u), aw = unorm8(own & 255u), az = unorm8((own >> 16) & 255u);
+    if (ax * 1.0f + ay * 1.0f + az * 1.0f + aw * 1.0f < 1e-5f) return false;
+    const float X = (float)x, Y = (float)y;
+    const bool horiz = max_(ax, az) > max_(ay, aw);
+    float bx = 0.0f, by = ay, bz = 0.0f, bw = aw, wx = ay, wy = aw;
+    if (horiz) { bx = ax; by = 0.0f; bz = az; bw = 0.0f; wx = ax; wy = az; }
+    const float sum = wx * 1.0f + wy * 1.0f;
+    wx /= sum;
+    wy /= sum;
+    const F4 s0 = sample_rgba(V.color, V.w, V.h, bx * 1.0f + X, by * 1.0f + Y), s1 = sample_rgba(V.color, V.w, V.h, bz * -1.0f + X, bw * -1.0f + Y);
+    F4 c{wx * s0.x, wx * s0.y, wx * s0.z, wx * s0.w};
+    c.x += wy * s1.x;
+    c.y += wy * s1.y;
+    c.z += wy * s1.z;
+    c.w += wy * s1.w;
+    out = to_unorm8(c.x) | (to_unorm8(c.y) << 8) | (to_unorm8(c.z) << 16) | (to_unorm8(c.w) << 24);
+    return true;
+}
+
+}  // namespace smaa

@@ -13,7 +13,10 @@ import numpy as np
 
 from . import _capi
 from ._capi import (RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
+                    RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_HIGH, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_OFF, RTX_SMAA_ULTRA, RTX_SMAA_WEIGHTS_RGBA8,
                     RTX_WRAP_CLAMP_TO_EDGE, RTX_WRAP_REPEAT)
+
+LOW, MEDIUM, HIGH, ULTRA = RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_HIGH, RTX_SMAA_ULTRA   # enum SMAA_PRESET (reference src/SMAA_Builder.h:9-12)
 
 
 class RtxError(RuntimeError):
@@ -43,6 +46,8 @@ class GLWrapper:
             self.last_error = self._lib.rtx_last_error().decode()
             return False
         self._ctx = ctx
+        if getattr(self, "_smaa", None) is not None:
+            _check(self._lib.rtx_enable_smaa(self._ctx, self._smaa), "enable_SMAA")
         return True
 
     def stop(self):
@@ -62,8 +67,31 @@ class GLWrapper:
     def getHeight(self):
         return self.height
 
-    def enable_SMAA(self, preset=None):
-        """Accepted and ignored: SMAA is a post-process after the tracer."""
+    def enable_SMAA(self, preset=ULTRA):
+        """GLWrapper::enable_SMAA (GLWrapper.cpp:149-153): every draw() is followed by the three SMAA passes; read the result with
+        read_pixels(RTX_SCREEN_RGBA8). Before init_window (the reference's order) the choice is remembered and applied there."""
+        if isinstance(preset, str):
+            preset = ("LOW", "MEDIUM", "HIGH", "ULTRA").index(preset)
+        self._smaa = int(preset)
+        if self._ctx is not None:
+            _check(self._lib.rtx_enable_smaa(self._ctx, self._smaa), "enable_SMAA")
+
+    def set_smaa_tables(self, area: np.ndarray, search: np.ndarray):
+        """SMAA_Builder::load_area_texture / load_search_texture (SMAA_Builder.h:52-83): area (560, 160, 2) uint8, search (16, 64) uint8."""
+        area = np.ascontiguousarray(area, np.uint8)
+        search = np.ascontiguousarray(search, np.uint8)
+        _check(self._lib.rtx_smaa_set_tables(self._ctx, area.ctypes.data, area.shape[1], area.shape[0], search.ctypes.data, search.shape[1], search.shape[0]),
+               "set_smaa_tables")
+
+    def smaa_resolve(self):
+        """The post-process alone on the current RGBA8 colour target (GLWrapper.cpp:173-204)."""
+        _check(self._lib.rtx_smaa_resolve(self._ctx), "smaa_resolve")
+
+    def write_pixels(self, rgba8: np.ndarray):
+        """Replace the RGBA8 colour target: (H, W, 4) uint8, row 0 = bottom row."""
+        a = np.ascontiguousarray(rgba8, np.uint8)
+        assert a.shape == (self.height, self.width, 4), a.shape
+        _check(self._lib.rtx_write_pixels(self._ctx, RTX_RGBA8, a.ctypes.data, a.nbytes), "write_pixels")
 
     # --- specialisation / blocks ----------------------------------------------------------
     def init_shaders(self, defines):
@@ -139,7 +167,7 @@ class GLWrapper:
 
     def read_pixels(self, fmt: int = RTX_RGBA32F) -> np.ndarray:
         """(H, W, 4) float32 or uint8; row 0 = bottom row (gl_FragCoord origin)."""
-        out = np.empty((self.height, self.width, 4), dtype=np.float32 if fmt == RTX_RGBA32F else np.uint8)
+        out = np.empty((self.height, self.width, 2 if fmt == RTX_SMAA_EDGES_RG8 else 4), dtype=np.float32 if fmt == RTX_RGBA32F else np.uint8)
         _check(self._lib.rtx_read_pixels(self._ctx, fmt, out.ctypes.data, out.nbytes), "read_pixels")
         return out
 

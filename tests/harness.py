@@ -94,3 +94,18 @@ def kat(type_, record: bytes, ro, rd, tmin=1e6):
     if rc != 0:
         raise RuntimeError(f"harness_kat failed ({rc})")
     return bool(out[0]), out[1], bool(out[2])
+
+
+def smaa(color_rgba8, preset, area, search):
+    """The product's SMAA arithmetic (csrc/smaa_device.h, host build) run densely: {'edges', 'blend', 'screen'} like oracle.smaa.run."""
+    color = np.ascontiguousarray(color_rgba8, np.uint8)
+    h, w = color.shape[:2]
+    area, search = np.ascontiguousarray(area, np.uint8), np.ascontiguousarray(search, np.uint8)
+    edges, blend, screen = np.empty((h, w, 2), np.uint8), np.empty((h, w, 4), np.uint8), np.empty((h, w, 4), np.uint8)
+    l = lib()
+    l.harness_smaa.restype = ctypes.c_int
+    l.harness_smaa.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    p = ("LOW", "MEDIUM", "HIGH", "ULTRA").index(preset) if isinstance(preset, str) else int(preset)
+    if l.harness_smaa(color.ctypes.data, w, h, p, area.ctypes.data, search.ctypes.data, edges.ctypes.data, blend.ctypes.data, screen.ctypes.data) != 0:
+        raise RuntimeError("harness_smaa failed")
+    return {"edges": edges, "blend": blend, "screen": screen}

@@ -37,7 +37,7 @@ def pattern(seed: int, w: int, h: int) -> np.ndarray:
         box = (np.abs(xx - cx) < w * 0.18) & (np.abs(yy - cy) < h * 0.22)
         img[m & box] = rng.uniform(0, 1, 3)
     for k in range(5):                                                    # discs and rings
-        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(3, min(w, h) * 0.15)
+        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(3, max(3.5, min(w, h) * 0.15))
         d = np.hypot(xx - cx, yy - cy)
         img[d < r] = rng.uniform(0, 1, 3)
         img[np.abs(d - 1.6 * r) < 0.7] = rng.uniform(0.5, 1, 3)           # thin ring: one-pixel features

@@ -39,6 +39,6 @@ def test_product_never_touches_the_oracle():
             for f in files:
                 if f.endswith((".py", ".h", ".cpp", ".hip", ".c")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
-                    if re.search(r"liboracle|rt_oracle|from oracle|import oracle|orc_render|libharness", text):
+                    if re.search(r"liboracle|rt_oracle|smaa_oracle|from oracle|import oracle|orc_render|libharness", text):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad

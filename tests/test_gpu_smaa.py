@@ -1,0 +1,132 @@
+"""SMAA on the GPU: the HIP kernels through the C ABI against the oracle, BYTE FOR BYTE -- the edge
+texture, the weight texture and the screen. The arithmetic itself is already pinned on the CPU (tests/test_smaa_host.py: the same
+device header, host build); what runs here in addition is the kernels' plumbing: the LDS luma tile and its clamped halo, the
+16-byte and the scalar pixel paths, the ballot-ranked edge list, the sparse passes and the clear-through-the-list invariant."""
+import numpy as np
+import pytest
+
+import smaa_cases
+import smaa_tables
+from oracle import smaa
+from raytracing_opengl_amd import scenes, wrapper
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tables():
+    return smaa_tables.area_table(), smaa_tables.search_table()
+
+
+def _ctx(w, h, preset, tables):
+    gl = wrapper.GLWrapper(w, h)
+    gl.enable_SMAA(preset)                  # the reference's order: before init_window (main.cpp:32-34)
+    assert gl.init_window(), getattr(gl, "last_error", "")
+    gl.set_smaa_tables(*tables)
+    return gl
+
+
+def _resolve(gl, img):
+    gl.write_pixels(img)
+    gl.smaa_resolve()
+    return {"edges": gl.read_pixels(wrapper.RTX_SMAA_EDGES_RG8), "blend": gl.read_pixels(wrapper.RTX_SMAA_WEIGHTS_RGBA8),
+            "screen": gl.read_pixels(wrapper.RTX_SCREEN_RGBA8)}
+
+
+def _same(got, want, what=""):
+    for k in ("edges", "blend", "screen"):
+        assert np.array_equal(got[k], want[k]), (what, k, int((got[k] != want[k]).sum()))
+
+
+@pytest.mark.parametrize("preset", smaa.PRESETS)
+@pytest.mark.parametrize("seed,w,h", [(1, 320, 200), (2, 203, 131), (3, 64, 16), (4, 5, 3), (5, 1, 1), (6, 131, 77), (7, 1024, 37), (8, 66, 300)])
+def test_patterns_byte_exact(built, tables, preset, seed, w, h):
+    img = smaa_cases.pattern(seed, w, h)
+    gl = _ctx(w, h, preset, tables)
+    got = _resolve(gl, img)
+    st = gl.stats()
+    gl.stop()
+    want = smaa.run(img, preset, *tables)
+    _same(got, want)
+    assert st["smaa_edge_pixels"] == int(want["edges"].any(-1).sum())
+
+
+def test_consecutive_frames_leave_no_stale_texels(built, tables):
+    """The edge and weight textures are only ever written at listed pixels and cleared through the previous list: A, B, A, blank, A
+    with preset changes in between must each equal a fresh oracle run."""
+    w, h = 257, 129
+    a, b = smaa_cases.pattern(31, w, h), smaa_cases.pattern(32, w, h)
+    blank = np.zeros_like(a)
+    blank[..., 3] = 255
+    gl = _ctx(w, h, "ULTRA", tables)
+    for k, (img, preset) in enumerate([(a, "ULTRA"), (b, "ULTRA"), (a, "LOW"), (blank, "HIGH"), (a, "MEDIUM"), (b, "ULTRA"), (b, "ULTRA")]):
+        gl.enable_SMAA(preset)
+        _same(_resolve(gl, img), smaa.run(img, preset, *tables), f"frame {k}")
+    gl.stop()
+
+
+def test_random_tables_and_noise(built):
+    rng = np.random.default_rng(9)
+    for k in range(4):
+        area = rng.integers(0, 256, smaa.AREA_SHAPE, dtype=np.uint8)
+        search = rng.choice(np.array([0, 127, 254], np.uint8), smaa.SEARCH_SHAPE)
+        img = rng.integers(0, 256, (96, 160, 4), dtype=np.uint8)
+        img[..., :3] = (img[..., :3] // 64) * 64
+        gl = _ctx(160, 96, smaa.PRESETS[k], (area, search))
+        _same(_resolve(gl, img), smaa.run(img, smaa.PRESETS[k], area, search), f"case {k}")
+        gl.stop()
+
+
+@pytest.mark.parametrize("kind,w,h,depth,preset", [("default", 960, 540, 4, "ULTRA"), ("torus", 480, 270, 6, "HIGH"), ("quadric", 481, 271, 4, "MEDIUM")])
+def test_draw_with_smaa_enabled_resolves_the_traced_frame(built, tables, mid_textures, kind, w, h, depth, preset):
+    """GLWrapper::draw with SMAA on (GLWrapper.cpp:155-204): trace -> RGBA8 colour target -> three passes -> screen."""
+    sc = scenes.build_scene(kind, w, h, depth)
+    gl = wrapper.make_renderer(sc, w, h, mid_textures["textures"], mid_textures["cubemap"])
+    gl.enable_SMAA(preset)
+    gl.set_smaa_tables(*tables)
+    gl.draw()
+    color = gl.read_pixels(wrapper.RTX_RGBA8)
+    got = {"edges": gl.read_pixels(wrapper.RTX_SMAA_EDGES_RG8), "blend": gl.read_pixels(wrapper.RTX_SMAA_WEIGHTS_RGBA8),
+           "screen": gl.read_pixels(wrapper.RTX_SCREEN_RGBA8)}
+    gl.draw()                                  # a second frame of the same scene: same bytes
+    again = gl.read_pixels(wrapper.RTX_SCREEN_RGBA8)
+    gl.enable_SMAA(wrapper.RTX_SMAA_OFF)
+    gl.draw()
+    off = gl.read_pixels(wrapper.RTX_SCREEN_RGBA8)
+    gl.stop()
+    want = smaa.run(color, preset, *tables)
+    _same(got, want)
+    assert np.array_equal(again, got["screen"]) and np.array_equal(off, color)
+    assert (got["screen"] != color).any(-1).mean() > 0.002      # it did anti-alias something
+
+
+def test_full_size_frame(built, tables):
+    """BASELINE's frame size: a 3840 x 2160 pattern, byte-exact against the oracle (all three textures)."""
+    w, h = 3840, 2160
+    img = np.tile(smaa_cases.pattern(41, 960, 540), (4, 4, 1))
+    gl = _ctx(w, h, "ULTRA", tables)
+    got = _resolve(gl, img)
+    gl.stop()
+    _same(got, smaa.run(img, "ULTRA", *tables))
+
+
+def test_error_behaviour(built, tables):
+    gl = wrapper.GLWrapper(64, 48)
+    assert gl.init_window()
+    with pytest.raises(wrapper.RtxError, match="not enabled"):
+        gl.smaa_resolve()
+    with pytest.raises(wrapper.RtxError, match="needs SMAA"):
+        gl.read_pixels(wrapper.RTX_SMAA_EDGES_RG8)
+    gl.enable_SMAA("HIGH")
+    with pytest.raises(wrapper.RtxError, match="tables"):
+        gl.smaa_resolve()
+    with pytest.raises(wrapper.RtxError, match="160x560"):
+        gl.set_smaa_tables(np.zeros((80, 160, 2), np.uint8), tables[1])
+    with pytest.raises(wrapper.RtxError, match="preset"):
+        gl.enable_SMAA(7)
+    gl.set_smaa_tables(*tables)
+    img = smaa_cases.pattern(5, 64, 48)
+    gl.write_pixels(img)
+    gl.smaa_resolve()
+    assert np.array_equal(gl.read_pixels(wrapper.RTX_SCREEN_RGBA8), smaa.run(img, "HIGH", *tables)["screen"])
+    gl.stop()
