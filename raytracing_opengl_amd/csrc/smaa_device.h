@@ -56,7 +56,17 @@ struct Views {             // device (or host) pointers of one frame's textures
 struct F2 { float x, y; };
 struct F4 { float x, y, z, w; };
 
-SM_HD float unorm8(uint32_t b) { return (float)b / 255.0f; }
+// byte / 255.0f without the IEEE divide: one multiply by RN(1/255) and an fma correction step give the correctly rounded quotient
+// for every one of the 256 inputs (checked exhaustively: tests/test_smaa_host.py on the host, rtx_selftest on the device).
+SM_HD float unorm8(uint32_t b)
+{
+    const float x = (float)b;
+    const float rcp = 0.0039215688593685626983642578125f;   // RN(1/255)
+    float q = x * rcp;
+    const float r = __builtin_fmaf(-q, 255.0f, x);
+    q = __builtin_fmaf(r, rcp, q);
+    return q;
+}
 SM_HD uint32_t to_unorm8(float v)
 {
     v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
@@ -151,31 +161,57 @@ struct Blend {
 
     SM_HDM static float decode1(float r) { return rintf(r * fabsf(5.0f * r - 3.75f)); }   // SMAADecodeDiagBilinearAccess, red channel
 
+    // The search loops below fetch SEARCH_BATCH steps ahead before testing the first of them. A step's position does not depend on what the
+    // previous step fetched, only whether the step is taken does, so the batch is evaluated in order from registers and abandoned at the
+    // first failing test: the same values, tests and results as one fetch per iteration, with the chain of dependent memory latencies cut
+    // by the batch size (a 32-step search of a long edge is 8 round trips to L2 instead of 32). Fetches past the stopping step are wasted
+    // bandwidth only (positions are clamped, any texel is readable).
+    enum { SEARCH_BATCH = 4 };
+
     // SMAASearchDiag1 / 2 (SMAA.h:861-892): steps of one texel along (dirx, diry); returns (steps, last weight); e = last edges
     SM_HDM F2 search_diag1(float tx, float ty, float dirx, float diry, F2& e) const
     {
         float n = -1.0f, wgt = 1.0f;
-        while (n < (float)(P.max_steps_diag - 1) && wgt > 0.9f) {
-            tx = 1.0f * dirx + tx;
-            ty = 1.0f * diry + ty;
-            n = 1.0f * 1.0f + n;
-            e = edges_at(tx, ty);
-            wgt = e.x * 0.5f + e.y * 0.5f;
+        const float last = (float)(P.max_steps_diag - 1);
+        while (n < last && wgt > 0.9f) {
+            F2 s[SEARCH_BATCH];
+            float px = tx, py = ty;
+            for (int k = 0; k < SEARCH_BATCH; k++) {
+                px = 1.0f * dirx + px;
+                py = 1.0f * diry + py;
+                s[k] = edges_at(px, py);
+            }
+            for (int k = 0; k < SEARCH_BATCH && n < last && wgt > 0.9f; k++) {
+                tx = 1.0f * dirx + tx;
+                ty = 1.0f * diry + ty;
+                n = 1.0f * 1.0f + n;
+                e = s[k];
+                wgt = e.x * 0.5f + e.y * 0.5f;
+            }
         }
         return F2{n, wgt};
     }
     SM_HDM F2 search_diag2(float tx, float ty, float dirx, float diry, F2& e) const
     {
         float n = -1.0f, wgt = 1.0f;
+        const float last = (float)(P.max_steps_diag - 1);
         tx += 0.25f;
-        while (n < (float)(P.max_steps_diag - 1) && wgt > 0.9f) {
-            tx = 1.0f * dirx + tx;
-            ty = 1.0f * diry + ty;
-            n = 1.0f * 1.0f + n;
-            const F2 s = edges_at(tx, ty);
-            e.x = decode1(s.x);
-            e.y = rintf(s.y);
-            wgt = e.x * 0.5f + e.y * 0.5f;
+        while (n < last && wgt > 0.9f) {
+            F2 s[SEARCH_BATCH];
+            float px = tx, py = ty;
+            for (int k = 0; k < SEARCH_BATCH; k++) {
+                px = 1.0f * dirx + px;
+                py = 1.0f * diry + py;
+                s[k] = edges_at(px, py);
+            }
+            for (int k = 0; k < SEARCH_BATCH && n < last && wgt > 0.9f; k++) {
+                tx = 1.0f * dirx + tx;
+                ty = 1.0f * diry + ty;
+                n = 1.0f * 1.0f + n;
+                e.x = decode1(s[k].x);
+                e.y = rintf(s[k].y);
+                wgt = e.x * 0.5f + e.y * 0.5f;
+            }
         }
         return F2{n, wgt};
     }
@@ -248,9 +284,18 @@ struct Blend {
     SM_HDM float search_x(float tx, float ty, float end, float dir) const
     {
         F2 e{0.0f, 1.0f};
+        const float stepx = (dir * 2.0f) * 1.0f;
         while ((dir < 0.0f ? tx > end : tx < end) && e.y > 0.8281f && e.x == 0.0f) {
-            e = edges_at(tx, ty);
-            tx = (dir * 2.0f) * 1.0f + tx;
+            F2 s[SEARCH_BATCH];
+            float px = tx;
+            for (int k = 0; k < SEARCH_BATCH; k++) {
+                s[k] = edges_at(px, ty);
+                px = stepx + px;
+            }
+            for (int k = 0; k < SEARCH_BATCH && (dir < 0.0f ? tx > end : tx < end) && e.y > 0.8281f && e.x == 0.0f; k++) {
+                e = s[k];
+                tx = stepx + tx;
+            }
         }
         const float off = -(255.0f / 127.0f) * search_length(e.x, e.y, dir < 0.0f ? 0.0f : 0.5f) + 3.25f;
         return (-dir) * off + tx;
@@ -258,9 +303,18 @@ struct Blend {
     SM_HDM float search_y(float tx, float ty, float end, float dir) const
     {
         F2 e{1.0f, 0.0f};
+        const float stepy = (dir * 2.0f) * 1.0f;
         while ((dir < 0.0f ? ty > end : ty < end) && e.x > 0.8281f && e.y == 0.0f) {
-            e = edges_at(tx, ty);
-            ty = (dir * 2.0f) * 1.0f + ty;
+            F2 s[SEARCH_BATCH];
+            float py = ty;
+            for (int k = 0; k < SEARCH_BATCH; k++) {
+                s[k] = edges_at(tx, py);
+                py = stepy + py;
+            }
+            for (int k = 0; k < SEARCH_BATCH && (dir < 0.0f ? ty > end : ty < end) && e.x > 0.8281f && e.y == 0.0f; k++) {
+                e = s[k];
+                ty = stepy + ty;
+            }
         }
         const float off = -(255.0f / 127.0f) * search_length(e.y, e.x, dir < 0.0f ? 0.0f : 0.5f) + 3.25f;
         return (-dir) * off + ty;

@@ -4,9 +4,10 @@
 // reads and writes whole frames although edges -- the only pixels the second and third pass do anything for -- are a few per cent
 // of a frame. Here the frame is touched densely ONCE and the rest is sparse:
 //
-//   smaa_edges_kernel    dense: reads the colour target (16 B per lane), copies it to the screen, detects luma edges on an LDS
-//                        tile of lumas (SMAA.h:689-741) and, for edge pixels only, writes the RG8 edge texel and appends the pixel
-//                        to a list -- one atomic per wave (ballot + prefix count), none for the waves without an edge;
+//   smaa_edges_kernel    dense: reads the colour target (16 B per lane, 1 KiB per wave and row), copies it to the screen, detects luma
+//                        edges (SMAA.h:689-741) on a four-row window of lumas held in registers and, for edge pixels only, writes the
+//                        RG8 edge texel and appends the pixel to a list -- one atomic per 256 x 8 strip (ballot ranks), none for the
+//                        strips without an edge;
 //   smaa_weights_kernel  over the list: blending weights (SMAA.h:1145-1243) -> RGBA8 weight texel of that pixel;
 //   smaa_blend_kernel    over the list: neighbourhood blending (SMAA.h:1252-1300) of the listed pixel, its left and its lower
 //                        neighbour -- the only pixels whose four weights can be non-zero -- overwriting their screen texels;
@@ -25,8 +26,9 @@
 
 namespace {
 
-constexpr int TILE_W = 64, TILE_H = 16;          // pixels per workgroup: 16 lanes x 4 pixels wide, 16 rows
-constexpr int LDS_W = TILE_W + 3, LDS_H = TILE_H + 3;   // + 2 left / lower, + 1 right / upper
+constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels = one 1 KiB row segment per load
+constexpr int STRIP_H = 8;       // rows per wave: 8 + 3 halo rows are read for 8 rows of output
+constexpr int WAVES_PER_WG = 4;  // four strips side by side per workgroup
 
 __device__ __forceinline__ uint32_t load_px(const uint32_t* color, int w, int h, int x, int y)
 {
@@ -35,74 +37,110 @@ __device__ __forceinline__ uint32_t load_px(const uint32_t* color, int w, int h,
     return color[(size_t)y * w + x];
 }
 
-__global__ __launch_bounds__(256) void smaa_edges_kernel(SmaaBuffers b, float threshold, unsigned cur)
+struct Row4 { float l[4]; };   // lumas of one lane's four pixels in one row
+
+// The dense pass. One wave owns a strip of STRIP_W x STRIP_H pixels and walks it bottom to top with a four-row window of lumas in
+// registers (rows y-2, y-1, y, y+1 of SMAA.h:689-741's "top-top", "top", centre, "bottom"); the three horizontal neighbours a lane
+// needs come from the adjacent lanes by cross-lane moves, the strip's outermost columns by two extra loads. Every row is copied to the
+// screen as it passes. Edge bits are kept in two registers per lane for the whole strip; at the end the wave reserves its list slots with
+// ONE atomic (none at all for the strips without an edge -- most of a frame), ranks its pixels with ballots and writes list + edge texels.
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffers b, float threshold, unsigned cur)
 {
-    __shared__ float L[LDS_H][LDS_W];
     const int w = b.w, h = b.h;
-    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int px = x0 + tx * 4, py = y0 + ty;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * WAVES_PER_WG + wave) * STRIP_W, y0 = blockIdx.y * STRIP_H;
+    if (x0 >= w) return;                                                       // wave-uniform
+    const int px = x0 + lane * 4;
+    const bool vec_ok = ((w & 3) == 0) && (px + 3 < w);
+
+    auto load_row = [&](int y, uint32_t c[4]) {                               // clamped in y; x clamped per pixel on the scalar path
+        const int yc = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        if (vec_ok) {
+            const uint4 v = *reinterpret_cast<const uint4*>(b.color + (size_t)yc * w + px);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] = load_px(b.color, w, h, px + k, yc);
+        }
+    };
+    auto lumas = [&](const uint32_t c[4]) {
+        Row4 r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.l[k] = smaa::luma_of(c[k]);
+        return r;
+    };
+
     uint32_t c[4];
-    const bool row_ok = py < h;
-    const bool vec = row_ok && (px + 3 < w) && ((w & 3) == 0);
-    if (vec) {
-        const uint4 v = *reinterpret_cast<const uint4*>(b.color + (size_t)py * w + px);
-        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
-        *reinterpret_cast<uint4*>(b.screen + (size_t)py * w + px) = v;          // the dense copy: pass 3 for every pixel without weights
-    } else {
+    load_row(y0 - 2, c);
+    Row4 Ltt = lumas(c);
+    load_row(y0 - 1, c);
+    Row4 Lt = lumas(c);
+    uint32_t cc[4];
+    load_row(y0, cc);
+    Row4 Lc = lumas(cc);
+    unsigned long long ebits = 0;                                              // 2 bits (R, G) per pixel: bit (row * 4 + k) * 2
+    for (int r = 0; r < STRIP_H; r++) {
+        const int y = y0 + r;
+        if (y >= h) break;                                                     // wave-uniform
+        uint32_t cb[4];
+        load_row(y + 1, cb);
+        const Row4 Lb = lumas(cb);
+        // the dense copy: pass 3 for every pixel without weights
+        if (vec_ok) {
+            *reinterpret_cast<uint4*>(b.screen + (size_t)y * w + px) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (px + k < w) b.screen[(size_t)y * w + px + k] = cc[k];
+        }
+        // horizontal neighbours of this row: two to the left of pixel 0, one to the right of pixel 3
+        float left1 = __shfl_up(Lc.l[3], 1, 64), left2 = __shfl_up(Lc.l[2], 1, 64), right = __shfl_down(Lc.l[0], 1, 64);
+        if (lane == 0) {
+            left1 = smaa::luma_of(load_px(b.color, w, h, px - 1, y));
+            left2 = smaa::luma_of(load_px(b.color, w, h, px - 2, y));
+        }
+        if (lane == 63 || px + 4 >= w) right = smaa::luma_of(load_px(b.color, w, h, px + 4, y));
+        const float row[7] = {left2, left1, Lc.l[0], Lc.l[1], Lc.l[2], Lc.l[3], right};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            c[k] = load_px(b.color, w, h, px + k, py);
-            if (row_ok && px + k < w) b.screen[(size_t)py * w + px + k] = c[k];
+            if (px + k < w) {
+                const uint32_t e = smaa::edge_from_lumas(threshold, row[k + 2], row[k + 1], Lt.l[k], row[k + 3], Lb.l[k], row[k], Ltt.l[k]);
+                const unsigned long long two = (unsigned long long)((e & 1u) | ((e >> 7) & 2u));   // RG8 texel 0x00ff / 0xff00 -> bits 0 / 1
+                ebits |= two << ((r * 4 + k) * 2);
+            }
         }
-    }
+        Ltt = Lt;
+        Lt = Lc;
+        Lc = Lb;
 #pragma unroll
-    for (int k = 0; k < 4; k++) L[ty + 2][tx * 4 + 2 + k] = smaa::luma_of(c[k]);
-    // halo: rows y0-2, y0-1, y0+TILE_H over all LDS_W columns; columns x0-2, x0-1, x0+TILE_W over the tile rows (249 cells)
-    {
-        const int t = threadIdx.x;
-        int lx = -1, ly = -1;
-        if (t < 3 * LDS_W) {
-            const int r = t / LDS_W;
-            lx = t - r * LDS_W;
-            ly = r < 2 ? r : LDS_H - 1;
-        } else if (t < 3 * LDS_W + 3 * TILE_H) {
-            const int u = t - 3 * LDS_W, r = u / 3, cidx = u - r * 3;
-            ly = r + 2;
-            lx = cidx < 2 ? cidx : LDS_W - 1;
-        }
-        if (lx >= 0) L[ly][lx] = smaa::luma_of(load_px(b.color, w, h, x0 + lx - 2, y0 + ly - 2));
+        for (int k = 0; k < 4; k++) cc[k] = cb[k];
     }
-    __syncthreads();
-    uint32_t e[4];
-    unsigned mask = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int lx = tx * 4 + 2 + k, ly = ty + 2;
-        const bool real = row_ok && (px + k < w);
-        e[k] = real ? smaa::edge_from_lumas(threshold, L[ly][lx], L[ly][lx - 1], L[ly - 1][lx], L[ly][lx + 1], L[ly + 1][lx], L[ly][lx - 2], L[ly - 2][lx]) : 0u;
-        if (e[k]) mask |= 1u << k;
-    }
-    // append the edge pixels of this wave: per-slot ballots give every lane its rank without a scan
-    unsigned long long bal[4];
+    // append: per-slot ballots rank the pixels; one atomic reserves the strip's entries
+    if (__ballot(ebits != 0) == 0) return;                                     // wave-uniform: most strips leave here
     unsigned total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { bal[k] = __ballot((mask >> k) & 1u); total += (unsigned)__popcll(bal[k]); }
-    if (total == 0) return;                                                    // wave-uniform: most waves leave here
+    unsigned long long any = ebits | (ebits >> 1);                             // bit 2s set <=> pixel slot s has an edge
+    {
+        unsigned mine = (unsigned)__popcll(any & 0x5555555555555555ull);
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        total = mine;
+    }
     unsigned base = 0;
-    const int lane = threadIdx.x & 63;
     if (lane == 0) base = atomicAdd(b.count + cur, total);
     base = __shfl(base, 0, 64);
     unsigned before = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if ((mask >> k) & 1u) {
-            const unsigned rank = before + (unsigned)__popcll(bal[k] & ((1ull << lane) - 1ull));
-            const uint32_t p = (uint32_t)((size_t)py * w + px + k);
+    for (int s = 0; s < STRIP_H * 4; s++) {
+        const bool has = (any >> (2 * s)) & 1ull;
+        const unsigned long long bal = __ballot(has);
+        if (bal == 0) continue;                                                // wave-uniform
+        if (has) {
+            const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            const int r = s >> 2, k = s & 3;
+            const uint32_t p = (uint32_t)((size_t)(y0 + r) * w + px + k);
+            const unsigned two = (unsigned)(ebits >> (2 * s)) & 3u;
             b.list[base + rank] = p;
-            b.edges[p] = (uint16_t)e[k];
+            b.edges[p] = (uint16_t)(((two & 1u) ? 0x00ffu : 0u) | ((two & 2u) ? 0xff00u : 0u));
         }
-        before += (unsigned)__popcll(bal[k]);
+        before += (unsigned)__popcll(bal);
     }
 }
 
@@ -157,8 +195,8 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const unsigned cur = frame & 1u, prev = cur ^ 1u;
     const int sparse_blocks = 1024;                                             // grid-stride over a device-side count
     hipLaunchKernelGGL(smaa_clear_kernel, dim3(sparse_blocks), dim3(256), 0, stream, b, prev);
-    const dim3 grid((b.w + TILE_W - 1) / TILE_W, (b.h + TILE_H - 1) / TILE_H);
-    hipLaunchKernelGGL(smaa_edges_kernel, grid, dim3(256), 0, stream, b, smaa::preset_of(preset).threshold, cur);
+    const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + STRIP_H - 1) / STRIP_H);
+    hipLaunchKernelGGL(smaa_edges_kernel, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, smaa::preset_of(preset).threshold, cur);
     hipLaunchKernelGGL(smaa_weights_kernel, dim3(sparse_blocks), dim3(256), 0, stream, b, preset, cur);
     hipLaunchKernelGGL(smaa_blend_kernel, dim3(sparse_blocks), dim3(256), 0, stream, b, cur);
     return hipGetLastError();

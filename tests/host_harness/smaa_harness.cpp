@@ -35,3 +35,14 @@ extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, con
         }
     return 0;
 }
+
+// exhaustive check of smaa::unorm8 (divide-free) against byte / 255.0f
+extern "C" int harness_smaa_unorm8_mismatches()
+{
+    int bad = 0;
+    for (uint32_t b = 0; b < 256; b++) {
+        volatile float ref = (float)b / 255.0f;
+        if (smaa::unorm8(b) != ref) bad++;
+    }
+    return bad;
+}

@@ -43,3 +43,10 @@ def test_random_tables_and_noise_byte_exact(built):
         img = rng.integers(0, 256, (48, 80, 4), dtype=np.uint8)
         img[..., :3] = (img[..., :3] // 64) * 64            # coarse levels: plenty of long runs and crossings
         _same(harness.smaa(img, smaa.PRESETS[k], area, search), smaa.run(img, smaa.PRESETS[k], area, search))
+
+
+def test_divide_free_unorm8_is_exact(built):
+    import ctypes
+    lib = harness.lib()
+    lib.harness_smaa_unorm8_mismatches.restype = ctypes.c_int
+    assert lib.harness_smaa_unorm8_mismatches() == 0
