@@ -327,11 +327,11 @@ int smaa_alloc(rtx_context* ctx)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_screen), px * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_edges), px * 2));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_blend), px * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_list), px * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_list), smaa_segment_capacity(ctx->width, ctx->height) * SMAA_SEGMENTS * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * SMAA_SEGMENTS * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(ctx->d_edges, 0, px * 2, ctx->stream));      // the sparse passes keep both textures zero outside the
     HIP_TRY(hipMemsetAsync(ctx->d_blend, 0, px * 4, ctx->stream));      // current frame's edge pixels (smaa_kernel.hip)
-    HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * SMAA_SEGMENTS * sizeof(uint32_t), ctx->stream));
     HIP_TRY(hipEventCreate(&ctx->smaa_start));
     HIP_TRY(hipEventCreate(&ctx->smaa_stop));
     ctx->smaa_frame = 0;
@@ -353,6 +353,7 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
     b.edges = ctx->d_edges;
     b.blend = ctx->d_blend;
     b.list = ctx->d_list;
+    b.segment_capacity = smaa_segment_capacity(ctx->width, ctx->height);
     b.count = ctx->d_smaa_count;
     b.area = ctx->d_area;
     b.search = ctx->d_search;
@@ -755,9 +756,9 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
     if (ctx->smaa_timed) {
         HIP_TRY(hipEventSynchronize(ctx->smaa_stop));
         HIP_TRY(hipEventElapsedTime(&out->last_smaa_ms, ctx->smaa_start, ctx->smaa_stop));
-        uint32_t n = 0;
-        HIP_TRY(hipMemcpy(&n, ctx->d_smaa_count + ((ctx->smaa_frame - 1u) & 1u), sizeof n, hipMemcpyDeviceToHost));
-        out->smaa_edge_pixels = n;
+        uint32_t n[SMAA_SEGMENTS];
+        HIP_TRY(hipMemcpy(n, ctx->d_smaa_count + ((ctx->smaa_frame - 1u) & 1u) * SMAA_SEGMENTS, sizeof n, hipMemcpyDeviceToHost));
+        for (int k = 0; k < SMAA_SEGMENTS; k++) out->smaa_edge_pixels += n[k];
     }
     if (ctx->opt_count) {
         unsigned long long c[4];

@@ -133,23 +133,26 @@ SM_HD float luma_of(uint32_t rgba)
 {
     return unorm8(rgba & 255u) * 0.2126f + unorm8((rgba >> 8) & 255u) * 0.7152f + unorm8((rgba >> 16) & 255u) * 0.0722f;
 }
-// Lumas: L centre, Ll / Lll one / two texels to the left, Lr right, Lt / Ltt one / two rows below in memory ("top" in the
-// shader's texture space: offset (0,-1)), Lb the row above. Returns the RG8 texel (0 = discarded fragment).
+// The edge decision from the six luma deltas of SMAA.h:709-737: d = |L - left|, |L - top| (the pixel's own two candidate edges), the
+// deltas to the right / bottom neighbours and the left / top neighbours' own deltas (left-left, top-top). The shader multiplies step()
+// results; with every factor in {0, 1} that product is the conjunction below -- the same decisions, a third of the instructions. Note
+// that each delta is ALSO some neighbour's own delta (|a - b| = |b - a| exactly): the dense kernel computes one horizontal and one
+// vertical delta per pixel and hands them along. Returns bit 0 = red (left edge), bit 1 = green (top edge).
+SM_HD uint32_t edge_bits(float threshold, float dx, float dy, float dx_right, float dy_bottom, float dx_left, float dy_top)
+{
+    bool ex = !(dx < threshold), ey = !(dy < threshold);                       // step(threshold, delta)
+    if (!(ex || ey)) return 0u;                                                // discard
+    const float fin = fmaxf(fmaxf(fmaxf(dx, dx_right), dx_left), fmaxf(fmaxf(dy, dy_bottom), dy_top));
+    ex = ex && !(2.0f * dx < fin);                                             // step(finalDelta, 2 * delta): local contrast adaptation
+    ey = ey && !(2.0f * dy < fin);
+    return (ex ? 1u : 0u) | (ey ? 2u : 0u);
+}
+// Lumas: L centre, Ll / Lll one / two texels to the left, Lr right, Lt / Ltt one / two rows below in memory ("top" in the shader's
+// texture space: offset (0,-1)), Lb the row above. Returns the RG8 texel (0 = discarded fragment).
 SM_HD uint32_t edge_from_lumas(float threshold, float L, float Ll, float Lt, float Lr, float Lb, float Lll, float Ltt)
 {
-    const float dx = fabsf(L - Ll), dy = fabsf(L - Lt);
-    float ex = step_(threshold, dx), ey = step_(threshold, dy);
-    if (ex * 1.0f + ey * 1.0f == 0.0f) return 0u;
-    float dz = fabsf(L - Lr), dw = fabsf(L - Lb);
-    float mx = max_(dx, dz), my = max_(dy, dw);
-    dz = fabsf(Ll - Lll);
-    dw = fabsf(Lt - Ltt);
-    mx = max_(mx, dz);
-    my = max_(my, dw);
-    const float fin = max_(mx, my);
-    ex *= step_(fin, 2.0f * dx);   // SMAA_LOCAL_CONTRAST_ADAPTATION_FACTOR
-    ey *= step_(fin, 2.0f * dy);
-    return to_unorm8(ex) | (to_unorm8(ey) << 8);
+    const uint32_t e = edge_bits(threshold, fabsf(L - Ll), fabsf(L - Lt), fabsf(L - Lr), fabsf(L - Lb), fabsf(Ll - Lll), fabsf(Lt - Ltt));
+    return ((e & 1u) ? 0x00ffu : 0u) | ((e & 2u) ? 0xff00u : 0u);
 }
 
 // ---- pass 2: blending weights (SMAA.h:835-1243) --------------------------------------------------------------

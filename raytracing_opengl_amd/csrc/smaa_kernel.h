@@ -4,18 +4,23 @@
 
 #include <cstdint>
 
+enum { SMAA_SEGMENTS = 64 };
+
 struct SmaaBuffers {
     int w, h;
     const uint32_t* color;   // RGBA8 colour target of the tracer (fboTexColor, GLWrapper.cpp:127)
     uint32_t* screen;        // RGBA8 output (what the reference draws to the default framebuffer, GLWrapper.cpp:195-204)
     uint16_t* edges;         // RG8 (fboTexEdge); ZERO outside the listed pixels at all times
     uint32_t* blend;         // RGBA8 (fboTexBlend); ZERO outside the listed pixels at all times
-    uint32_t* list;          // pixel indices (y * w + x) of the current frame's edge pixels, w * h entries of capacity
-    uint32_t* count;         // two counters, used alternately by consecutive frames (see smaa_kernel.hip)
+    uint32_t* list;          // pixel indices (y * w + x) of the current frame's edge pixels: SMAA_SEGMENTS segments of segment_capacity entries
+    size_t segment_capacity;
+    uint32_t* count;         // 2 x SMAA_SEGMENTS counters, the two sets used alternately by consecutive frames (see smaa_kernel.hip)
     const uint16_t* area;    // 160 x 560 RG8
     const uint8_t* search;   // 64 x 16 R8
 };
 
 // One SMAA resolve of `b.color` into `b.screen` (asynchronous on `stream`). `frame` is the caller's running count of resolves on
 // these buffers (selects the counter). preset: 0 LOW .. 3 ULTRA.
+// entries one list segment must hold for a w x h frame (every pixel of the strips that append to it)
+size_t smaa_segment_capacity(int w, int h);
 hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream);

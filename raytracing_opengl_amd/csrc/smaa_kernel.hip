@@ -18,16 +18,30 @@
 // would have produced (glClear(0) + discard, GLWrapper.cpp:177-178,189-190). Algorithmic HBM traffic per frame: W*H*4 B read +
 // W*H*4 B written, against 6 x W*H*4 B + 2 x W*H*2 B for three dense passes.
 //
-// Counters: two, used alternately. Frame f appends to count[f & 1]; smaa_clear of frame f walks the list with count[(f-1) & 1]
-// entries; smaa_weights of frame f, the first kernel after which nobody needs it any more, zeroes count[(f-1) & 1] for frame f+1.
+// The list is kept in SMAA_SEGMENTS independent segments, each with its own counter: a strip appends to segment (strip index mod
+// SMAA_SEGMENTS), and the sparse kernels walk all segments (blockIdx.y = segment). One shared counter was measured to cost 16 us per 4K
+// frame by itself -- ~3000 atomics on ONE address serialise in one L2 channel (profiles/r02_smaa_ablation.txt) -- with 64 addresses
+// the append disappears into the dense pass. A segment's capacity is the pixel count of the strips that map to it, so it cannot overflow.
+//
+// Counters: two sets, used alternately. Frame f appends to set f & 1; smaa_clear of frame f walks the lists with the counts of set
+// (f-1) & 1; smaa_weights of frame f, the first kernel after which nobody needs them any more, zeroes set (f-1) & 1 for frame f+1.
+// The sparse kernels treat the segments as one list again (SegmentedList below), so their work stays balanced.
 #include "smaa_kernel.h"
+
+#include <cstdlib>
 
 #include "smaa_device.h"
 
 namespace {
 
 constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels = one 1 KiB row segment per load
-constexpr int STRIP_H = 8;       // rows per wave: 8 + 3 halo rows are read for 8 rows of output
+#ifndef SMAA_ABL
+#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded */
+#endif
+#ifndef SMAA_STRIP_H
+#define SMAA_STRIP_H 8
+#endif
+constexpr int STRIP_H_DEFAULT = SMAA_STRIP_H;   // rows per wave: H + 3 rows are read for H rows of output
 constexpr int WAVES_PER_WG = 4;  // four strips side by side per workgroup
 
 __device__ __forceinline__ uint32_t load_px(const uint32_t* color, int w, int h, int x, int y)
@@ -44,111 +58,189 @@ struct Row4 { float l[4]; };   // lumas of one lane's four pixels in one row
 // needs come from the adjacent lanes by cross-lane moves, the strip's outermost columns by two extra loads. Every row is copied to the
 // screen as it passes. Edge bits are kept in two registers per lane for the whole strip; at the end the wave reserves its list slots with
 // ONE atomic (none at all for the strips without an edge -- most of a frame), ranks its pixels with ballots and writes list + edge texels.
+template <int STRIP_H>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffers b, float threshold, unsigned cur)
 {
+    static_assert(STRIP_H * 4 * 2 <= 128, "edge bits of a strip live in two 64-bit registers per lane");
+    // Per-channel luma terms, unorm8(byte) * weight, as three 256-entry tables in LDS: the same float products the arithmetic contract
+    // spells out (smaa::luma_of), computed once per workgroup instead of per pixel -- a pixel's luma is three look-ups and two adds. The
+    // dense pass is VALU-bound without this (25 us of luma arithmetic at 4K against 10 us of memory time, profiles/r02_smaa_ablation.txt).
+    __shared__ float lut[3][256];
+    {
+        const float wgt[3] = {0.2126f, 0.7152f, 0.0722f};
+        for (int i = threadIdx.x; i < 768; i += 64 * WAVES_PER_WG) lut[i >> 8][i & 255] = smaa::unorm8((uint32_t)(i & 255)) * wgt[i >> 8];
+    }
+    __syncthreads();
+#if SMAA_ABL & 8
+    auto luma = [&](uint32_t rgba) { return (float)(rgba & 255u) + (float)((rgba >> 8) & 255u) * 0.5f; };
+#else
+    auto luma = [&](uint32_t rgba) { return lut[0][rgba & 255u] + lut[1][(rgba >> 8) & 255u] + lut[2][(rgba >> 16) & 255u]; };
+#endif
     const int w = b.w, h = b.h;
+    const uint32_t* __restrict__ color = b.color;      // the colour target and the screen are different allocations: let the loads of
+    uint32_t* __restrict__ screen = b.screen;          // the next rows move above the stores of this one
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = (blockIdx.x * WAVES_PER_WG + wave) * STRIP_W, y0 = blockIdx.y * STRIP_H;
-    if (x0 >= w) return;                                                       // wave-uniform
+    if (x0 >= w) return;                                                       // wave-uniform (after the barrier)
     const int px = x0 + lane * 4;
     const bool vec_ok = ((w & 3) == 0) && (px + 3 < w);
 
     auto load_row = [&](int y, uint32_t c[4]) {                               // clamped in y; x clamped per pixel on the scalar path
         const int yc = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
         if (vec_ok) {
-            const uint4 v = *reinterpret_cast<const uint4*>(b.color + (size_t)yc * w + px);
+            const uint4 v = *reinterpret_cast<const uint4*>(color + (size_t)yc * w + px);
             c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) c[k] = load_px(b.color, w, h, px + k, yc);
+            for (int k = 0; k < 4; k++) c[k] = load_px(color, w, h, px + k, yc);
         }
     };
     auto lumas = [&](const uint32_t c[4]) {
         Row4 r;
 #pragma unroll
-        for (int k = 0; k < 4; k++) r.l[k] = smaa::luma_of(c[k]);
+        for (int k = 0; k < 4; k++) r.l[k] = luma(c[k]);
         return r;
     };
 
+    // window: lumas of rows y-1 (Lt) and y (Lc), vertical deltas |row - row below| of rows y-1 (dyt) and y (dyc)
     uint32_t c[4];
     load_row(y0 - 2, c);
-    Row4 Ltt = lumas(c);
+    const Row4 Ltt = lumas(c);
     load_row(y0 - 1, c);
     Row4 Lt = lumas(c);
-    uint32_t cc[4];
+    uint32_t cc[4], cb[4], cn[4];
     load_row(y0, cc);
     Row4 Lc = lumas(cc);
-    unsigned long long ebits = 0;                                              // 2 bits (R, G) per pixel: bit (row * 4 + k) * 2
+    Row4 dyt, dyc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { dyt.l[k] = fabsf(Lt.l[k] - Ltt.l[k]); dyc.l[k] = fabsf(Lc.l[k] - Lt.l[k]); }
+    load_row(y0 + 1, cb);                                                      // two rows are always in flight ahead of the one being
+    unsigned long long ebits[2] = {0, 0};                                      // worked on. 2 bits (R, G) per pixel: bit (row * 4 + k) * 2
+    unsigned valid = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) valid |= (px + k < w) ? (3u << (2 * k)) : 0u;
+#pragma unroll
     for (int r = 0; r < STRIP_H; r++) {
         const int y = y0 + r;
         if (y >= h) break;                                                     // wave-uniform
-        uint32_t cb[4];
-        load_row(y + 1, cb);
+#if SMAA_ABL & 32
+        if (r + 1 < STRIP_H) { for (int k = 0; k < 4; k++) cn[k] = cb[k] ^ (uint32_t)r; }
+#else
+        if (r + 1 < STRIP_H) load_row(y + 2, cn);
+#endif
         const Row4 Lb = lumas(cb);
-        // the dense copy: pass 3 for every pixel without weights
+        // the dense copy: pass 3 for every pixel without weights (streamed: nothing reads these lines again before the sparse passes)
         if (vec_ok) {
-            *reinterpret_cast<uint4*>(b.screen + (size_t)y * w + px) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const v4u v = {cc[0], cc[1], cc[2], cc[3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(screen + (size_t)y * w + px));
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (px + k < w) b.screen[(size_t)y * w + px + k] = cc[k];
+                if (px + k < w) screen[(size_t)y * w + px + k] = cc[k];
         }
         // horizontal neighbours of this row: two to the left of pixel 0, one to the right of pixel 3
+#if SMAA_ABL & 4
+        float left1 = Lc.l[3], left2 = Lc.l[2], right = Lc.l[0];
+#else
         float left1 = __shfl_up(Lc.l[3], 1, 64), left2 = __shfl_up(Lc.l[2], 1, 64), right = __shfl_down(Lc.l[0], 1, 64);
+#endif
+#if !(SMAA_ABL & 2)
         if (lane == 0) {
-            left1 = smaa::luma_of(load_px(b.color, w, h, px - 1, y));
-            left2 = smaa::luma_of(load_px(b.color, w, h, px - 2, y));
+            left1 = luma(load_px(color, w, h, px - 1, y));
+            left2 = luma(load_px(color, w, h, px - 2, y));
         }
-        if (lane == 63 || px + 4 >= w) right = smaa::luma_of(load_px(b.color, w, h, px + 4, y));
+        if (lane == 63 || px + 4 >= w) right = luma(load_px(color, w, h, px + 4, y));
+#endif
         const float row[7] = {left2, left1, Lc.l[0], Lc.l[1], Lc.l[2], Lc.l[3], right};
+        float dx[6];                                                           // dx[j] = |row[j+1] - row[j]|: pixel k's own delta is dx[k+1]
+#pragma unroll
+        for (int j = 0; j < 6; j++) dx[j] = fabsf(row[j + 1] - row[j]);
+        Row4 dyb;                                                              // the row above's own vertical delta = this row's "bottom" delta
+        unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (px + k < w) {
-                const uint32_t e = smaa::edge_from_lumas(threshold, row[k + 2], row[k + 1], Lt.l[k], row[k + 3], Lb.l[k], row[k], Ltt.l[k]);
-                const unsigned long long two = (unsigned long long)((e & 1u) | ((e >> 7) & 2u));   // RG8 texel 0x00ff / 0xff00 -> bits 0 / 1
-                ebits |= two << ((r * 4 + k) * 2);
-            }
+            dyb.l[k] = fabsf(Lb.l[k] - Lc.l[k]);
+#if !(SMAA_ABL & 1)
+            bits |= smaa::edge_bits(threshold, dx[k + 1], dyc.l[k], dx[k + 2], dyb.l[k], dx[k], dyt.l[k]) << (2 * k);
+#endif
         }
-        Ltt = Lt;
+        ebits[r >> 3] |= (unsigned long long)(bits & valid) << ((r & 7) * 8);
         Lt = Lc;
         Lc = Lb;
+        dyt = dyc;
+        dyc = dyb;
 #pragma unroll
-        for (int k = 0; k < 4; k++) cc[k] = cb[k];
+        for (int k = 0; k < 4; k++) { cc[k] = cb[k]; cb[k] = cn[k]; }
     }
     // append: per-slot ballots rank the pixels; one atomic reserves the strip's entries
-    if (__ballot(ebits != 0) == 0) return;                                     // wave-uniform: most strips leave here
-    unsigned total = 0;
-    unsigned long long any = ebits | (ebits >> 1);                             // bit 2s set <=> pixel slot s has an edge
-    {
-        unsigned mine = (unsigned)__popcll(any & 0x5555555555555555ull);
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-        total = mine;
-    }
+#if SMAA_ABL & 16
+    if (threshold > -1.0e30f) { if (ebits[0] == 0x123456789abcdefull) screen[0] = 1; return; }   // keep the arithmetic alive, skip the append
+#endif
+    if (__ballot((ebits[0] | ebits[1]) != 0) == 0) return;                     // wave-uniform: most strips leave here
+    const unsigned long long any[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
+    unsigned total = (unsigned)__popcll(any[0]) + (unsigned)__popcll(any[1]);  // bit 2s of any[] set <=> pixel slot s has an edge
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(b.count + cur, total);
+    const unsigned strip = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
+    const unsigned seg = strip % SMAA_SEGMENTS;
+    uint32_t* const list = b.list + (size_t)seg * b.segment_capacity;
+    if (lane == 0) base = atomicAdd(b.count + cur * SMAA_SEGMENTS + seg, total);
     base = __shfl(base, 0, 64);
     unsigned before = 0;
     for (int s = 0; s < STRIP_H * 4; s++) {
-        const bool has = (any >> (2 * s)) & 1ull;
+        const int sh = 2 * (s & 31);
+        const bool has = (any[s >> 5] >> sh) & 1ull;
         const unsigned long long bal = __ballot(has);
         if (bal == 0) continue;                                                // wave-uniform
         if (has) {
             const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
             const int r = s >> 2, k = s & 3;
             const uint32_t p = (uint32_t)((size_t)(y0 + r) * w + px + k);
-            const unsigned two = (unsigned)(ebits >> (2 * s)) & 3u;
-            b.list[base + rank] = p;
+            const unsigned two = (unsigned)(ebits[s >> 5] >> sh) & 3u;
+            list[base + rank] = p;
             b.edges[p] = (uint16_t)(((two & 1u) ? 0x00ffu : 0u) | ((two & 2u) ? 0xff00u : 0u));
         }
         before += (unsigned)__popcll(bal);
     }
 }
 
+// The sparse kernels see the segments as ONE list: the first wave of every workgroup scans the 64 counts (one per lane) into LDS, and
+// a flat index is mapped to (segment, entry) by a six-step search of that prefix. Work is then balanced over the whole grid whatever
+// the segments' individual lengths.
+struct SegmentedList {
+    unsigned prefix[SMAA_SEGMENTS + 1];
+    __device__ __forceinline__ unsigned load(const uint32_t* counts)    // returns the total; all 256 threads must call it
+    {
+        static_assert(SMAA_SEGMENTS == 64, "one count per lane of the first wave");
+        if (threadIdx.x < 64) {
+            unsigned v = counts[threadIdx.x];
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned u = __shfl_up(v, off, 64);
+                if ((int)threadIdx.x >= off) v += u;
+            }
+            prefix[threadIdx.x + 1] = v;
+            if (threadIdx.x == 0) prefix[0] = 0;
+        }
+        __syncthreads();
+        return prefix[SMAA_SEGMENTS];
+    }
+    __device__ __forceinline__ uint32_t entry(const SmaaBuffers& b, unsigned i) const
+    {
+        unsigned lo = 0;                                                  // largest seg with prefix[seg] <= i
+#pragma unroll
+        for (int bit = 32; bit > 0; bit >>= 1)
+            if (prefix[lo + bit] <= i) lo += bit;
+        return b.list[(size_t)lo * b.segment_capacity + (i - prefix[lo])];
+    }
+};
+
 __global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned prev)
 {
-    const unsigned n = b.count[prev];
+    __shared__ SegmentedList L;
+    const unsigned n = L.load(b.count + prev * SMAA_SEGMENTS);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = b.list[i];
+        const uint32_t p = L.entry(b, i);
         b.edges[p] = 0;
         b.blend[p] = 0;
     }
@@ -156,13 +248,14 @@ __global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned
 
 __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int preset, unsigned cur)
 {
-    const unsigned n = b.count[cur];
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.count[cur ^ 1u] = 0;            // free for the next frame's appends (see the header comment)
+    __shared__ SegmentedList L;
+    const unsigned n = L.load(b.count + cur * SMAA_SEGMENTS);
+    if (blockIdx.x == 0 && threadIdx.x < SMAA_SEGMENTS) b.count[(cur ^ 1u) * SMAA_SEGMENTS + threadIdx.x] = 0;   // free for the next frame's appends
     const smaa::Preset P = smaa::preset_of(preset);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
     const smaa::Blend B{V, P};
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = b.list[i];
+        const uint32_t p = L.entry(b, i);
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
         b.blend[p] = B.weights(x, y);
     }
@@ -170,7 +263,8 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
 
 __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned cur)
 {
-    const unsigned n = b.count[cur];
+    __shared__ SegmentedList L;
+    const unsigned n = L.load(b.count + cur * SMAA_SEGMENTS);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
     // three candidates per listed pixel: itself, its left and its lower neighbour (a pixel's weights come from its own weight texel,
     // its right neighbour's alpha and its upper neighbour's green; only listed pixels have non-zero weight texels). A pixel reached
@@ -178,7 +272,7 @@ __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned
     const unsigned items = n * 3u;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
         const unsigned which = i / n;                                           // all "itself" first, then the neighbours: coalesced list reads
-        const uint32_t p = b.list[i - which * n];
+        const uint32_t p = L.entry(b, i - which * n);
         int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
         if (which == 1) x -= 1;
         if (which == 2) y -= 1;
@@ -190,14 +284,35 @@ __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned
 
 }  // namespace
 
+int smaa_strip_count(int w, int h, int strip_h)
+{
+    const int gx = (w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), gy = (h + strip_h - 1) / strip_h;
+    return gx * gy * WAVES_PER_WG;
+}
+static int strip_rows()
+{
+    static const int v = [] { const char* e = getenv("RTX_SMAA_STRIP_H"); const int x = e ? atoi(e) : STRIP_H_DEFAULT; return (x == 4 || x == 8 || x == 16) ? x : STRIP_H_DEFAULT; }();   // A/B knob
+    return v;
+}
+size_t smaa_segment_capacity(int w, int h)
+{
+    const int strip_h = strip_rows();
+    const int strips = smaa_strip_count(w, h, strip_h);
+    return (size_t)((strips + SMAA_SEGMENTS - 1) / SMAA_SEGMENTS) * (size_t)(STRIP_W * strip_h);
+}
+
 hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream)
 {
     const unsigned cur = frame & 1u, prev = cur ^ 1u;
-    const int sparse_blocks = 1024;                                             // grid-stride over a device-side count
-    hipLaunchKernelGGL(smaa_clear_kernel, dim3(sparse_blocks), dim3(256), 0, stream, b, prev);
-    const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + STRIP_H - 1) / STRIP_H);
-    hipLaunchKernelGGL(smaa_edges_kernel, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, smaa::preset_of(preset).threshold, cur);
-    hipLaunchKernelGGL(smaa_weights_kernel, dim3(sparse_blocks), dim3(256), 0, stream, b, preset, cur);
-    hipLaunchKernelGGL(smaa_blend_kernel, dim3(sparse_blocks), dim3(256), 0, stream, b, cur);
+    const dim3 sparse(1024);                                                    // grid-stride over the device-side total of the segment counts
+    hipLaunchKernelGGL(smaa_clear_kernel, sparse, dim3(256), 0, stream, b, prev);
+    const int strip_h = strip_rows();
+    const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
+    const float thr = smaa::preset_of(preset).threshold;
+    if (strip_h == 4) hipLaunchKernelGGL(smaa_edges_kernel<4>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
+    else if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
+    else hipLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
+    hipLaunchKernelGGL(smaa_weights_kernel, sparse, dim3(256), 0, stream, b, preset, cur);
+    hipLaunchKernelGGL(smaa_blend_kernel, sparse, dim3(256), 0, stream, b, cur);
     return hipGetLastError();
 }
