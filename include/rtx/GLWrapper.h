@@ -8,7 +8,9 @@
 // (GLWrapper.cpp:224-227,371-375; utils.h:57-63). What is different, by construction:
 //   * the "window" is a device colour target; `window` is a null GLFWwindow* (windowing, input and
 //     presentation are outside the replaced path -- SURVEY.md section 8(b),(f));
-//   * enable_SMAA is accepted and ignored (post-process after the tracer; section 8(f1));
+//   * enable_SMAA(preset) switches on the SMAA post-process (the three passes of GLWrapper.cpp:173-204 as HIP kernels); its two
+//     look-up tables are third-party data this repository does not carry: built inside the reference tree (AreaTex.h / SearchTex.h
+//     on the include path) the shim hands those arrays over in init_shaders like SMAA_Builder does; otherwise call set_SMAA_tables;
 //   * image files: the tracer boundary takes decoded 8-bit texels. load_texture/load_cubemap
 //     decode through a pluggable function (set_image_decoder); the built-in decoder reads PNG (png_decode.h), JPEG
 //     (jpeg_decode.h; stb_image's arithmetic, so the texels equal the reference's) and binary PPM/PGM (P6/P5) and
@@ -33,6 +35,13 @@
 #include "png_decode.h"
 #include "jpeg_decode.h"
 #include "png_write.h"
+#if defined(__has_include)
+#if __has_include("AreaTex.h") && __has_include("SearchTex.h")
+#include "AreaTex.h"     // the reference's own tables (src/AreaTex.h, src/SearchTex.h), when the shim is built in its tree
+#include "SearchTex.h"
+#define RTX_SHIM_HAVE_SMAA_TABLES 1
+#endif
+#endif
 
 #ifndef ASSETS_DIR
 #define ASSETS_DIR "."
@@ -168,6 +177,7 @@ public:
             return false;
         }
         std::printf("rtx %s\n", rtx_version());
+        if (SMAA_enabled) rtx_shim::check(rtx_enable_smaa(ctx, static_cast<int>(SMAA_preset)), "enable_SMAA");
         return true;
     }
 
@@ -177,6 +187,10 @@ public:
         static_assert(sizeof(rtx_defines) == sizeof(rt_defines), "rt_defines layout");
         std::memcpy(&d, &defines, sizeof d);
         rtx_shim::check(rtx_specialize(ctx, &d), "init_shaders");
+#ifdef RTX_SHIM_HAVE_SMAA_TABLES
+        if (SMAA_enabled)   // GLWrapper.cpp:251-270: areaTex = load_area_texture(), searchTex = load_search_texture()
+            rtx_shim::check(rtx_smaa_set_tables(ctx, areaTexBytes, AREATEX_WIDTH, AREATEX_HEIGHT, searchTexBytes, SEARCHTEX_WIDTH, SEARCHTEX_HEIGHT), "init_shaders (SMAA tables)");
+#endif
     }
 
     void set_skybox(unsigned int textureId)  // GLWrapper.cpp:135-141
@@ -187,7 +201,17 @@ public:
     }
 
     void stop() {}                           // GLWrapper.cpp:143-147: nothing to tear down before ~GLWrapper
-    void enable_SMAA(SMAA_PRESET) {}         // accepted, ignored
+    void enable_SMAA(SMAA_PRESET preset)     // GLWrapper.cpp:149-153; the reference calls it before init_window (main.cpp:32), here any time works
+    {
+        SMAA_enabled = true;
+        SMAA_preset = preset;
+        if (ctx) rtx_shim::check(rtx_enable_smaa(ctx, static_cast<int>(preset)), "enable_SMAA");
+    }
+    // extra: SMAA_Builder::load_area_texture / load_search_texture with caller-supplied bytes (160 x 560 RG8, 64 x 16 R8)
+    void set_SMAA_tables(const unsigned char* area_rg8, const unsigned char* search_r8)
+    {
+        rtx_shim::check(rtx_smaa_set_tables(ctx, area_rg8, 160, 560, search_r8, 64, 16), "set_SMAA_tables");
+    }
 
     GLFWwindow* window;
 
@@ -258,10 +282,10 @@ public:
 
     // glReadPixels stand-in: RTX_RGBA32F -> w*h*4 floats, RTX_RGBA8 -> w*h*4 bytes; row 0 = bottom
     void read_pixels(int format, void* dst, size_t bytes) { rtx_shim::check(rtx_read_pixels(ctx, format, dst, bytes), "read_pixels"); }
-    bool save_png(const char* path)   // the current frame (RGBA8, what the reference's framebuffer holds), top row first
+    bool save_png(const char* path)   // what the reference's window shows (RGBA8; after SMAA when that is enabled), top row first
     {
         std::vector<unsigned char> rgba(static_cast<size_t>(width) * static_cast<size_t>(height) * 4);
-        read_pixels(RTX_RGBA8, rgba.data(), rgba.size());
+        read_pixels(RTX_SCREEN_RGBA8, rgba.data(), rgba.size());
         return rtx_png::write_file(path, rgba.data(), width, height, 4, /*bottom_up=*/true);
     }
 
@@ -271,4 +295,6 @@ private:
     int height;
     bool fullScreen;
     bool useCustomResolution;
+    bool SMAA_enabled = false;
+    SMAA_PRESET SMAA_preset = ULTRA;
 };

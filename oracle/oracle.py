@@ -90,6 +90,9 @@ def lib():
     return _lib
 
 
+TAG_BOX_INSIDE, TAG_REFRACT, TAG_TORUS, TAG_TEXTURE, TAG_BOX_NAN, TAG_TIR, TAG_QUAD_DIVERGENT = 1, 2, 4, 8, 16, 32, 64   # ORC_TAG_* of rt_oracle.c
+
+
 class OracleScene:
     """Holds one frame description (blocks + textures) alive for orc_render calls."""
 
@@ -128,12 +131,25 @@ class OracleScene:
         self.frame = fr
         self.width, self.height = fb_width, fb_height
 
-    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0):
-        """Returns (float32 array (rows, W, 4), counters dict). Row 0 = bottom (gl_FragCoord)."""
+    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0, jitter=(0.0, 0.0), tags=None):
+        """Returns (float32 array (rows, W, 4), counters dict). Row 0 = bottom (gl_FragCoord).
+        jitter: diagnostic displacement of every primary ray (orc_set_ray_jitter), in units of the un-normalised view vector.
+        tags: optional (rows, W) uint32 array that receives the per-pixel ORC_TAG_* event bits (TAG_* below)."""
         y1 = self.height if y1 is None else y1
         out = np.empty((y1 - y0, self.width, 4), dtype=np.float32)
         cnt = Counters()
-        rc = lib().orc_render(ctypes.byref(self.frame), y0, y1, out.ctypes.data, ctypes.byref(cnt), threads)
+        l = lib()
+        l.orc_set_ray_jitter.argtypes = [ctypes.c_float, ctypes.c_float]
+        l.orc_set_tag_buffer.argtypes = [ctypes.c_void_p]
+        l.orc_set_ray_jitter(float(jitter[0]), float(jitter[1]))
+        if tags is not None:
+            assert tags.shape == (y1 - y0, self.width) and tags.dtype == np.uint32 and tags.flags.c_contiguous
+            l.orc_set_tag_buffer(tags.ctypes.data)
+        try:
+            rc = l.orc_render(ctypes.byref(self.frame), y0, y1, out.ctypes.data, ctypes.byref(cnt), threads)
+        finally:
+            l.orc_set_ray_jitter(0.0, 0.0)
+            l.orc_set_tag_buffer(None)
         if rc != 0:
             raise RuntimeError("orc_render failed")
         return out, cnt.as_dict()

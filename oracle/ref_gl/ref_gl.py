@@ -97,9 +97,12 @@ def _oracle_mip_chain(arr):
         L += 1
 
 
-def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube_mipmap: bool = False, oracle_mips: bool = False):
+def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube_mipmap: bool = False, oracle_mips: bool = False, level0_only: bool = False):
     """One frame of the reference's program. Returns (H, W, 4) float32, row 0 = bottom row, and the set of block
-    names the linked program does not contain (the reference would exit on those)."""
+    names the linked program does not contain (the reference would exit on those).
+    Diagnostics: oracle_mips uploads the oracle's mip levels instead of calling glGenerateMipmap (same texels on both sides, only the
+    level selection differs); level0_only uploads level 0 alone with GL_TEXTURE_MAX_LEVEL = 0, so that every fetch of the unchanged
+    shader -- texture() and textureLod() alike -- is a level-0 bilinear fetch (no implementation-defined mip machinery at all)."""
     l = lib()
     vert, frag = shader_sources(scene_blocks.defines)
     keep = []
@@ -123,8 +126,10 @@ def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube
         nm = uniform.encode()
         keep.append(nm)
         n_levels, lv = 0, None
-        if oracle_mips:
+        if oracle_mips or level0_only:
             chain = _oracle_mip_chain(arr)
+            if level0_only:
+                chain = chain[:1]
             keep.append(chain)
             lv = (ctypes.c_void_p * len(chain))(*[c.ctypes.data for c in chain])
             keep.append(lv)

@@ -196,7 +196,21 @@ typedef struct {
     int light_index;      /* which light calcShade is processing (part of the fetch key) */
     struct quad_s* quad;  /* NULL when texture_lod == 0 */
     int quad_slot;        /* 0..3: bit0 = x&1, bit1 = y&1 */
+    uint32_t tag;         /* diagnostic: ORC_TAG_* events of this pixel (orc_set_tag_buffer) */
 } inv_t;
+
+/* Per-pixel event tags (diagnostic output for tests/reference_classify.py: WHICH implementation-defined mechanism a pixel touched). */
+enum { ORC_TAG_BOX_INSIDE = 1,   /* intersectBox returned a negative distance (trap T21) */
+       ORC_TAG_REFRACT = 2,      /* a refraction segment was taken (i--, trap T2) */
+       ORC_TAG_TORUS = 4,        /* a Durand-Kerner root was accepted (closest-hit or shadow scan): the root is only good to the solver's 1e-3 stop */
+       ORC_TAG_TEXTURE = 8,      /* a 2-D texture was sampled (mip level selection, atan/asin uv) */
+       ORC_TAG_BOX_NAN = 16,     /* NaN through intersectBox (trap T5) */
+       ORC_TAG_TIR = 32,
+       ORC_TAG_QUAD_DIVERGENT = 64 };   /* a mip-mapped fetch for which a 2x2-quad neighbour did not execute the same fetch: GLSL leaves
+                                          derivatives undefined in non-uniform control flow (GLSL 4.50 section 8.13.1); the oracle's rule
+                                          takes that derivative as 0, llvmpipe differences whatever its masked-off lanes hold */
+static uint32_t* g_tag_buffer = NULL;   /* fb_width * rows uint32, or NULL */
+void orc_set_tag_buffer(uint32_t* p) { g_tag_buffer = p; }
 
 /* ---------------------------------------------------------------------------------------------
  * GLSL built-ins, restated
@@ -219,6 +233,11 @@ static inline vec3 normalize3(vec3 a) { return div3s(a, length3(a)); }
  * wording: min "returns y if y < x, otherwise x". Mode 1 is DIAGNOSTIC: the SSE minps/maxps behaviour of Mesa llvmpipe
  * (x < y ? x : y, i.e. the second operand when unordered), used only to show that the reference-on-llvmpipe frames of
  * degenerate scenes differ from the oracle in nothing but this choice (tools/fuzz_reference.py, orc_set_nan_minmax). */
+/* Diagnostic: add a constant to every level of detail before the mip levels are chosen. Level selection is the GL implementation's
+ * (its log2, its derivative estimates, its rounding: GL 4.5 section 8.14.1 allows a range); a reference pixel that lies between the
+ * oracle's pixels for lambda - b and lambda + b is reproduced by a level of detail within b of the oracle's. Normally 0. */
+static float g_lod_bias = 0.0f;
+void orc_set_lod_bias(float b) { g_lod_bias = b; }
 static int g_nan_minmax = 0;
 void orc_set_nan_minmax(int mode) { g_nan_minmax = mode; }
 static inline float gl_min(float a, float b) { return g_nan_minmax ? (a < b ? a : b) : (b < a ? b : a); }
@@ -548,6 +567,7 @@ static int key_cmp(const fetch_key* p, const fetch_key* q)
 /* texture fetch as seen by the pixel program */
 static vec4 tex_fetch(inv_t* iv, int slot, int site, int a, int b, int ptype, int pnum, vec2 uv, int mode)
 {
+    iv->tag |= ORC_TAG_TEXTURE;
     const orc_texture* t = &iv->fr->tex[slot];
     if (!iv->quad) return sample2d_level0(t, uv); /* texture_lod == 0 */
     quad_t* q = iv->quad;
@@ -576,6 +596,7 @@ static void quad_resolve(quad_t* q, const orc_frame* fr)
         vec2 ddx = v2(0.0f, 0.0f), ddy = v2(0.0f, 0.0f);
         if (in_set[kx]) { const quad_lane* r = &q->lane[k | 1]; const quad_lane* l = &q->lane[k & ~1]; ddx = v2(r->uv.x - l->uv.x, r->uv.y - l->uv.y); }
         if (in_set[ky]) { const quad_lane* tp = &q->lane[k | 2]; const quad_lane* bt = &q->lane[k & ~2]; ddy = v2(tp->uv.x - bt->uv.x, tp->uv.y - bt->uv.y); }
+        if (!in_set[kx] || !in_set[ky]) q->lane[k].iv.tag |= ORC_TAG_QUAD_DIVERGENT;
         const orc_texture* t = &fr->tex[key.slot];
         float lambda;
         if (q->lane[k].mode == LOD_EXPLICIT_SPHERE) {
@@ -594,6 +615,7 @@ static void quad_resolve(quad_t* q, const orc_frame* fr)
                 lambda = r2 > 0.0f ? 0.5f * ((float)(e - 1) + (2.0f * m - 1.0f)) : -1000.0f;
             }
         }
+        if (g_lod_bias != 0.0f) lambda += g_lod_bias;   /* diagnostic, see orc_set_lod_bias */
         res[k] = sample2d_lod(t, q->lane[k].uv, lambda);
     }
     for (int k = 0; k < 4; k++)
@@ -634,10 +656,20 @@ static inline vec3 rotate(vec4 qr, vec3 v) /* :305-311 */
     return v3(r.x, r.y, r.z);
 }
 
+/* Diagnostic for the pin against a real GL implementation (tests/reference_classify.py): displace every primary ray by (jx, jy) in
+ * the units of the un-normalised view vector (1 / canvas_height = one pixel). A GL implementation is free to evaluate normalize(),
+ * dot() and the intersectors with other roundings, fused or reordered; at a pixel where a hit/miss, root-selection or branch decision
+ * is within rounding of flipping, the reference's own output is implementation-defined. Such pixels are found by asking whether a
+ * displacement of a few ulp changes the oracle's own answer. Normally (0, 0). */
+static float g_ray_jitter[2] = {0.0f, 0.0f};
+void orc_set_ray_jitter(float jx, float jy) { g_ray_jitter[0] = jx; g_ray_jitter[1] = jy; }
+
 static vec3 getRayDir(const inv_t* iv) /* :313-317 */
 {
     float cw = (float)iv->scene->canvas_width, ch = (float)iv->scene->canvas_height;
     vec3 result = v3((iv->frag_x - cw / 2.0f) / ch, (iv->frag_y - ch / 2.0f) / ch, 1.0f);
+    if (g_ray_jitter[0] != 0.0f) result.x += g_ray_jitter[0];
+    if (g_ray_jitter[1] != 0.0f) result.y += g_ray_jitter[1];
     return normalize3(rotate(iv->scene->quat_camera_rotation, result));
 }
 
@@ -717,6 +749,9 @@ static int intersectBox(inv_t* iv, vec3 ro, vec3 rd, int num, float tmin, float*
     vec3 t2 = add3(neg3(n), k);
     float tN = gl_max(gl_max(t1.x, t1.y), t1.z);
     float tF = gl_min(gl_min(t2.x, t2.y), t2.z);
+    /* a NaN operand (0 * inf for an axis-parallel ray, trap T5) entered the min / max chains: GLSL leaves min/max of a NaN undefined,
+     * and whether this box is hit, missed or hit at another distance is the implementation's choice -- also when the result is finite */
+    if (t1.x != t1.x || t1.y != t1.y || t1.z != t1.z || t2.x != t2.x || t2.y != t2.y || t2.z != t2.z) iv->tag |= ORC_TAG_BOX_NAN;
     if (tN > tF || tF < 0.0f) return 0;
     if (tN >= tmin) return 0;
     vec3 nor;
@@ -725,8 +760,8 @@ static int intersectBox(inv_t* iv, vec3 ro, vec3 rd, int num, float tmin, float*
     nor.z = -gl_sign(rdd.z) * gl_step(t1.x, t1.z) * gl_step(t1.y, t1.z);
     *t = tN;
     iv->opt_normal = rotate(quat_inv(box->quat_rotation), nor);
-    if (!(tN == tN)) iv->cnt->box_nan_hits++;
-    else if (tN < 0.0f) iv->cnt->box_inside_hits++;
+    if (!(tN == tN)) { iv->cnt->box_nan_hits++; iv->tag |= ORC_TAG_BOX_NAN; }
+    else if (tN < 0.0f) { iv->cnt->box_inside_hits++; iv->tag |= ORC_TAG_BOX_INSIDE; }
     return 1;
 }
 static vec4 getBoxTexture(inv_t* iv, vec3 pt, vec3 normal, int num) /* :428-436 */
@@ -893,7 +928,7 @@ static float calcInter(inv_t* iv, vec3 ro, vec3 rd, int* num, int* type) /* :587
     }
     for (i = 0; i < iv->TORUS_SIZE; i++) {
         iv->cnt->tests[TYPE_TORUS]++;
-        if (intersectTorus(iv, ro, rd, i, tmin, &t)) { *num = i; tmin = t; *type = TYPE_TORUS; }
+        if (intersectTorus(iv, ro, rd, i, tmin, &t)) { *num = i; tmin = t; *type = TYPE_TORUS; iv->tag |= ORC_TAG_TORUS; }
     }
     for (i = 0; i < iv->RING_SIZE; i++) {
         iv->cnt->tests[TYPE_RING]++;
@@ -926,7 +961,7 @@ static float inShadow(inv_t* iv, vec3 ro, vec3 rd, float dist) /* :630-658 */
     }
     for (i = 0; i < iv->TORUS_SIZE; i++) {
         iv->cnt->tests[TYPE_TORUS]++;
-        if (intersectTorus(iv, ro, rd, i, dist, &t)) shadow = 1.0f;
+        if (intersectTorus(iv, ro, rd, i, dist, &t)) { shadow = 1.0f; iv->tag |= ORC_TAG_TORUS; }
     }
     for (i = 0; i < iv->RING_SIZE; i++) {
         iv->cnt->tests[TYPE_RING]++;
@@ -1136,10 +1171,11 @@ static vec4 shade_pixel(inv_t* iv) /* main(), :804-902 */
                     vec3 absorb = v3(expf(-mat.absorb.x * absorbDistance), expf(-mat.absorb.y * absorbDistance), expf(-mat.absorb.z * absorbDistance));
                     mask = mul3(mask, absorb);
                 }
-                if (reflectMultiplier >= 1.0f) { iv->cnt->tir_breaks++; break; }
+                if (reflectMultiplier >= 1.0f) { iv->cnt->tir_breaks++; iv->tag |= ORC_TAG_TIR; break; }
                 ro = sub3(pt, scale3(n, hr.bias_mult));
                 rd = gl_refract(rd, n, outside ? 1.0f / mat.refraction : mat.refraction);
                 iv->cnt->refract_segments++;
+                iv->tag |= ORC_TAG_REFRACT;
                 i--; /* REFLECT_REDUCE_ITERATION is defined (:22,870-872; trap T2) */
             } else if (mat.reflection > 0.0f) { /* reflective :874-880 */
                 ro = add3(pt, scale3(n, hr.bias_mult));
@@ -1234,6 +1270,7 @@ static void render_quad(quad_t* q, const inv_t* base, const orc_frame* fr, int q
         L->iv.quad = q;
         L->iv.quad_slot = k;
         L->iv.step = 0;
+        L->iv.tag = 0;
         L->iv.frag_x = (float)x + 0.5f;
         L->iv.frag_y = (float)y + 0.5f;
         getcontext(&L->ctx);
@@ -1267,6 +1304,7 @@ static void render_quad(quad_t* q, const inv_t* base, const orc_frame* fr, int q
             float* o = out_rgba + ((size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x) * 4;
             const vec4 c = q->lane[k].color;
             o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+            if (g_tag_buffer) g_tag_buffer[(size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x] = q->lane[k].iv.tag;
         }
     }
 }
@@ -1304,9 +1342,11 @@ int orc_render(const orc_frame* fr, int y0, int y1, float* out_rgba, orc_counter
                     iv.frag_x = (float)x + 0.5f;
                     iv.frag_y = (float)y + 0.5f;
                     iv.step = 0;
+                    iv.tag = 0;
                     vec4 c = shade_pixel(&iv);
                     float* o = out_rgba + ((size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x) * 4;
                     o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+                    if (g_tag_buffer) g_tag_buffer[(size_t)(y - y0) * (size_t)fr->fb_width + (size_t)x] = iv.tag;
                 }
             }
         } else {

@@ -57,6 +57,11 @@ CASES = {
 # level) instead of glGenerateMipmap, so that only level selection and filtering are compared. Checked with the oracle in
 # its llvmpipe-LOD mode (texture_lod = 2): what is left is llvmpipe's atan/asin approximation on the planets + silhouettes.
 SAME_MIPS = ("default_same_mips", 0.025, 0.008)   # name, max fraction > 1e-4, > 1e-2
+# Variants of the two textured cases (same scene blocks and textures, different GL texture state; oracle/ref_gl/ref_gl.py):
+#   <case>_same_mips : GL was given the oracle's mip texels -> compared with the oracle in its llvmpipe LOD mode (texture_lod = 2)
+#   <case>_level0    : GL was given level 0 only (GL_TEXTURE_MAX_LEVEL = 0) -> compared with the oracle at texture_lod = 0
+TEXTURED = ("default", "trap_degenerate_rings")
+VARIANTS = {f"{c}_{v}": (c, v) for c in TEXTURED for v in ("same_mips", "level0")}
 
 
 def texture_set():
@@ -92,6 +97,10 @@ def load(name):
         raise RuntimeError(f"inputs of reference frame '{name}' no longer reproduce (textures.py changed?)")
     return dict(scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
                 frame=z["frame"], limits=CASES[name][2] if name in CASES else SAME_MIPS[1:], renderer=str(z["renderer"]))
+
+
+def textured(name) -> bool:
+    return CASES[name][1] if name in CASES else True
 
 
 def compare(candidate, reference_rgb):

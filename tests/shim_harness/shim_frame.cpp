@@ -3,7 +3,7 @@
 // A main.cpp-shaped program (reference src/main.cpp:23-195 without GLFW): GLWrapper, enable_SMAA, init_window, scene through
 // SceneManager::create_* (scene_recipes.h), init_shaders, load_cubemap / load_texture FROM IMAGE FILES (decoded by the shim's
 // own PNG / JPEG readers), SceneManager::init, one update + the per-frame texture binds + draw. It then dumps the frame three
-// ways -- RGBA32F raw, RGBA8 raw, save_png -- for tests/test_gpu_widened.py to compare with the oracle. Run with the current
+// ways -- RGBA32F raw, RGBA8 raw, save_png (and the SMAA screen when smaa = 1, with tables read from smaa_area.bin / smaa_search.bin) -- for tests/test_gpu_widened.py to compare with the oracle. Run with the current
 // directory holding textures/{sky0..5.png,t1.jpg,t2.jpg,t3.jpg,ring.png,box.png} (ASSETS_DIR defaults to ".").
 //   shim_frame W H depth time delta yaw pitch smaa(0/1) out_prefix
 #include <cstdio>
@@ -38,6 +38,16 @@ int main(int argc, char** argv)
     GLWrapper glWrapper(W, H, false);
     if (smaa) glWrapper.enable_SMAA(ULTRA);          // main.cpp:32
     if (!glWrapper.init_window()) return 1;
+    std::vector<unsigned char> area(160 * 560 * 2), search(64 * 16);
+    if (smaa) {   // the tables are not part of this repository: the test supplies them as files
+        FILE* fa = std::fopen("smaa_area.bin", "rb");
+        FILE* fs = std::fopen("smaa_search.bin", "rb");
+        const bool ok_t = fa && fs && std::fread(area.data(), 1, area.size(), fa) == area.size() && std::fread(search.data(), 1, search.size(), fs) == search.size();
+        if (fa) std::fclose(fa);
+        if (fs) std::fclose(fs);
+        if (!ok_t) { std::fprintf(stderr, "smaa_area.bin / smaa_search.bin missing\n"); return 4; }
+        glWrapper.set_SMAA_tables(area.data(), search.data());
+    }
 
     scene_container scene = {};
     scene_recipes::anim_slots slots = scene_recipes::build_default(scene, W, H, depth);
@@ -72,6 +82,11 @@ int main(int argc, char** argv)
     glWrapper.read_pixels(RTX_RGBA32F, f32.data(), f32.size() * sizeof(float));
     glWrapper.read_pixels(RTX_RGBA8, u8.data(), u8.size());
     bool ok = dump(out + ".f32", f32.data(), f32.size() * sizeof(float)) && dump(out + ".u8", u8.data(), u8.size());
+    if (smaa) {
+        std::vector<unsigned char> screen(px * 4);
+        glWrapper.read_pixels(RTX_SCREEN_RGBA8, screen.data(), screen.size());
+        ok = dump(out + ".screen", screen.data(), screen.size()) && ok;
+    }
     ok = glWrapper.save_png((out + ".png").c_str()) && ok;
     glWrapper.stop();
     return ok ? 0 : 3;

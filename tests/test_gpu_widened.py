@@ -126,6 +126,26 @@ def test_cpp_shim_program_renders_the_oracles_frame(built, tmp_path, w, h, kw):
     assert np.array_equal(png[::-1], img8)
 
 
+def test_cpp_shim_program_with_smaa(built, tmp_path):
+    """main.cpp's own order -- enable_SMAA(ULTRA) before init_window (main.cpp:32-34) -- through the C++ shim: the screen it reads back
+    and the PNG it saves are the oracle's SMAA of the RGBA8 frame it traced."""
+    import smaa_tables
+    from oracle import smaa
+    d, tex, cube = _asset_dir(tmp_path)
+    area, search = smaa_tables.area_table(), smaa_tables.search_table()
+    (tmp_path / "smaa_area.bin").write_bytes(area.tobytes())
+    (tmp_path / "smaa_search.bin").write_bytes(search.tobytes())
+    w, h, depth = 322, 182, 4
+    out = tmp_path / "frame"
+    subprocess.run([SHIM, str(w), str(h), str(depth), "3.5", "0.01", "20.0", "-3.0", "1", str(out)], check=True, cwd=d, timeout=300)
+    img8 = np.fromfile(str(out) + ".u8", np.uint8).reshape(h, w, 4)
+    screen = np.fromfile(str(out) + ".screen", np.uint8).reshape(h, w, 4)
+    want = smaa.run(img8, "ULTRA", area, search)["screen"]
+    assert np.array_equal(screen, want)
+    assert np.array_equal(_decode(str(out) + ".png")[::-1], screen)
+    assert (screen != img8).any()
+
+
 def test_rgba8_target_is_the_exact_quantisation_of_the_float_target(mid_textures):
     """a21: both targets come from one launch; the 8-bit one must be clamp/round of the very same floats, not +-1 LSB."""
     for kind, w, h, depth in [("default", 960, 540, 4), ("quadric", 333, 207, 4), ("torus", 320, 180, 6)]:

@@ -28,13 +28,15 @@ def main():
     ts = rf.texture_set()
     only = sys.argv[1:]
     cases = dict(rf.CASES)
-    cases[rf.SAME_MIPS[0]] = (rf.CASES["default"][0], True, rf.SAME_MIPS[1:])
+    for vname, (case, _variant) in rf.VARIANTS.items():
+        cases[vname] = (rf.CASES[case][0], True, rf.SAME_MIPS[1:])
     for name, (build, textured, limits) in cases.items():
         if only and name not in only:
             continue
         sc = build()
-        same_mips = name == rf.SAME_MIPS[0]
-        ref, inactive = ref_gl.render(sc, rf.W, rf.H, ts["textures"], ts["cubemap"], oracle_mips=same_mips)
+        same_mips = name.endswith("_same_mips")
+        level0 = name.endswith("_level0")
+        ref, inactive = ref_gl.render(sc, rf.W, rf.H, ts["textures"], ts["cubemap"], oracle_mips=same_mips, level0_only=level0)
         arrays = dict(width=rf.W, height=rf.H, frame=np.ascontiguousarray(ref[..., :3]), digest=rf.input_digest(sc, ts),
                       renderer=ref_gl.renderer() + " GALLIVM_PERF=" + os.environ["GALLIVM_PERF"], tex_scale=rf.TEX_SCALE,
                       defines=np.asarray(sc.defines, dtype=np.float64), inactive_blocks=",".join(sorted(inactive)))
@@ -42,7 +44,7 @@ def main():
             if sc.blocks.get(n):
                 arrays["block_" + n] = np.frombuffer(sc.blocks[n], dtype=np.uint8)
         np.savez_compressed(rf.path(name), **arrays)
-        img, _ = oracle.OracleScene(sc, rf.W, rf.H, ts["textures"], ts["cubemap"], texture_lod=2 if same_mips else 1).render(0, rf.H, threads=os.cpu_count() or 1)
+        img, _ = oracle.OracleScene(sc, rf.W, rf.H, ts["textures"], ts["cubemap"], texture_lod=2 if same_mips else (0 if level0 else 1)).render(0, rf.H, threads=os.cpu_count() or 1)
         f4, f2, mx = rf.compare(img, ref[..., :3])
         assert np.all(ref[..., 3] == 1.0)
         print(f"{name:34s} oracle vs reference: {100*f4:7.3f}% of pixels > 1e-4, {100*f2:7.3f}% > 1e-2, max {mx:.3g}   "
