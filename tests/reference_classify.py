@@ -46,6 +46,9 @@ EDGE_TOL = 1e-3
 APPROX_TOL = 5e-4    # llvmpipe's pow / exp are polynomial approximations: pow(x, 200) of a specular term is good to ~1e-3 of its value
 
 
+_PROBES = {}   # per fixture and LOD mode: the oracle's frame, its event tags and its instability mask (shared by the oracle / host / GPU tests)
+
+
 def _diff(a, b):
     d = np.abs(a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)).max(-1)
     return np.where(np.isnan(d), np.inf, d)
@@ -56,15 +59,12 @@ def classify(ref: dict, candidate: np.ndarray | None = None, texture_lod: int = 
     tex_tol: bound for pixels of the `texture` category (0 = none may differ). Returns counts per category and `unexplained`
     (must be 0) with up to 8 (x, y, difference, tags)."""
     w, h = ref["width"], ref["height"]
-    O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod)
-    tags = np.zeros((h, w), np.uint32)
-    base, _ = O.render(threads=threads, tags=tags)
-    img = base if candidate is None else candidate
-    d = _diff(img, ref["frame"])
-    bad = d > TOL
-    out = dict(pixels=w * h, over=int(bad.sum()), max=float(d.max()))
-    unstable = np.zeros_like(bad)
-    if bad.any():
+    key = (id(ref["frame"]), ref.get("name"), texture_lod)
+    if key not in _PROBES:
+        O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod)
+        tags = np.zeros((h, w), np.uint32)
+        base, _ = O.render(threads=threads, tags=tags)
+        unstable = np.zeros((h, w), bool)
         for px, tol in [(p, STABLE_TOL + GRADIENT * p) for p in JITTER_PX] + [(p, JUMP_TOL) for p in JUMP_PX]:
             dj = px / h
             for jx, jy in itertools.product((-dj, 0.0, dj), repeat=2):
@@ -72,6 +72,12 @@ def classify(ref: dict, candidate: np.ndarray | None = None, texture_lod: int = 
                     continue
                 ij, _ = O.render(threads=threads, jitter=(jx, jy))
                 unstable |= _diff(ij, base) > tol
+        _PROBES[key] = (base, tags, unstable, ref["frame"])     # (the frame is kept so that its id stays unique)
+    base, tags, unstable, _ = _PROBES[key]
+    img = base if candidate is None else candidate
+    d = _diff(img, ref["frame"])
+    bad = d > TOL
+    out = dict(pixels=w * h, over=int(bad.sum()), max=float(d.max()))
     left = bad & ~unstable
     out["unstable"] = int((bad & unstable).sum())
     out["unstable_pixels_in_frame"] = int(unstable.sum())

@@ -85,8 +85,13 @@ def path(name):
     return os.path.join(GOLDEN, f"ref_frame_{name}.npz")
 
 
+_LOADED = {}
+
+
 def load(name):
     """-> dict(scene, textures, cubemap, frame (H,W,3 float32, row 0 = bottom), limits, renderer)"""
+    if name in _LOADED:
+        return _LOADED[name]
     z = np.load(path(name))
     d = z["defines"]
     defines = tuple(int(v) for v in d[:9]) + tuple(float(np.float32(v)) for v in d[9:15])
@@ -95,8 +100,9 @@ def load(name):
     ts = texture_set()
     if input_digest(sc, ts) != str(z["digest"]):
         raise RuntimeError(f"inputs of reference frame '{name}' no longer reproduce (textures.py changed?)")
-    return dict(scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
-                frame=z["frame"], limits=CASES[name][2] if name in CASES else SAME_MIPS[1:], renderer=str(z["renderer"]))
+    _LOADED[name] = dict(name=name, scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
+                         frame=z["frame"], limits=CASES[name][2] if name in CASES else SAME_MIPS[1:], renderer=str(z["renderer"]))
+    return _LOADED[name]
 
 
 def textured(name) -> bool:
