@@ -9,9 +9,9 @@ tests/test_gpu_parity.py) and is measured once, untimed, with the counting kerne
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into
 interleaved row bands (raytracing_opengl_amd/bands.py), every rank traces its bands, and the frame
-is gathered to rank 0 over RCCL each step -> "scaling": "strong". The gathered frame is RGBA8 by default --
-the format of the reference's framebuffer (GLWrapper.cpp:127,209-222); the trace itself is the same f32
-computation (--target rgba32f gathers the 16 B/pixel parity buffer instead: 4x the xGMI traffic).
+is gathered to rank 0 over RCCL each step -> "scaling": "strong". The target is the same at every N (default: the RGBA32F
+parity buffer the metric is defined on; --target rgba8 traces and gathers what the reference's framebuffer holds,
+GLWrapper.cpp:127,209-222, a quarter of the bytes), so a 1/2/4/8 series is one workload.
 
 Extra objects on the JSON line:
   roofline     HBM-write roofline of the trace kernel: W*H*16 B of RGBA32F per launch / mean kernel
@@ -19,6 +19,7 @@ Extra objects on the JSON line:
                (VALU instructions per launch from profiles/valu.json / live duration vs the chip's issue rate).
   cpu_baseline the oracle (scalar C restatement of the shader, all host cores) timed on one full
                frame of the same workload, rank 0, N = 1 only.
+  smaa         the SMAA post-process on the traced frame: time of one resolve and its HBM roofline (untimed addition).
 """
 from __future__ import annotations
 
@@ -54,9 +55,11 @@ def main():
     ap.add_argument("--cull", type=int, default=1)
     ap.add_argument("--xcd", type=int, default=0, help="1: XCD-aware super-tile workgroup order; 0: row-major")
     ap.add_argument("--lod", type=int, default=1, help="1: mip chain + quad-derivative LOD (reference texture state); 0: level-0 bilinear")
-    ap.add_argument("--target", choices=("auto", "rgba32f", "rgba8"), default="auto",
-                    help="colour target the bands are traced into and gathered as. auto: rgba32f (the parity buffer) on one GPU, "
-                         "rgba8 -- what the reference's framebuffer holds (GLWrapper.cpp:127,209-222) -- for N > 1")
+    ap.add_argument("--target", choices=("rgba32f", "rgba8"), default="rgba32f",
+                    help="colour target the bands are traced into and gathered as -- the SAME at every N, so that a 1/2/4/8 series is one "
+                         "workload: rgba32f (default) = the 16 B/pixel parity buffer of the BASELINE metric; rgba8 = what the reference's "
+                         "framebuffer holds (GLWrapper.cpp:127,209-222), a quarter of the gather traffic")
+    ap.add_argument("--no-smaa", action="store_true", help="skip the untimed SMAA post-process measurement (N = 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,7 +87,7 @@ def main():
     gl.set_option(wrapper.RTX_OPT_XCD_REMAP, args.xcd)
 
     band_rows = ((H + 7) // 8) * 8 if world == 1 else bands.choose_band_rows(H, world)
-    target = args.target if args.target != "auto" else ("rgba32f" if world == 1 else "rgba8")
+    target = args.target
     tgt_dtype, tgt_format, px_bytes = (torch.float32, wrapper.RTX_RGBA32F, 16) if target == "rgba32f" else (torch.uint8, wrapper.RTX_RGBA8, 4)
     gather = bands.FrameGather(H, W, 4, band_rows, tgt_dtype, device, dst=0)
     bufs = [gather.new_local(tgt_dtype, device) for _ in range(2)]
@@ -174,24 +177,62 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "note": f"HBM-write roofline of the {target.upper()} frame ({px_bytes} B/pixel); the path is bound by VALU issue, see roofline.valu and DESIGN.md"},
         }
-        # The kernel's real ceiling is VALU issue, which the bound/peak vocabulary above cannot name: report it beside.
-        valu_file = os.path.join(ROOT, "profiles", "valu.json")
-        if os.path.exists(valu_file) and world == 1 and (W, H, args.depth, args.scene, args.cull, args.lod) == (WIDTH, HEIGHT, DEPTH, SCENE, 1, 1):
+        # The kernel's real ceiling is VALU issue, which the bound/peak vocabulary above cannot name: report it beside. The instruction and
+        # traffic counts come from rocprofv3 PMC passes (tools/profile_gpu.sh -> tools/prof_to_json.py); they are quoted only while the
+        # kernel sources they were measured on are the ones running (kernel_hash), and the peak is the measured issue rate of
+        # tools/micro/valu_rate.hip (profiles/valu_peak.json), not a nominal figure.
+        from raytracing_opengl_amd import build_info
+        khash = build_info.kernel_source_hash()
+        suffix = "" if args.scene == "default" else "_" + args.scene
+
+        def prof(name):
+            f = os.path.join(ROOT, "profiles", f"{name}{suffix}.json")
             try:
-                v = json.load(open(valu_file))
+                v = json.load(open(f))
+            except Exception:
+                return None
+            if v.get("kernel_hash") != khash or (v.get("width"), v.get("height"), v.get("depth")) != (W, H, args.depth):
+                return None          # measured on other sources or another workload: stale, not reported
+            return v
+        if world == 1 and (args.cull, args.lod, args.lds, args.xcd) == (1, 1, 0, 0):
+            v = prof("valu")
+            try:
+                peak = json.load(open(os.path.join(ROOT, "profiles", "valu_peak.json")))
+            except Exception:
+                peak = None
+            if v and peak:
                 rate = v["valu_insts_per_launch"] / (kernel_ms * 1e-3)
-                out["roofline"]["valu"] = {"insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1),
-                                           "peak": round(v["peak_wave_insts_per_s"] / 1e9, 1), "unit": "G wave-instructions/s",
-                                           "frac": round(rate / v["peak_wave_insts_per_s"], 4), "lane_utilisation": v["lane_utilisation"],
-                                           "note": "instruction count from rocprofv3 PMC (profiles/valu.json), duration live"}
-            except Exception:
-                pass
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file) and world == 1 and (W, H, args.depth, args.scene) == (WIDTH, HEIGHT, DEPTH, SCENE):
-            try:
-                out["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                out["roofline"]["valu"] = {
+                    "insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1), "unit": "G wave-instructions/s",
+                    "peak": peak["simple_op_peak_G_per_s"], "frac": round(rate / 1e9 / peak["simple_op_peak_G_per_s"], 4),
+                    "peak_fma_class": peak["fma_class_peak_G_per_s"], "frac_of_fma_class": round(rate / 1e9 / peak["fma_class_peak_G_per_s"], 4),
+                    "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "valu_pipe_busy": v.get("valu_pipe_busy"),
+                    "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash,
+                    "note": "instruction count and pipe-busy from rocprofv3 PMC on these kernel sources (" + v.get("source", "") + "), duration live; "
+                            "peaks = measured issue rates of v_add/v_mul-class and v_fma/v_cmp/v_max-class instructions (" + peak.get("source", "") + ")"}
+            t = prof("traffic")
+            if t:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / float(W * H * px_bytes), 3)
+        if world == 1 and not args.no_smaa:
+            # the post-process that follows the tracer in the reference's draw(). Untimed addition to the line: ULTRA (main.cpp:32)
+            # on the frame just traced, HIP events around the four kernels of one resolve. Algorithmic bytes: W*H*4 read + W*H*4 written.
+            from raytracing_opengl_amd import smaa_tables
+            gl.enable_SMAA(wrapper.ULTRA)
+            gl.set_smaa_tables(smaa_tables.area_table(), smaa_tables.search_table())
+            gl.draw()
+            ts_ms = []
+            for _ in range(12):
+                gl.smaa_resolve()
+                ts_ms.append(gl.stats()["last_smaa_ms"])
+            sm = gl.stats()
+            smaa_ms = float(np.median(ts_ms[2:]))
+            gl.enable_SMAA(wrapper.RTX_SMAA_OFF)
+            out["smaa"] = {"preset": "ULTRA", "ms_per_resolve": round(smaa_ms, 4), "edge_pixels": int(sm["smaa_edge_pixels"]),
+                           "roofline": {"bound": "hbm", "achieved": round(W * H * 8 / smaa_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(W * H * 8 / smaa_ms / 1e6 / HBM_PEAK_GBS, 4)},
+                           "note": "all four kernels of one resolve of the traced frame (RGBA8 in, RGBA8 screen out); synthetic area table, "
+                                   "search table from its definition; byte-exact against the oracle in tests/test_gpu_smaa.py"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod)
