@@ -6,6 +6,9 @@
 // launch on the context's stream, bracketed by HIP events for the per-draw time.
 // There is no CPU fallback: without a usable HIP device rtx_create fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen-ed when a multi-device context asks for it
+
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -19,6 +22,7 @@
 #include "rt_kernel.h"
 #include "rt_pack.h"
 #include "smaa_kernel.h"
+#include "bands_kernel.h"
 
 using namespace rtdev;
 
@@ -112,6 +116,21 @@ struct rtx_context {
     uint8_t* d_search = nullptr;
     hipEvent_t smaa_start = nullptr, smaa_stop = nullptr;
     bool smaa_timed = false;
+    // multi-device (rtx_create_multi): the context the caller holds is rank 0 (the root, which owns the assembled frame); `peers` are
+    // the contexts of ranks 1..N-1, ordinary single-device contexts that every scene / texture / option call is forwarded to.
+    std::vector<rtx_context*> peers;
+    rtx_context* owner = nullptr;      // set on a peer: its root
+    int gather_kind = RTX_GATHER_RCCL;
+    int band_rows = 0;                 // rows per band of the interleaved split
+    void* d_packed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [format][frame parity] this rank's packed bands, on its own device
+    std::vector<void*> d_stage[2][2];  // root only: [format][frame parity][rank] landing buffers for the peers' bands, on the root's device
+    ncclComm_t comm = nullptr;
+    hipStream_t gather_stream = nullptr;   // root only: receives + band placement run here, beside the next frame's trace
+    hipEvent_t traced[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
+    unsigned frame_no = 0;
+    float last_gather_ms = 0.0f;
+    hipEvent_t gather_start = nullptr, gather_stop = nullptr;
+    bool gather_timed = false;
     // timing
     hipEvent_t ev_start[EVENT_RING], ev_stop[EVENT_RING];
     int ev_head = 0, ev_pending = 0;
