@@ -43,8 +43,11 @@ if valu["active_inst_valu_quad_cycles"]:
     valu["lane_utilisation"] = round(valu["thread_cycles_valu"] / (64.0 * valu["active_inst_valu_quad_cycles"]), 4)
     valu["cycles_per_valu_inst"] = round(4.0 * valu["active_inst_valu_quad_cycles"] / valu["valu_insts_per_launch"], 3)
 if valu["grbm_gui_active"]:
-    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; the chip has 1024 SIMDs, each busy for at most GRBM_GUI_ACTIVE cycles
-    valu["valu_pipe_busy"] = round(4.0 * valu["active_inst_valu_quad_cycles"] / (1024.0 * valu["grbm_gui_active"]), 4)
+    # SQ_ACTIVE_INST_VALU: quad-cycles (4 shader cycles) with a VALU instruction in flight, summed over the 1024 SIMDs; GRBM_GUI_ACTIVE:
+    # busy cycles summed over the 8 XCDs. busy = VALU-active time per SIMD / kernel time. (Comes out a few per cent above 1 on a saturated
+    # pipe -- the two counters' units are nominal -- and is reported as measured.)
+    valu["valu_pipe_busy"] = round(4.0 * valu["active_inst_valu_quad_cycles"] / 1024.0 / (valu["grbm_gui_active"] / 8.0), 4)
+    valu["shader_clock_GHz"] = round(valu["grbm_gui_active"] / 8.0 / (stamp["kernel_us_rocprof"] * 1e3), 3) if stamp["kernel_us_rocprof"] else None
 json.dump(valu, open(os.path.join(ROOT, "profiles", f"valu{suffix}.json"), "w"), indent=1)
 fetch_kb, write_kb = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)
 traffic = dict(stamp, hbm_bytes_per_launch=int((fetch_kb + write_kb) * 1024), fetch_size_kb=round(fetch_kb, 1), write_size_kb=round(write_kb, 1),
