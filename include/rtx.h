@@ -83,6 +83,8 @@ typedef enum rtx_option {
     RTX_OPT_HOT_ROWS_FIRST = 6, /* 1 (default): in rtx_draw_bands launches that cover a quarter of the frame or less (band_stride >= 4)
                                 the workgroup rows that show a torus -- tiles that run ~20x the median -- are dispatched first, so
                                 that they do not form the tail of the launch; 0: plain row order. Same results either way. */
+    RTX_OPT_GATHER_TARGETS = 7, /* multi-device contexts: which colour targets travel to the root each draw: 1 = RGBA32F only, 2 = RGBA8
+                                only (what the reference's framebuffer holds: a quarter of the bytes), 3 (default) = both */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which register budget of the trace kernel runs: 0 = 6 waves/SIMD,
                                 1 = 7 waves/SIMD (spills to scratch, hides the scalar table walks of scenes with many
                                 primitives), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
@@ -96,6 +98,7 @@ typedef struct rtx_stats {
     uint64_t rays_shadow_cast; /*   shadow scans the kernel actually executed (dp > 0 only) */
     uint64_t torus_solves;     /*   Durand-Kerner solves actually run */
     float last_smaa_ms;        /* HIP-event time of the last SMAA resolve (all of its kernels), 0 if none ran */
+    float last_gather_ms;      /* multi-device contexts: transfer + band placement of the last frame on the root (0 otherwise) */
     uint32_t smaa_edge_pixels; /* pixels with an edge in the last resolve (the sparse passes' work list) */
 } rtx_stats;
 
@@ -106,6 +109,15 @@ RTX_API const char* rtx_version(void);
  * Creates the device context and the w x h colour target on HIP device `device`.
  * The new context becomes current (see rtx_current). */
 RTX_API int rtx_create(int width, int height, int device, rtx_context** out);
+/* The same on N devices of one node (BASELINE north_star: "GLWrapper dispatch -> HIP launch + RCCL tile gather"). The
+ * context returned is used exactly like a single-device one: blocks, textures and options are replicated to every device, rtx_draw
+ * splits the frame into interleaved 8-row bands (band b -> device b mod N), every device traces its bands, and the root (device_ids[0])
+ * receives them and assembles the colour targets that rtx_read_pixels / the SMAA resolve see. `gather`: how the bands reach the root --
+ * RTX_GATHER_RCCL: one grouped ncclSend/ncclRecv pair per peer (librccl.so is loaded at this call; one device per rank);
+ * RTX_GATHER_PEER_COPY: hipMemcpyPeerAsync by the root (no library; ranks may share a device). n_devices = 1 is a plain context. */
+typedef enum rtx_gather { RTX_GATHER_RCCL = 0, RTX_GATHER_PEER_COPY = 1 } rtx_gather;
+RTX_API int rtx_create_multi(int width, int height, int n_devices, const int* device_ids, int gather, rtx_context** out);
+RTX_API int rtx_device_count(rtx_context* ctx, int* n_devices);
 /* GLWrapper::~GLWrapper / stop()  [GLWrapper.cpp:25-44,143-147] */
 RTX_API void rtx_destroy(rtx_context* ctx);
 /* The reference's update_buffer / load_cubemap are static and act on "the current GL context";

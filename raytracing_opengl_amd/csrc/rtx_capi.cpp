@@ -120,15 +120,16 @@ struct rtx_context {
     // the contexts of ranks 1..N-1, ordinary single-device contexts that every scene / texture / option call is forwarded to.
     std::vector<rtx_context*> peers;
     rtx_context* owner = nullptr;      // set on a peer: its root
+    int rank = 0;
     int gather_kind = RTX_GATHER_RCCL;
-    int band_rows = 0;                 // rows per band of the interleaved split
-    void* d_packed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [format][frame parity] this rank's packed bands, on its own device
-    std::vector<void*> d_stage[2][2];  // root only: [format][frame parity][rank] landing buffers for the peers' bands, on the root's device
+    int gather_targets = 3;            // bit 0: RGBA32F, bit 1: RGBA8 travel to the root (RTX_OPT_GATHER_TARGETS)
+    int band_rows = 8;                 // rows per band of the interleaved split: the kernel's tile height, the finest interleave
+    void* d_packed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [target][frame parity] this rank's packed bands, on its own device
+    std::vector<void*> d_stage[2][2];  // root only: [target][frame parity][rank] landing buffers for the peers' bands, on the root's device
     ncclComm_t comm = nullptr;
-    hipStream_t gather_stream = nullptr;   // root only: receives + band placement run here, beside the next frame's trace
-    hipEvent_t traced[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
+    hipStream_t xfer_stream = nullptr; // sends (peers) / receives + band placement (root) run here, beside the next frame's trace
+    hipEvent_t traced[2] = {nullptr, nullptr}, moved[2] = {nullptr, nullptr};   // per frame parity: bands traced / buffers free again
     unsigned frame_no = 0;
-    float last_gather_ms = 0.0f;
     hipEvent_t gather_start = nullptr, gather_stop = nullptr;
     bool gather_timed = false;
     // timing
@@ -384,9 +385,179 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
     return RTX_OK;
 }
 
+// ---- multi-device contexts (rtx_create_multi) ----------------------------------------------------------------------------------
+// RCCL is loaded on demand: a single-device program, and a box without the library, never touch it.
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(std::string& err)
+    {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {   // a copy the process already holds (PyTorch ships one) is found first
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { const char* e = dlerror(); err = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return false; }
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) { err = "librccl.so lacks an expected symbol"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t _r = (expr);                                                                               \
+        if (_r != ncclSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+inline int n_ranks(const rtx_context* ctx) { return 1 + static_cast<int>(ctx->peers.size()); }
+inline rtx_context* rank_ctx(rtx_context* ctx, int r) { return r == 0 ? ctx : ctx->peers[r - 1]; }
+inline size_t target_bytes(int t) { return t == 0 ? 16 : 4; }   // target 0 = RGBA32F, 1 = RGBA8
+
+int rows_of_rank(const rtx_context* root, int rank)
+{
+    const int N = n_ranks(root), n_bands = (root->height + root->band_rows - 1) / root->band_rows;
+    int rows = 0;
+    for (int b = rank; b < n_bands; b += N) {
+        const int y0 = b * root->band_rows, y1 = y0 + root->band_rows < root->height ? y0 + root->band_rows : root->height;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+// GLWrapper::draw on N devices (BASELINE north_star: "GLWrapper dispatch -> HIP launch + RCCL tile gather"). Every rank traces its
+// interleaved row bands into packed buffers on its own device and stream (one launch writes both colour targets); the peers' packed bands
+// travel to the root -- one ncclSend / ncclRecv pair per peer and target inside ONE group, i.e. every peer straight over its own xGMI link,
+// no ring -- and a copy kernel puts every rank's rows in their place in the root's colour targets. Sends, receives and placement run on
+// each device's transfer stream and the packed / landing buffers alternate between two sets, so the gather of frame k overlaps the trace of
+// frame k+1 on all devices. RTX_GATHER_PEER_COPY replaces the RCCL pair by hipMemcpyPeerAsync on the root's transfer stream (same data path
+// over xGMI, no library; also the only mode in which two ranks may share a device, which the tests use on single-GPU boxes).
+int multi_draw(rtx_context* root)
+{
+    const int N = n_ranks(root), par = static_cast<int>(root->frame_no & 1u);
+    int st;
+    for (int r = 0; r < N; r++) {
+        rtx_context* c = rank_ctx(root, r);
+        if ((st = use_device(c)) != RTX_OK) return st;
+        if (root->frame_no >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->moved[par], 0));   // this buffer set: its previous transfer is done
+        st = draw_impl(c, root->band_rows, r, N, static_cast<float*>(c->d_packed[0][par]), static_cast<uint32_t*>(c->d_packed[1][par]), c->stream);
+        if (st) return st;
+        HIP_TRY(hipEventRecord(c->traced[par], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->xfer_stream, c->traced[par], 0));
+    }
+    if ((st = use_device(root)) != RTX_OK) return st;
+    HIP_TRY(hipEventRecord(root->gather_start, root->xfer_stream));
+    if (root->gather_kind == RTX_GATHER_RCCL && N > 1) {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int r = 1; r < N; r++) {
+            rtx_context* c = rank_ctx(root, r);
+            const size_t rows = static_cast<size_t>(rows_of_rank(root, r));
+            for (int t = 0; t < 2; t++) {
+                if (!((root->gather_targets >> t) & 1)) continue;
+                const size_t bytes = rows * root->width * target_bytes(t);
+                NCCL_TRY(g_rccl.Send(c->d_packed[t][par], bytes, ncclUint8, 0, c->comm, c->xfer_stream));
+                NCCL_TRY(g_rccl.Recv(root->d_stage[t][par][r], bytes, ncclUint8, r, root->comm, root->xfer_stream));
+            }
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+    } else {
+        for (int r = 1; r < N; r++) {
+            rtx_context* c = rank_ctx(root, r);
+            HIP_TRY(hipStreamWaitEvent(root->xfer_stream, c->traced[par], 0));
+            const size_t rows = static_cast<size_t>(rows_of_rank(root, r));
+            for (int t = 0; t < 2; t++) {
+                if (!((root->gather_targets >> t) & 1)) continue;
+                HIP_TRY(hipMemcpyPeerAsync(root->d_stage[t][par][r], root->device, c->d_packed[t][par], c->device, rows * root->width * target_bytes(t), root->xfer_stream));
+            }
+        }
+    }
+    for (int r = 0; r < N; r++)
+        for (int t = 0; t < 2; t++) {
+            if (!((root->gather_targets >> t) & 1)) continue;
+            const void* src = r == 0 ? root->d_packed[t][par] : root->d_stage[t][par][r];
+            void* dst = t == 0 ? static_cast<void*>(root->d_fb_f32) : static_cast<void*>(root->d_fb_u8);
+            HIP_TRY(bands_unpack(src, dst, root->width, root->height, static_cast<int>(target_bytes(t)), root->band_rows, r, N, rows_of_rank(root, r), root->xfer_stream));
+        }
+    HIP_TRY(hipEventRecord(root->gather_stop, root->xfer_stream));
+    HIP_TRY(hipEventRecord(root->moved[par], root->xfer_stream));
+    for (int r = 1; r < N; r++) {   // a peer's buffers are free once its send (RCCL) or the root's copy (peer copy) has completed
+        rtx_context* c = rank_ctx(root, r);
+        if (root->gather_kind == RTX_GATHER_RCCL) {
+            if ((st = use_device(c)) != RTX_OK) return st;
+            HIP_TRY(hipEventRecord(c->moved[par], c->xfer_stream));
+        } else {
+            c->moved[par] = root->moved[par];   // (shared handle: recorded on the root's transfer stream above; owned by the root)
+        }
+    }
+    root->gather_timed = true;
+    root->frame_no++;
+    return RTX_OK;
+}
+
+// the assembled frame is written on the root's transfer stream: whoever reads the colour targets waits for it
+int multi_sync(rtx_context* root)
+{
+    if (root->peers.empty()) return RTX_OK;
+    int st = use_device(root);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(root->xfer_stream));
+    return RTX_OK;
+}
+
+int multi_alloc(rtx_context* root)
+{
+    const int N = n_ranks(root);
+    for (int r = 0; r < N; r++) {
+        rtx_context* c = rank_ctx(root, r);
+        int st = use_device(c);
+        if (st) return st;
+        c->rank = r;
+        HIP_TRY(hipStreamCreateWithFlags(&c->xfer_stream, hipStreamNonBlocking));
+        const size_t rows = static_cast<size_t>(rows_of_rank(root, r)) + 8;
+        for (int t = 0; t < 2; t++)
+            for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&c->d_packed[t][p], rows * root->width * target_bytes(t)));
+        for (int p = 0; p < 2; p++) {
+            HIP_TRY(hipEventCreateWithFlags(&c->traced[p], hipEventDisableTiming));
+            if (r == 0 || root->gather_kind == RTX_GATHER_RCCL) HIP_TRY(hipEventCreateWithFlags(&c->moved[p], hipEventDisableTiming));
+        }
+    }
+    int st = use_device(root);
+    if (st) return st;
+    HIP_TRY(hipEventCreate(&root->gather_start));
+    HIP_TRY(hipEventCreate(&root->gather_stop));
+    for (int t = 0; t < 2; t++)
+        for (int p = 0; p < 2; p++) {
+            root->d_stage[t][p].assign(N, nullptr);
+            for (int r = 1; r < N; r++) HIP_TRY(hipMalloc(&root->d_stage[t][p][r], (static_cast<size_t>(rows_of_rank(root, r)) + 8) * root->width * target_bytes(t)));
+        }
+    return RTX_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// a multi-device context forwards every call that changes scene, texture or option state to its peers (replicated inputs)
+#define RTX_FORWARD(call)                                             \
+    do {                                                              \
+        for (rtx_context * _p : ctx->peers) {                         \
+            rtx_context* ctx = _p;                                    \
+            const int _st = (call);                                   \
+            if (_st != RTX_OK) return _st;                            \
+        }                                                             \
+    } while (0)
 
 const char* rtx_last_error(void) { return g_error.c_str(); }
 const char* rtx_version(void) { return "rtx-hip 0.1 (gfx950, HIP tracer for the rt.frag path)"; }
@@ -433,11 +604,85 @@ int rtx_create(int width, int height, int device, rtx_context** out)
     return RTX_OK;
 }
 
+int rtx_create_multi(int width, int height, int n_devices, const int* device_ids, int gather, rtx_context** out)
+{
+    if (!out || !device_ids || n_devices < 1 || n_devices > 64) return fail(RTX_ERR_INVALID, "rtx_create_multi: bad arguments");
+    if (gather != RTX_GATHER_RCCL && gather != RTX_GATHER_PEER_COPY) return fail(RTX_ERR_INVALID, "unknown gather kind %d", gather);
+    *out = nullptr;
+    if (gather == RTX_GATHER_RCCL)
+        for (int a = 0; a < n_devices; a++)
+            for (int b = a + 1; b < n_devices; b++)
+                if (device_ids[a] == device_ids[b]) return fail(RTX_ERR_INVALID, "device %d listed twice: RCCL needs one device per rank (RTX_GATHER_PEER_COPY allows it)", device_ids[a]);
+    rtx_context* root = nullptr;
+    int st = rtx_create(width, height, device_ids[0], &root);
+    if (st) return st;
+    root->gather_kind = gather;
+    for (int r = 1; r < n_devices; r++) {
+        rtx_context* peer = nullptr;
+        st = rtx_create(width, height, device_ids[r], &peer);
+        if (st) { rtx_destroy(root); return st; }
+        peer->owner = root;
+        root->peers.push_back(peer);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_mutex);
+        g_current = root;   // rtx_create made the last peer current
+    }
+    if (n_devices > 1) {
+        st = multi_alloc(root);
+        if (st == RTX_OK && gather == RTX_GATHER_RCCL) {
+            std::string err;
+            if (!g_rccl.load(err)) st = fail(RTX_ERR_DEVICE, "%s", err.c_str());
+            if (st == RTX_OK) {
+                std::vector<ncclComm_t> comms(n_devices);
+                ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_devices, device_ids);
+                if (r != ncclSuccess) st = fail(RTX_ERR_DEVICE, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
+                else for (int k = 0; k < n_devices; k++) rank_ctx(root, k)->comm = comms[k];
+            }
+        }
+        if (st) { rtx_destroy(root); return st; }
+    }
+    *out = root;
+    return RTX_OK;
+}
+
+int rtx_device_count(rtx_context* ctx, int* n)
+{
+    if (!ctx || !n) return fail(RTX_ERR_INVALID, "null argument");
+    *n = n_ranks(ctx);
+    return RTX_OK;
+}
+
 void rtx_destroy(rtx_context* ctx)
 {
     if (!ctx) return;
+    for (rtx_context* p : ctx->peers) {
+        (void)hipSetDevice(p->device);
+        if (p->xfer_stream) (void)hipStreamSynchronize(p->xfer_stream);
+    }
     (void)hipSetDevice(ctx->device);
+    if (ctx->xfer_stream) (void)hipStreamSynchronize(ctx->xfer_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (rtx_context* p : ctx->peers) {
+        if (ctx->gather_kind != RTX_GATHER_RCCL) p->moved[0] = p->moved[1] = nullptr;   // shared with the root's events in peer-copy mode
+        rtx_destroy(p);
+    }
+    ctx->peers.clear();
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
+    for (int t = 0; t < 2; t++)
+        for (int p = 0; p < 2; p++) {
+            if (ctx->d_packed[t][p]) (void)hipFree(ctx->d_packed[t][p]);
+            for (void* q : ctx->d_stage[t][p])
+                if (q) (void)hipFree(q);
+        }
+    for (int p = 0; p < 2; p++) {
+        if (ctx->traced[p]) (void)hipEventDestroy(ctx->traced[p]);
+        if (ctx->moved[p]) (void)hipEventDestroy(ctx->moved[p]);
+    }
+    if (ctx->gather_start) (void)hipEventDestroy(ctx->gather_start);
+    if (ctx->gather_stop) (void)hipEventDestroy(ctx->gather_stop);
+    if (ctx->xfer_stream) (void)hipStreamDestroy(ctx->xfer_stream);
     for (auto& kv : ctx->textures)
         if (kv.second.d_texels) (void)hipFree(kv.second.d_texels);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
@@ -500,6 +745,7 @@ int rtx_specialize(rtx_context* ctx, const rtx_defines* d)
     std::memcpy(&ctx->defines, d, sizeof *d);
     ctx->specialized = true;
     ctx->scene_dirty = true;
+    RTX_FORWARD(rtx_specialize(ctx, d));
     return RTX_OK;
 }
 
@@ -514,6 +760,7 @@ int rtx_block_create(rtx_context* ctx, const char* name, int /*binding_point*/, 
     ctx->block_created[b] = true;
     ctx->scene_dirty = true;
     *handle = static_cast<uint32_t>(b + 1);  // handles 1..9 (0 is GL's "no buffer")
+    RTX_FORWARD(rtx_block_create(ctx, name, 0, size, data, handle));
     return RTX_OK;
 }
 
@@ -526,6 +773,7 @@ int rtx_block_update(rtx_context* ctx, uint32_t handle, size_t size, const void*
     if (size && !data) return fail(RTX_ERR_INVALID, "null data");
     if (size) std::memcpy(blk.data(), data, size);
     ctx->scene_dirty = true;
+    RTX_FORWARD(rtx_block_update(ctx, handle, size, data));
     return RTX_OK;
 }
 
@@ -548,6 +796,7 @@ int rtx_texture2d_create(rtx_context* ctx, int width, int height, int channels, 
     const uint32_t h = ctx->next_handle++;
     ctx->textures[h] = t;
     *handle = h;
+    RTX_FORWARD(rtx_texture2d_create(ctx, width, height, channels, texels, wrap, handle));
     return RTX_OK;
 }
 
@@ -575,6 +824,7 @@ int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint
     const uint32_t h = ctx->next_handle++;
     ctx->textures[h] = t;
     *handle = h;
+    RTX_FORWARD(rtx_cubemap_create(ctx, face_size, channels, faces, 0, handle));
     return RTX_OK;
 }
 
@@ -586,6 +836,7 @@ int rtx_sampler_unit(rtx_context* ctx, const char* sampler_name, int unit)
     if (s < 0) return fail(RTX_ERR_NAME, "unknown sampler '%s'", sampler_name ? sampler_name : "(null)");
     if (unit < 0 || unit >= UNIT_COUNT) return fail(RTX_ERR_INVALID, "texture unit %d out of range", unit);
     ctx->sampler_unit[s] = unit;
+    RTX_FORWARD(rtx_sampler_unit(ctx, sampler_name, unit));
     return RTX_OK;
 }
 
@@ -593,6 +844,7 @@ int rtx_bind_texture(rtx_context* ctx, int unit, uint32_t handle)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "rtx_bind_texture: no current context");
     if (unit < 0 || unit >= UNIT_COUNT) return fail(RTX_ERR_INVALID, "texture unit %d out of range", unit);
+    RTX_FORWARD(rtx_bind_texture(ctx, unit, handle));
     if (handle == 0) { ctx->unit_texture_2d[unit] = 0; ctx->unit_texture_cube[unit] = 0; return RTX_OK; }  // glBindTexture(target, 0): there is no target argument here, so both bindings of the unit are cleared
     auto it = ctx->textures.find(handle);
     if (it == ctx->textures.end()) return fail(RTX_ERR_HANDLE, "unknown texture handle %u", handle);
@@ -615,6 +867,7 @@ int rtx_texture_destroy(rtx_context* ctx, uint32_t handle)
         if (ctx->unit_texture_cube[u] == handle) ctx->unit_texture_cube[u] = 0;
     }
     ctx->textures.erase(it);
+    RTX_FORWARD(rtx_texture_destroy(ctx, handle));
     return RTX_OK;
 }
 
@@ -629,8 +882,10 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_XCD_REMAP: ctx->opt_xcd = value != 0; break;
         case RTX_OPT_HIGH_OCCUPANCY: ctx->opt_occ = value < 0 ? -1 : (value != 0); break;
         case RTX_OPT_HOT_ROWS_FIRST: ctx->opt_hot = value != 0; break;
+        case RTX_OPT_GATHER_TARGETS: if (value < 1 || value > 3) return fail(RTX_ERR_INVALID, "RTX_OPT_GATHER_TARGETS: 1, 2 or 3"); ctx->gather_targets = value; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
+    RTX_FORWARD(rtx_set_option(ctx, option, value));
     return RTX_OK;
 }
 int rtx_get_option(rtx_context* ctx, int option, int* value)
@@ -644,6 +899,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_XCD_REMAP: *value = ctx->opt_xcd; break;
         case RTX_OPT_HIGH_OCCUPANCY: *value = ctx->opt_occ; break;
         case RTX_OPT_HOT_ROWS_FIRST: *value = ctx->opt_hot; break;
+        case RTX_OPT_GATHER_TARGETS: *value = ctx->gather_targets; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;
@@ -652,8 +908,19 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
 int rtx_draw(rtx_context* ctx)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "null context");
+    if (ctx->owner) return fail(RTX_ERR_INVALID, "rtx_draw on a peer of a multi-device context: draw through the root");
+    int st;
+    if (!ctx->peers.empty()) {
+        st = multi_draw(ctx);
+        if (st == RTX_OK && ctx->smaa_preset >= 0) {   // the post-process runs on the root once the frame is assembled
+            st = use_device(ctx);
+            if (st == RTX_OK) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->moved[(ctx->frame_no - 1u) & 1u], 0));
+            if (st == RTX_OK) st = smaa_resolve(ctx, ctx->stream);
+        }
+        return st;
+    }
     const int band = ((ctx->height + 7) / 8) * 8;
-    int st = draw_impl(ctx, band, 0, 1, ctx->d_fb_f32, ctx->d_fb_u8, ctx->stream);
+    st = draw_impl(ctx, band, 0, 1, ctx->d_fb_f32, ctx->d_fb_u8, ctx->stream);
     if (st == RTX_OK && ctx->smaa_preset >= 0) st = smaa_resolve(ctx, ctx->stream);   // GLWrapper.cpp:168-204: the passes follow the tracer
     return st;
 }
@@ -714,6 +981,7 @@ int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host, size_t 
 int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride, void* dst_device, int format, void* stream)
 {
     if (!ctx || !dst_device) return fail(RTX_ERR_INVALID, "rtx_draw_bands: null argument");
+    if (!ctx->peers.empty()) return fail(RTX_ERR_INVALID, "rtx_draw_bands on a multi-device context: it splits the frame itself (rtx_draw)");
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     if (format == RTX_RGBA32F) return draw_impl(ctx, band_rows, band_first, band_stride, static_cast<float*>(dst_device), nullptr, s);
     if (format == RTX_RGBA8) return draw_impl(ctx, band_rows, band_first, band_stride, nullptr, static_cast<uint32_t*>(dst_device), s);
@@ -726,7 +994,12 @@ int rtx_finish(rtx_context* ctx)
     int st = use_device(ctx);
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return RTX_OK;
+    for (rtx_context* p : ctx->peers) {
+        if ((st = use_device(p)) != RTX_OK) return st;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipStreamSynchronize(p->xfer_stream));
+    }
+    return multi_sync(ctx);
 }
 
 int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_bytes)
@@ -747,6 +1020,9 @@ int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_byt
     }
     if (!src) return fail(RTX_ERR_ORDER, "format %d needs SMAA to be enabled (rtx_enable_smaa)", format);
     if (dst_bytes < need) return fail(RTX_ERR_INVALID, "destination holds %zu bytes, %zu needed", dst_bytes, need);
+    if ((format == RTX_RGBA32F && !(ctx->gather_targets & 1)) || (format == RTX_RGBA8 && !(ctx->gather_targets & 2)))
+        if (!ctx->peers.empty()) return fail(RTX_ERR_ORDER, "this colour target is not gathered (RTX_OPT_GATHER_TARGETS)");
+    if ((st = multi_sync(ctx)) != RTX_OK) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(dst_host, src, need, hipMemcpyDeviceToHost));
     return RTX_OK;
@@ -772,6 +1048,15 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
     std::memset(out, 0, sizeof *out);
     out->last_draw_ms = ctx->last_ms;
     out->launches = ctx->launches;
+    for (rtx_context* p : ctx->peers) {   // slowest rank's kernel; counters summed below
+        if ((st = use_device(p)) != RTX_OK || (st = drain_events(p)) != RTX_OK) return st;
+        if (p->last_ms > out->last_draw_ms) out->last_draw_ms = p->last_ms;
+    }
+    if ((st = use_device(ctx)) != RTX_OK) return st;
+    if (ctx->gather_timed) {
+        HIP_TRY(hipEventSynchronize(ctx->gather_stop));
+        HIP_TRY(hipEventElapsedTime(&out->last_gather_ms, ctx->gather_start, ctx->gather_stop));
+    }
     if (ctx->smaa_timed) {
         HIP_TRY(hipEventSynchronize(ctx->smaa_stop));
         HIP_TRY(hipEventElapsedTime(&out->last_smaa_ms, ctx->smaa_start, ctx->smaa_stop));
@@ -786,6 +1071,16 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
         out->rays_shadow = c[1];
         out->rays_shadow_cast = c[2];
         out->torus_solves = c[3];
+        for (rtx_context* p : ctx->peers) {
+            if ((st = use_device(p)) != RTX_OK) return st;
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            HIP_TRY(hipMemcpy(c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
+            out->rays_closest += c[0];
+            out->rays_shadow += c[1];
+            out->rays_shadow_cast += c[2];
+            out->torus_solves += c[3];
+        }
+        if ((st = use_device(ctx)) != RTX_OK) return st;
     }
     return RTX_OK;
 }
