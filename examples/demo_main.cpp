@@ -41,7 +41,9 @@ int main(int argc, char** argv)
 {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 60;
     GLWrapper glWrapper(wind_width, wind_height, false);
-    glWrapper.enable_SMAA(ULTRA);  // accepted, ignored
+#ifdef RTX_SHIM_HAVE_SMAA_TABLES
+    glWrapper.enable_SMAA(ULTRA);  // main.cpp:32. The post-process needs the reference's two look-up tables, which this repository does not
+#endif                             // carry: built with -I<reference>/src the shim finds AreaTex.h / SearchTex.h and hands them over
     if (!glWrapper.init_window()) return 1;
     wind_width = glWrapper.getWidth();
     wind_height = glWrapper.getHeight();

@@ -171,8 +171,33 @@ public:
 
     bool init_window()  // GLWrapper.cpp:61-133 -> returns false on failure, never exits
     {
-        const char* dev = std::getenv("RTX_DEVICE");
-        if (rtx_create(width, height, dev ? std::atoi(dev) : 0, &ctx) != RTX_OK) {
+        // Which GPUs draw() uses is the environment's choice, so that a main.cpp-style program needs no new code for a multi-GPU node:
+        //   RTX_DEVICES = "0,1,2,3" (device ids) or "4" (the first four) -> rtx_create_multi: interleaved row bands, assembled on the first;
+        //   RTX_GATHER  = "rccl" (default) | "peer" (hipMemcpyPeerAsync);   RTX_DEVICE = id of the single device otherwise (default 0).
+        std::vector<int> ids;
+        if (const char* list = std::getenv("RTX_DEVICES")) {
+            const std::string t = list;
+            if (t.find(',') == std::string::npos) {
+                for (int k = 0; k < std::atoi(t.c_str()); k++) ids.push_back(k);
+            } else {
+                size_t pos = 0;
+                while (pos <= t.size()) {
+                    const size_t next = t.find(',', pos);
+                    ids.push_back(std::atoi(t.substr(pos, next == std::string::npos ? std::string::npos : next - pos).c_str()));
+                    if (next == std::string::npos) break;
+                    pos = next + 1;
+                }
+            }
+        }
+        int st;
+        if (ids.size() > 1) {
+            const char* g = std::getenv("RTX_GATHER");
+            st = rtx_create_multi(width, height, static_cast<int>(ids.size()), ids.data(), (g && g[0] == 'p') ? RTX_GATHER_PEER_COPY : RTX_GATHER_RCCL, &ctx);
+        } else {
+            const char* dev = std::getenv("RTX_DEVICE");
+            st = rtx_create(width, height, ids.size() == 1 ? ids[0] : (dev ? std::atoi(dev) : 0), &ctx);
+        }
+        if (st != RTX_OK) {
             std::fprintf(stderr, "rtx_create failed: %s\n", rtx_last_error());
             return false;
         }

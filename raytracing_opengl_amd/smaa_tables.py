@@ -7,7 +7,7 @@ independently of what the tables hold, so parity tests use the tables built here
   search_table()  -- the SMAA search table computed from its published definition (Jimenez et al. 2012, section 3.2 + the
                      pseudo-gather trick): for a bilinear fetch of four edges at offset (-0.25, -0.125) it says how many of the
                      last two pixels (0, 1, 2 -> bytes 0, 127, 254) still belong to the line. In the build container
-                     tests/test_smaa_oracle.py checks that this equals the reference's searchTexBytes byte for byte.
+                     the build-container test of the SMAA pin checks that this equals the reference's searchTexBytes byte for byte.
   area_table()    -- a SYNTHETIC area table of the right shape: unsmoothed analytic trapezoid areas for the orthogonal
                      patterns and a smooth made-up function for the diagonal ones. Not the reference's values (those include
                      smoothing and sampled diagonal coverage) -- good enough to drive every code path with plausible weights.

@@ -105,9 +105,10 @@ def test_decoded_image_files_render_like_the_expected_texels(built, tmp_path):
     assert float(np.abs(ref - ref_plain).max()) > 0.05        # the textures are actually in the picture
 
 
+@pytest.mark.parametrize("env", [{}, {"RTX_DEVICES": "0,0,0", "RTX_GATHER": "peer"}], ids=["one_device", "three_ranks_peer_copy"])
 @pytest.mark.parametrize("w,h,kw", [(320, 180, dict(time=0.0, delta=0.0, yaw=0.0, pitch=0.0)),
                                     (322, 182, dict(time=7.25, delta=0.02, yaw=35.0, pitch=-6.0))])
-def test_cpp_shim_program_renders_the_oracles_frame(built, tmp_path, w, h, kw):
+def test_cpp_shim_program_renders_the_oracles_frame(built, tmp_path, w, h, kw, env):
     """The header-only GLWrapper / SceneManager / SurfaceFactory surface, compiled as a main.cpp-shaped program and run on the
     GPU: frame (RGBA32F) within 1e-4 of the oracle on the same scene recipe; its RGBA8 dump and its save_png agree exactly."""
     assert os.path.exists(SHIM), "tests/shim_harness/shim_frame was not built (python -c 'import __graft_entry__ as g; g.build()')"
@@ -115,7 +116,7 @@ def test_cpp_shim_program_renders_the_oracles_frame(built, tmp_path, w, h, kw):
     depth = 5
     out = tmp_path / "frame"
     subprocess.run([SHIM, str(w), str(h), str(depth), repr(kw["time"]), repr(kw["delta"]), repr(kw["yaw"]), repr(kw["pitch"]), "0", str(out)],
-                   check=True, cwd=d, timeout=300)
+                   check=True, cwd=d, timeout=300, env=dict(os.environ, **env))   # RTX_DEVICES: the shim picks a multi-device context
     img = np.fromfile(str(out) + ".f32", np.float32).reshape(h, w, 4)
     img8 = np.fromfile(str(out) + ".u8", np.uint8).reshape(h, w, 4)
     sc = scenes.build_scene("default", w, h, depth, **kw)
