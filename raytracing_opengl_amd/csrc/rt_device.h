@@ -265,6 +265,8 @@ struct SceneView {
     RT_HDM const DevSurfaceCull* surf_cull() const { return at<DevSurfaceCull>(h->off_surf_cull); }
     RT_HDM const f4* torus_bound() const { return at<f4>(h->off_torus_bound); }
     RT_HDM const f4* ring_bound() const { return at<f4>(h->off_ring_bound); }
+    RT_HDM const f4* surf_group() const { return at<f4>(h->off_surf_group); }
+    RT_HDM const f4* torus_group() const { return at<f4>(h->off_torus_group); }
 };
 // `hdr` normally is the blob's own first record; with the tables staged in LDS it stays in global memory.
 RT_HD SceneView make_view(const char* blob, const DevSceneHeader* hdr)
@@ -892,6 +894,43 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
     return fmaf(b, b, -(a * cc)) < -1e-5f * a * d2;  // rounding-safe (see sphere_cull); NaN -> false -> not culled
 }
 
+// ---- second-level culls for long tables (RT_GROUP consecutive primitives under one sphere, built by the packer) ----
+// A scene with 64 tori or 96 quadrics spends most of its instructions on one first-level cull per primitive and ray. A group sphere
+// contains its members' (inflated) bounds, so "provably misses the group" implies "provably misses every member's bound" -- the
+// conclusion each member's own cull would reach. Groups are runs of consecutive indices and are visited in order: scan order, the
+// strict-< tie rule and every per-lane test sequence stay what they were.
+//  * tori: a wave none of whose lanes can reach the group skips the group's eight first-level tests. Same preconditions as
+//    torus_cull (unit direction only: for other directions the solver's answer is not geometric and nothing may be culled).
+//  * quadrics: missing the bounds does not settle a quadric -- its degenerate branch (trap T4, |p2| < 1e-6) ignores the clip box --
+//    so a skipped group still evaluates the p2 pre-check of every member (quadric_may_degenerate: the first third of surface_cull) and
+//    runs the exact test for a lane whose direction is that close to a member's asymptotic cone.
+RT_HD bool torus_group_cull(f4 g, f3 ro, f3 rd, float tlimit)
+{
+    if (!(g.w >= 0.0f)) return false;   // a member that is never culled (zero tube, non-unit quaternion): neither is the group
+    if (!unit_direction(dot3_fma(rd, rd))) return false;
+    return sphere_cull(xyz(g), g.w, ro, rd, gl_min(tlimit, 100.0f));
+}
+RT_HD bool surface_group_cull(f4 g, f3 ro, f3 rd)
+{
+    if (!(g.w >= 0.0f)) return false;
+    const float a = dot3_fma(rd, rd);
+    if (!(a > 0.25f && a < 4.0f)) return false;
+    const f3 oc = ro - xyz(g);
+    const float b = dot3_fma(oc, rd);
+    const float d2 = dot3_fma(oc, oc);
+    return fmaf(b, b, -(a * (d2 - g.w))) < -1e-5f * a * d2;
+}
+RT_HD bool quadric_may_degenerate(const DevSurfaceCull& Q, f3 rd)
+{
+    const float dxx = rd.x * rd.x, dyy = rd.y * rd.y, dzz = rd.z * rd.z;
+    const float dxy = 2.0f * (rd.x * rd.y), dxz = 2.0f * (rd.x * rd.z), dyz = 2.0f * (rd.y * rd.z);
+    const float p2 = fmaf(Q.sym1.x, dyz, fmaf(Q.sym0.z, dxz, fmaf(Q.sym0.y, dxy, fmaf(Q.sym1.y, dzz, fmaf(Q.sym0.w, dyy, Q.sym0.x * dxx)))));
+    return !(fabsf(p2) > Q.sym1.z);
+}
+#ifndef RT_GROUP_MIN
+#define RT_GROUP_MIN 16   /* tables shorter than this keep the one-level scan */
+#endif
+
 // ------------------------------------------------------------------------------------------
 // closest hit (rt.frag:587-628) and any-hit (rt.frag:630-658)
 // ------------------------------------------------------------------------------------------
@@ -945,12 +984,20 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
     {
         const int n = S.h->n_surface;
         const DevSurfaceCull* cullrec = S.surf_cull();
+        const bool grouped = CULL && n >= RT_GROUP_MIN;
+        bool group_live = true;   // wave-uniform: some lane may reach the current group's sphere
         for (int i = 0; i < n; i += 2) {
+            if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd));
             bool need[2] = {true, i + 1 < n};
             if (CULL) {
                 const DevSurfaceCull c0 = cullrec[i], c1 = cullrec[i + 1];
-                need[0] = !surface_cull(c0, ro, rd);
-                need[1] = need[1] && !surface_cull(c1, ro, rd);
+                if (group_live) {
+                    need[0] = !surface_cull(c0, ro, rd);
+                    need[1] = need[1] && !surface_cull(c1, ro, rd);
+                } else {           // every lane misses the group: only the degenerate branch could still answer
+                    need[0] = quadric_may_degenerate(c0, rd);
+                    need[1] = need[1] && quadric_may_degenerate(c1, rd);
+                }
             }
             for (int k = 0; k < 2; k++) {
                 if (RT_ANY(need[k])) {
@@ -974,7 +1021,11 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         for (int base = 0; base < n; base += 64) {
             unsigned long long cand = 0ull;
             const int end = base + 64 < n ? base + 64 : n;
+            const bool grouped = n >= RT_GROUP_MIN;
+            bool group_live = true;
             for (int i = base; i < end; i += 4) {
+                if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin));
+                if (!group_live) continue;   // wave-uniform: no lane can reach any of the group's tori
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd, tmin)) cand |= 1ull << (i + k - base);)
             }
@@ -1067,12 +1118,20 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
     if (RT_ANY(on)) {
         const int n = S.h->n_surface;
         const DevSurfaceCull* cullrec = S.surf_cull();
+        const bool grouped = CULL && n >= RT_GROUP_MIN;
+        bool group_live = true;
         for (int i = 0; i < n; i += 2) {
+            if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd));
             bool need[2] = {on, on && i + 1 < n};
             if (CULL) {
                 const DevSurfaceCull c0 = cullrec[i], c1 = cullrec[i + 1];
-                need[0] = need[0] && !surface_cull(c0, ro, rd);
-                need[1] = need[1] && !surface_cull(c1, ro, rd);
+                if (group_live) {
+                    need[0] = need[0] && !surface_cull(c0, ro, rd);
+                    need[1] = need[1] && !surface_cull(c1, ro, rd);
+                } else {
+                    need[0] = need[0] && quadric_may_degenerate(c0, rd);
+                    need[1] = need[1] && quadric_may_degenerate(c1, rd);
+                }
             }
             for (int k = 0; k < 2; k++) {
                 if (RT_ANY(need[k])) {
@@ -1089,7 +1148,11 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             for (int base = 0; base < n; base += 64) {
                 unsigned long long cand = 0ull;
                 const int end = base + 64 < n ? base + 64 : n;
+                const bool grouped = n >= RT_GROUP_MIN;
+                bool group_live = true;
                 for (int i = base; i < end; i += 4) {
+                    if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, dist));
+                    if (!group_live) continue;
                     const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                     RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd, dist)) cand |= 1ull << (i + k - base);)
                 }

@@ -222,6 +222,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     h.off_surf_cull = reserve(sizeof(DevSurfaceCull) * pad(d.surface_size, 2));
     h.off_torus_bound = reserve(sizeof(f4) * pad(d.torus_size, 4));
     h.off_ring_bound = reserve(sizeof(f4) * pad(d.ring_size, 4));
+    h.off_surf_group = reserve(sizeof(f4) * pad(d.surface_size, RT_GROUP) / RT_GROUP + 16);
+    h.off_torus_group = reserve(sizeof(f4) * pad(d.torus_size, RT_GROUP) / RT_GROUP + 16);
     h.total_bytes = static_cast<int32_t>(off);
     blob.assign(off, 0);
     std::memcpy(blob.data(), &h, sizeof h);
@@ -367,6 +369,36 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_ring_bound) + i, &rbnd, sizeof rbnd);
         std::memcpy(mat_at(TYPE_RING, i), p, 64);
     }
+    // second-level bounds: a sphere around the first-level bounds of every RT_GROUP consecutive quadrics / tori (rt_device.h group_cull).
+    // Conservative by construction: it contains each member's (already inflated) bound, so a ray that provably misses it provably misses
+    // every member's bound. A member without a finite bound makes its group unbounded (never culled).
+    auto group_bounds = [&](int count, uint32_t off_group, auto member_bound) {
+        for (int g = 0; g * RT_GROUP < count; g++) {
+            const int i0 = g * RT_GROUP, i1 = i0 + RT_GROUP < count ? i0 + RT_GROUP : count;
+            double cx = 0, cy = 0, cz = 0;
+            bool bounded = true;
+            for (int i = i0; i < i1; i++) {
+                const f4 b = member_bound(i);
+                if (!(b.w >= 0.0f) || !std::isfinite(b.w) || !std::isfinite(b.x) || !std::isfinite(b.y) || !std::isfinite(b.z)) bounded = false;
+                cx += b.x; cy += b.y; cz += b.z;
+            }
+            f4 out = mk4(0.0f, 0.0f, 0.0f, -1.0f);
+            if (bounded) {
+                cx /= (i1 - i0); cy /= (i1 - i0); cz /= (i1 - i0);
+                double rad = 0.0;
+                for (int i = i0; i < i1; i++) {
+                    const f4 b = member_bound(i);
+                    const double dx = b.x - cx, dy = b.y - cy, dz = b.z - cz;
+                    rad = std::fmax(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(static_cast<double>(b.w)));
+                }
+                rad = rad * 1.0001 + 1e-3;
+                if (rad < 1.0e15) out = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
+            }
+            std::memcpy(reinterpret_cast<f4*>(blob.data() + off_group) + g, &out, sizeof out);
+        }
+    };
+    group_bounds(d.surface_size, h.off_surf_group, [&](int i) { return (reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + i)->bound; });
+    group_bounds(d.torus_size, h.off_torus_group, [&](int i) { return reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i]; });
     for (int i = 0; i < d.light_point_size; i++) {
         const unsigned char* p = blocks[BLK_LIGHTS_POINT].data() + static_cast<size_t>(i) * SZ_LIGHT_POINT;
         DevLightPoint s;

@@ -110,12 +110,17 @@ struct alignas(16) DevSceneHeader {
     uint32_t off_torus_bound;  // f4 per torus: centre, inflated bounding radius^2
     uint32_t off_ring_bound;   // f4 per ring:  centre, inflated outer radius^2
     uint32_t cam_ident;        // 1 if cam_quat is the identity (any zero signs): getRayDir's rotation is then v + 0.0f
-    uint32_t _pad[2];
+    // second-level cull arrays for long tables: one f4 per group of RT_GROUP consecutive quadrics / tori = a sphere around the group's
+    // first-level bounds (centre, radius^2; w < 0 or inf: the group has an unbounded member and is never culled)
+    uint32_t off_surf_group;
+    uint32_t off_torus_group;
 };
 
 // ---- textures --------------------------------------------------------------------------------
 // Texels are stored as RGBA8 (one dword per texel) whatever the source channel count, so a tap
 // is one aligned 4-byte load; RGB sources get alpha 255 (= 1.0 exactly), GL_RED gets (r,0,0,255).
+enum { RT_GROUP = 8 };   // primitives per second-level cull group (consecutive indices: scan order is untouched)
+
 enum { TEX_SPHERE_1 = 0, TEX_SPHERE_2, TEX_SPHERE_3, TEX_SPHERE_4, TEX_RING, TEX_BOX, TEX_SLOTS };
 enum { MAX_MIPS = 15 };
 

@@ -131,3 +131,49 @@ def scaled_quat_scene(seed: int, w: int, h: int):
         struct.pack_into("<4f", buf, 0, *q)
         blocks["scene_buf"] = bytes(buf)
     return type(sc)(defines=sc.defines, blocks=blocks)
+
+
+def crowd_scene(seed: int, w: int, h: int):
+    """Long primitive tables (16 ... 100 quadrics and / or tori, plus a few of everything else): exercises the second-level group culls
+    (rt_device.h RT_GROUP) -- groups with an unbounded member, members with non-unit quaternions, quadrics of every kind incl. ones whose
+    degenerate branch (trap T4) fires for axis-parallel rays, clusters spread far apart so that whole groups are skipped."""
+    rng = np.random.default_rng(seed ^ 0xc0de)
+    depth = int(rng.integers(1, 5))
+    n_surf = int(rng.choice([0, 17, 40, 96]))
+    n_tor = int(rng.choice([0, 16, 33, 64])) if n_surf else int(rng.choice([16, 33, 64]))
+
+    def where(k, n):
+        cols = max(1, int(math.sqrt(n) * 1.4))
+        return (float((k % cols - cols / 2) * 2.7 + rng.normal() * 0.3), float((k // cols - n / cols / 2) * 2.9 + rng.normal() * 0.3), float(14.0 + rng.random() * 8.0))
+    surfaces = []
+    for k in range(n_surf):
+        p = where(k, n_surf)
+        coef = [dict(a=1, b=1, c=1, f=-float(rng.random() * 0.5 + 0.3)), dict(a=4, b=4, c=-1), dict(a=4, b=4, f=-1), dict(a=1.5, b=1.5, d=-1),
+                dict(a=1.5, b=-1.5, d=-1), dict(a=4, b=4, c=-1, f=-1)][int(rng.integers(6))]
+        r = rng.random()
+        if r < 0.8:
+            clip = dict(vmin=(p[0] - 1.2, p[1] - 1.2, p[2] - 1.2), vmax=(p[0] + 1.2, p[1] + 1.2, p[2] + 1.2))
+        elif r < 0.9:
+            from scene_util import FLT_MAX
+            clip = dict(vmin=(-FLT_MAX, p[1] - 1.0, -FLT_MAX), vmax=(FLT_MAX, p[1] + 1.0, FLT_MAX))    # clipped in y only
+        else:
+            clip = {}                                                                                      # unbounded: its group is never culled
+        q = _quat(rng)
+        if rng.random() < 0.1:
+            q = tuple(float(np.float32(v) * np.float32(0.9)) for v in q)
+        surfaces.append(surface(p, _mat(rng), quat=q, **coef, **clip))
+    toruses = []
+    for k in range(n_tor):
+        p = where(k, n_tor)
+        q = _quat(rng)
+        if rng.random() < 0.1:
+            q = tuple(float(np.float32(v) * np.float32(1.1)) for v in q)
+        toruses.append(torus((p[0], p[1], p[2] - 4.0), float(rng.random() * 0.5 + 0.6), float(rng.choice([0.0, 0.2, 0.3])), _mat(rng), quat=q))
+    spheres = [sphere(_pos(rng, 8.0, 12.0), float(rng.random() + 0.3), _mat(rng)) for _ in range(int(rng.integers(0, 4)))]
+    boxes = [box(_pos(rng, 8.0, 12.0), tuple(rng.random(3) + 0.3), _mat(rng), quat=_quat(rng)) for _ in range(int(rng.integers(0, 3)))]
+    planes = [plane((0, 1, 0), (0, -12.0, 0), _mat(rng))] if rng.random() < 0.5 else []
+    lights_point = [light_point((3.0, 5.0, 0.0), 0.1, intensity=25.5)]
+    lights_direct = [light_direct((3.0, -1.0, 1.0))] if rng.random() < 0.7 else []
+    cam_quat = quat_euler(float(rng.normal() * 0.1), float(rng.normal() * 0.2), 0.0) if rng.random() < 0.5 else (0.0, 0.0, 0.0, 1.0)
+    return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, lights_point=lights_point,
+                      lights_direct=lights_direct, cam_pos=(0.0, 0.0, -5.0), cam_quat=cam_quat)

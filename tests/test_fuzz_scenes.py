@@ -86,6 +86,19 @@ def test_scaled_quaternion_scene_bit_exact_on_host(built, small_textures, seed):
         assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_crowd_scene_bit_exact_on_host(built, small_textures, seed):
+    """Long tables (tests/random_scenes.py::crowd_scene): the second-level group culls must not change a bit or a ray count."""
+    W, H = [(96, 54), (97, 55)][seed % 2]
+    sc = random_scenes.crowd_scene(seed, W, H)
+    ref, cnt = oracle.OracleScene(sc, W, H, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
+    for cull in (True, False):
+        img, hc = harness.render(sc, W, H, small_textures["textures"], small_textures["cubemap"], cull=cull)
+        same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), (seed, cull, int((~same).sum()))
+        assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(24))
 def test_scaled_quaternion_scene_on_gpu(built, small_textures, seed):
@@ -109,7 +122,7 @@ SWEEP = 500   # seeds per generator in the -m gpu suite (milliseconds each; tool
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gen", ["random_scene", "nasty_scene", "scaled_quat_scene"])
+@pytest.mark.parametrize("gen", ["random_scene", "nasty_scene", "scaled_quat_scene", "crowd_scene"])
 def test_fuzz_sweep_on_gpu(built, small_textures, gen):
     """500 seeds of each generator through ONE context per frame size (re-specialised per scene, as a program that swaps scenes
     would): culls on (the product path) against the un-culled oracle -- max 1e-4, NaN/inf in the same places, identical ray counts."""
@@ -118,7 +131,7 @@ def test_fuzz_sweep_on_gpu(built, small_textures, gen):
     sizes = [(96, 64), (97, 65)]
     ctx = {}
     bad = []
-    for seed in range(20000, 20000 + SWEEP):
+    for seed in range(20000, 20000 + (SWEEP if gen != "crowd_scene" else 150)):   # crowd scenes: ~30x the oracle time each
         w, h = sizes[seed % 2]
         sc = make(seed, w, h)
         ref, cnt = oracle.OracleScene(sc, w, h, small_textures["textures"], small_textures["cubemap"], texture_lod=1).render()
