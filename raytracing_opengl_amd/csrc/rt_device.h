@@ -961,7 +961,9 @@ RT_HD int lane_pop(unsigned long long& m)
 
 #define RT_UNROLL4(BODY) { { constexpr int k = 0; BODY } { constexpr int k = 1; BODY } { constexpr int k = 2; BODY } { constexpr int k = 3; BODY } }
 
-template <bool CULL, bool COUNT>
+// GROUPS: compile the second-level group culls in. Only the many-primitive kernel variant (and the host build) does: in the default
+// variant the extra code cost 2.5 % of the default scene's frame time through the instruction cache without ever being executed.
+template <bool CULL, bool COUNT, bool GROUPS = true>
 RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt)
 {
     float tmin = RT_MAXDIST;
@@ -984,7 +986,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
     {
         const int n = S.h->n_surface;
         const DevSurfaceCull* cullrec = S.surf_cull();
-        const bool grouped = CULL && n >= RT_GROUP_MIN;
+        const bool grouped = GROUPS && CULL && n >= RT_GROUP_MIN;
         bool group_live = true;   // wave-uniform: some lane may reach the current group's sphere
         for (int i = 0; i < n; i += 2) {
             if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd));
@@ -1021,7 +1023,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         for (int base = 0; base < n; base += 64) {
             unsigned long long cand = 0ull;
             const int end = base + 64 < n ? base + 64 : n;
-            const bool grouped = n >= RT_GROUP_MIN;
+            const bool grouped = GROUPS && n >= RT_GROUP_MIN;
             bool group_live = true;
             for (int i = base; i < end; i += 4) {
                 if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin));
@@ -1092,7 +1094,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
 // set it to 1 or add a non-negative alpha and the result is min(shadow,1) (rt.frag:657), so the
 // early exit is exact. The any-hit scan is an OR (a float sum for textured rings only), so the
 // cheap classes go first; ring order is kept for the sum.
-template <bool CULL, bool COUNT>
+template <bool CULL, bool COUNT, bool GROUPS = true>
 RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt)
 {
     float shadow = 0.0f;
@@ -1118,7 +1120,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
     if (RT_ANY(on)) {
         const int n = S.h->n_surface;
         const DevSurfaceCull* cullrec = S.surf_cull();
-        const bool grouped = CULL && n >= RT_GROUP_MIN;
+        const bool grouped = GROUPS && CULL && n >= RT_GROUP_MIN;
         bool group_live = true;
         for (int i = 0; i < n; i += 2) {
             if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd));
@@ -1148,7 +1150,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             for (int base = 0; base < n; base += 64) {
                 unsigned long long cand = 0ull;
                 const int end = base + 64 < n ? base + 64 : n;
-                const bool grouped = n >= RT_GROUP_MIN;
+                const bool grouped = GROUPS && n >= RT_GROUP_MIN;
                 bool group_live = true;
                 for (int i = base; i < end; i += 4) {
                     if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, dist));
@@ -1241,7 +1243,7 @@ struct Surf {           // what calcShade needs from a hit
     float kd, ks;
 };
 
-template <bool CULL, bool COUNT>
+template <bool CULL, bool COUNT, bool GROUPS = true>
 RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd, const Surf& m, f3 normal, LaneCounters& cnt)
 {
     f3 diffuse = mk3(0.0f, 0.0f, 0.0f);
@@ -1275,7 +1277,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         // (NaN dp must still take the full path so that it propagates like in the shader.)
         const bool cast = on && !(dp == 0.0f);
         RT_PH_BEGIN(_sh0);
-        const float sh = 1.0f - in_shadow<CULL, COUNT>(S, T, cast, on, pt, light_dir, dist, cnt);
+        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS>(S, T, cast, on, pt, light_dir, dist, cnt);
         RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
@@ -1520,7 +1522,7 @@ struct PathScalars {   // the four loop scalars: LDS slots PS_SCALARS.. (WIDE la
     RT_HDM void sti(const PathStore& P, int k, int v) { st(P, k, __builtin_bit_cast(float, v)); }
 };
 
-template <bool CULL, bool COUNT, bool WIDE = false>
+template <bool CULL, bool COUNT, bool WIDE = false, bool GROUPS = true>
 RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
 {
     PathScalars<WIDE> Q;
@@ -1549,7 +1551,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- one closest-hit ray per live lane ----
         int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
         float tm = RT_MAXDIST;
-        if (alive) tm = calc_inter<CULL, COUNT>(S, ro, rd, num, type, cnt);
+        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt);
         const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
         RT_PH_LAP(cnt, PH_SCAN);
         const f3 pt = ro + rd * tm;
@@ -1669,7 +1671,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
             Q.st(P, QS_W, w_s);
             Q.st(P, QS_K, k_mask);
             P.fence();
-            col = calc_shade<CULL, COUNT>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
+            col = calc_shade<CULL, COUNT, GROUPS>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
         }
         RT_PH_LAP(cnt, PH_SHADE);
 

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     path.base = path_lds + threadIdx.x;
     path.fence_slot = p.ps_fence_slot;
 #endif
-    const f4 px = trace_pixel<CULL, COUNT, WIDE>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);
+    const f4 px = trace_pixel<CULL, COUNT, WIDE, (WPE == RT_WPE_HEAVY && !COUNT && !LDS)>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);   // group culls: the many-primitive variant only
 
     // The pixel's coordinates are needed again only here. They are RE-DERIVED from the thread index
     // (laundered through an empty asm so the compiler cannot keep the first copy alive) instead of

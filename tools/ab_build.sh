@@ -9,6 +9,6 @@ BASE="-DRT_WAVES_PER_EU=6 -DRT_WPE_HEAVY=7 --offload-arch=gfx950 -O3 -fno-slp-ve
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc $BASE $flags -shared -o raytracing_opengl_amd/variants/librtx_hip_$name.so \
-      raytracing_opengl_amd/csrc/rt_kernel.hip -x hip raytracing_opengl_amd/csrc/rtx_capi.cpp 2>&1 | grep -v "warning\|^$" | head -5; echo "built $name" ) &
+      raytracing_opengl_amd/csrc/rt_kernel.hip raytracing_opengl_amd/csrc/smaa_kernel.hip raytracing_opengl_amd/csrc/bands_kernel.hip -x hip raytracing_opengl_amd/csrc/rtx_capi.cpp -ldl 2>&1 | grep -v "warning\|^$" | head -5; echo "built $name" ) &
 done
 wait
