@@ -343,3 +343,25 @@ def test_error_behaviour():
     with pytest.raises(wrapper.RtxError):
         gl.draw()  # blocks missing
     gl.stop()
+
+
+@pytest.mark.parametrize("kind,w,h,depth", [("default", 3840, 2160, 4), ("quadric", 3840, 2160, 4), ("torus", 3840, 2160, 6), ("default", 7680, 4320, 4)])
+def test_culls_and_kernel_variants_change_nothing_at_full_size(kind, w, h, depth):
+    """Every BASELINE configuration at its FULL size: the product path (culls on; the many-primitive variant with its group culls where it
+    is selected) against the literal scans (RTX_OPT_CULL = 0) on the GPU itself -- frames bit for bit, ray counters equal. The oracle
+    cannot audit 8 M pixels per case in seconds; the un-culled kernel, itself pinned to the oracle at small sizes above, can."""
+    from raytracing_opengl_amd import textures
+    ts = textures.default_texture_set(scale=4)
+    sc = scenes.build_scene(kind, w, h, depth)
+    frames, counts = [], []
+    for cull, count in ((1, 0), (1, 1), (0, 1)):          # product variant (no counters), counting variant, literal scans
+        gl = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
+        gl.set_option(wrapper.RTX_OPT_CULL, cull)
+        gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, count)
+        gl.draw()
+        frames.append(gl.read_pixels(wrapper.RTX_RGBA32F).view(np.uint32))
+        st = gl.stats()
+        counts.append((st["rays_closest"], st["rays_shadow"]))
+        gl.stop()
+    assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[1], frames[2])
+    assert counts[1] == counts[2] and counts[1][0] > w * h
