@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: many random scenes (tests/random_scenes.py) through the C ABI against the oracle -- max pixel difference and
-ray counts -- beyond the 40 seeds the test suite runs. usage: tools/fuzz_gpu.py first_seed count [width height]"""
+ray counts -- beyond the seeds the test suite runs. Each scene is drawn twice: with the counting kernel variant (ray counts) and with the
+PRODUCT variant (no counters; the many-primitive variant with its group culls where it is selected); both frames must be within the bar.
+usage: [FUZZ_GEN=random_scene|nasty_scene|scaled_quat_scene|crowd_scene] tools/fuzz_gpu.py first_seed count [width height]"""
 import os
 import sys
 
@@ -22,23 +24,29 @@ def main():
     worst, bad = 0.0, 0
     for seed in range(first, first + count):
         w, h = fixed or sizes[seed % len(sizes)]
-        sc = random_scenes.nasty_scene(seed, w, h) if os.environ.get("FUZZ_NASTY") else random_scenes.random_scene(seed, w, h)
+        gen = os.environ.get("FUZZ_GEN", "nasty_scene" if os.environ.get("FUZZ_NASTY") else "random_scene")
+        sc = getattr(random_scenes, gen)(seed, w, h)
         ref, cnt = oracle.OracleScene(sc, w, h, ts["textures"], ts["cubemap"], texture_lod=1).render()
         gl = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
         gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
         gl.draw()
         img = gl.read_pixels()
         st = gl.stats()
+        gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 0)
+        gl.draw()
+        img_product = gl.read_pixels()
         gl.stop()
-        nan_bad = int((np.isnan(img) ^ np.isnan(ref)).sum()) + int((np.isinf(img) ^ np.isinf(ref)).sum())
-        fin = np.isfinite(img) & np.isfinite(ref)
-        mx = float(np.abs(np.where(fin, img - ref, 0.0)).max())
+        nan_bad, mx = 0, 0.0
+        for im in (img, img_product):
+            nan_bad += int((np.isnan(im) ^ np.isnan(ref)).sum()) + int((np.isinf(im) ^ np.isinf(ref)).sum())
+            fin = np.isfinite(im) & np.isfinite(ref)
+            mx = max(mx, float(np.abs(np.where(fin, im - ref, 0.0)).max()))
         rays_ok = st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
         worst = max(worst, mx)
         if nan_bad or mx > 1e-4 or not rays_ok:
             bad += 1
             print(f"seed {seed}: max {mx:.3e} nan-mismatch {nan_bad} rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
-    print(f"{count} scenes from seed {first} ({'%dx%d' % fixed if fixed else 'mixed sizes'}): {bad} outside the bar, worst max-abs difference {worst:.3e}")
+    print(f"{os.environ.get('FUZZ_GEN', 'random_scene')}: {count} scenes from seed {first} ({'%dx%d' % fixed if fixed else 'mixed sizes'}): {bad} outside the bar, worst max-abs difference {worst:.3e}")
 
 
 if __name__ == "__main__":
