@@ -252,6 +252,13 @@ def main():
                 _r, c1 = o.render(y, y + 1, threads=1)
                 one_rays += c1["rays_closest"] + c1["rays_shadow"]
             one_s = time.perf_counter() - c0
+            # The oracle applies the quad-derivative texture rule by running every 2x2 quad as four ucontext coroutines -- a checker's
+            # structure, not a renderer's. The same frame with level-0 textures needs no quads and runs as plain loops: reported beside, as
+            # the closer stand-in for "the shader math on the host cores" (a different texture state: not the value).
+            o0 = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=0)
+            c0 = time.perf_counter()
+            _r0, cnt0 = o0.render(0, H, threads=cores)
+            plain_s = time.perf_counter() - c0
             try:
                 cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
             except Exception:
@@ -260,6 +267,9 @@ def main():
                                    "cores": cores, "kind": "port", "cpu": cpu_model,
                                    "one_thread": {"value": round(one_rays / one_s / 1e6, 4), "unit": "Mray/s",
                                                   "sample": f"{len(rows)} rows spread over the frame, {one_s:.2f} s"},
+                                   "without_quad_coroutines": {"value": round((cnt0["rays_closest"] + cnt0["rays_shadow"]) / plain_s / 1e6, 3), "unit": "Mray/s",
+                                                               "sample": f"one full frame with level-0 textures (plain loops, no 2x2-quad coroutines), {plain_s:.2f} s"},
+                                   "note": "the oracle is the CHECKER (scalar, contraction-free, quads as coroutines): a baseline for orientation, not a tuned CPU renderer",
                                    "sample": f"{reps} full {W}x{H} depth-{args.depth} frames of the same workload (mean {cpu_s:.2f} s each), "
                                              f"oracle/rt_oracle.c, OpenMP over rows"}
             # the oracle frame is there anyway: report full-size parity next to the timing

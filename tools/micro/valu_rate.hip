@@ -25,9 +25,9 @@ struct WaveRec { unsigned long long t0, t1, r0, r1; unsigned hw_id, xcc_id; };
 #define REP8(X) X X X X X X X X
 #define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
-enum { K_FMA, K_ADD, K_MUL, K_MOV, K_MAX, K_CMP, K_CNDMASK, K_PK_FMA, K_PK_MUL, K_RCP, K_ADD_U32, K_FMAC, K_COUNT };
+enum { K_FMA, K_ADD, K_MUL, K_MOV, K_MAX, K_CMP, K_CNDMASK, K_PK_FMA, K_PK_MUL, K_RCP, K_ADD_U32, K_FMAC, K_CNDMASK_SGPR, K_CMP_CNDMASK, K_MIN, K_SQRT, K_CVT_UBYTE, K_DIV_FIXUP, K_COUNT };
 static const char* const kNames[K_COUNT] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_mov_b32", "v_max_f32", "v_cmp_lt_f32", "v_cndmask_b32", "v_pk_fma_f32",
-                                            "v_pk_mul_f32", "v_rcp_f32", "v_add_u32", "v_fmac_f32"};
+                                            "v_pk_mul_f32", "v_rcp_f32", "v_add_u32", "v_fmac_f32", "v_cndmask_e64(sgpr)", "cmp+cndmask pair", "v_min_f32", "v_sqrt_f32", "v_cvt_f32_ubyte0", "v_div_fixup_f32"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void stream(WaveRec* rec, float* sink, int iters, float s)
@@ -54,6 +54,12 @@ __global__ __launch_bounds__(256) void stream(WaveRec* rec, float* sink, int ite
             if (KIND == K_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if (KIND == K_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
             if (KIND == K_FMAC) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i]) : "v"(s));
+            if (KIND == K_CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(s) : "s20", "s21");
+            if (KIND == K_CMP_CNDMASK) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(s) : "vcc");   // counted as ONE
+            if (KIND == K_MIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (KIND == K_SQRT) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == K_CVT_UBYTE) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a[i]));
+            if (KIND == K_DIV_FIXUP) asm volatile("v_div_fixup_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(s));
         }
     }
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1));
@@ -115,10 +121,12 @@ int main()
     hipMalloc(&d_rec, 256 * 8 * 4 * sizeof(WaveRec));
     hipMalloc(&d_sink, 256 * 8 * 256 * sizeof(float));
     const int iters = 4000;
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 4, 8}) {
         run<K_FMA>(d_rec, d_sink, w, iters); run<K_ADD>(d_rec, d_sink, w, iters); run<K_MUL>(d_rec, d_sink, w, iters); run<K_MOV>(d_rec, d_sink, w, iters);
         run<K_MAX>(d_rec, d_sink, w, iters); run<K_CMP>(d_rec, d_sink, w, iters); run<K_CNDMASK>(d_rec, d_sink, w, iters); run<K_PK_FMA>(d_rec, d_sink, w, iters);
         run<K_PK_MUL>(d_rec, d_sink, w, iters); run<K_RCP>(d_rec, d_sink, w, iters); run<K_ADD_U32>(d_rec, d_sink, w, iters); run<K_FMAC>(d_rec, d_sink, w, iters);
+        run<K_CNDMASK_SGPR>(d_rec, d_sink, w, iters); run<K_CMP_CNDMASK>(d_rec, d_sink, w, iters); run<K_MIN>(d_rec, d_sink, w, iters); run<K_SQRT>(d_rec, d_sink, w, iters);
+        run<K_CVT_UBYTE>(d_rec, d_sink, w, iters); run<K_DIV_FIXUP>(d_rec, d_sink, w, iters);
     }
     return 0;
 }
