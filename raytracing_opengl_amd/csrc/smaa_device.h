@@ -222,58 +222,53 @@ struct Blend {
     {
         return sample_rg(V.area, AREA_W, AREA_H, (20.0f * e1 + d1) + 80.0f, 20.0f * e2 + d2);
     }
-    SM_HDM F2 diag_weights(float X, float Y, F2 e) const   // SMAACalculateDiagWeights (SMAA.h:918-985)
+    // SMAACalculateDiagWeights (SMAA.h:918-985) in two steps: the four diagonal searches -- independent of each other -- and the rest.
+    // diag_search(k): k = 0 / 1 the first pair (towards (-1,+1) / (+1,-1)), k = 2 / 3 the second ((-1,-1) / (+1,+1)); returns (distance,
+    // last weight) as the shader's d.x/d.z, d.y/d.w. The HIP kernel gives each search to its own lane (smaa_kernel.hip).
+    SM_HDM F2 diag_search(int k, float X, float Y, F2 e) const
+    {
+        F2 end{0.0f, 0.0f};
+        if (k == 0) {
+            if (!(e.x > 0.0f)) return F2{0.0f, 0.0f};
+            const F2 r = search_diag1(X, Y, -1.0f, 1.0f, end);
+            return F2{r.x + ((end.y > 0.9f) ? 1.0f : 0.0f), r.y};
+        }
+        if (k == 1) return search_diag1(X, Y, 1.0f, -1.0f, end);
+        if (k == 2) return search_diag2(X, Y, -1.0f, -1.0f, end);
+        if (!(edges_at(X, Y, 1, 0).x > 0.0f)) return F2{0.0f, 0.0f};
+        const F2 r = search_diag2(X, Y, 1.0f, 1.0f, end);
+        return F2{r.x + ((end.y > 0.9f) ? 1.0f : 0.0f), r.y};
+    }
+    SM_HDM F2 diag_weights_from(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r) const
     {
         F2 wts{0.0f, 0.0f};
-        F2 end{0.0f, 0.0f};
-        float dx, dy, dz, dw;
-        if (e.x > 0.0f) {
-            const F2 r = search_diag1(X, Y, -1.0f, 1.0f, end);
-            dx = r.x + ((end.y > 0.9f) ? 1.0f : 0.0f);
-            dz = r.y;
-        } else {
-            dx = 0.0f;
-            dz = 0.0f;
+        {
+            const float dx = s0r.x, dz = s0r.y, dy = s1r.x, dw = s1r.y;
+            if (dx + dy > 2.0f) {
+                const F2 s0 = edges_at((-dx + 0.25f) * 1.0f + X, dx * 1.0f + Y, -1, 0), s1 = edges_at(dy * 1.0f + X, (-dy - 0.25f) * 1.0f + Y, 1, 0);
+                // c.yxwz = decode(c.xyzw): decoded red of each fetch lands in c.y / c.w, rounded green in c.x / c.z
+                const float cy = decode1(s0.x), cx = rintf(s0.y), cw = decode1(s1.x), cz = rintf(s1.y);
+                float c1 = 2.0f * cx + cy, c2 = 2.0f * cz + cw;
+                if (step_(0.9f, dz) != 0.0f) c1 = 0.0f;
+                if (step_(0.9f, dw) != 0.0f) c2 = 0.0f;
+                const F2 a = area_diag(dx, dy, c1, c2);
+                wts.x += a.x;
+                wts.y += a.y;
+            }
         }
         {
-            const F2 r = search_diag1(X, Y, 1.0f, -1.0f, end);
-            dy = r.x;
-            dw = r.y;
-        }
-        if (dx + dy > 2.0f) {
-            const F2 s0 = edges_at((-dx + 0.25f) * 1.0f + X, dx * 1.0f + Y, -1, 0), s1 = edges_at(dy * 1.0f + X, (-dy - 0.25f) * 1.0f + Y, 1, 0);
-            // c.yxwz = decode(c.xyzw): decoded red of each fetch lands in c.y / c.w, rounded green in c.x / c.z
-            const float cy = decode1(s0.x), cx = rintf(s0.y), cw = decode1(s1.x), cz = rintf(s1.y);
-            float c1 = 2.0f * cx + cy, c2 = 2.0f * cz + cw;
-            if (step_(0.9f, dz) != 0.0f) c1 = 0.0f;
-            if (step_(0.9f, dw) != 0.0f) c2 = 0.0f;
-            const F2 a = area_diag(dx, dy, c1, c2);
-            wts.x += a.x;
-            wts.y += a.y;
-        }
-        {
-            const F2 r = search_diag2(X, Y, -1.0f, -1.0f, end);
-            dx = r.x;
-            dz = r.y;
-        }
-        if (edges_at(X, Y, 1, 0).x > 0.0f) {
-            const F2 r = search_diag2(X, Y, 1.0f, 1.0f, end);
-            dy = r.x + ((end.y > 0.9f) ? 1.0f : 0.0f);
-            dw = r.y;
-        } else {
-            dy = 0.0f;
-            dw = 0.0f;
-        }
-        if (dx + dy > 2.0f) {
-            const float ax = -dx * 1.0f + X, ay = -dx * 1.0f + Y, bx = dy * 1.0f + X, by = dy * 1.0f + Y;
-            const float cx = edges_at(ax, ay, -1, 0).y, cy = edges_at(ax, ay, 0, -1).x;
-            const F2 s = edges_at(bx, by, 1, 0);
-            float c1 = 2.0f * cx + cy, c2 = 2.0f * s.y + s.x;
-            if (step_(0.9f, dz) != 0.0f) c1 = 0.0f;
-            if (step_(0.9f, dw) != 0.0f) c2 = 0.0f;
-            const F2 a = area_diag(dx, dy, c1, c2);
-            wts.x += a.y;
-            wts.y += a.x;
+            const float dx = s2r.x, dz = s2r.y, dy = s3r.x, dw = s3r.y;
+            if (dx + dy > 2.0f) {
+                const float ax = -dx * 1.0f + X, ay = -dx * 1.0f + Y, bx = dy * 1.0f + X, by = dy * 1.0f + Y;
+                const float cx = edges_at(ax, ay, -1, 0).y, cy = edges_at(ax, ay, 0, -1).x;
+                const F2 s = edges_at(bx, by, 1, 0);
+                float c1 = 2.0f * cx + cy, c2 = 2.0f * s.y + s.x;
+                if (step_(0.9f, dz) != 0.0f) c1 = 0.0f;
+                if (step_(0.9f, dw) != 0.0f) c2 = 0.0f;
+                const F2 a = area_diag(dx, dy, c1, c2);
+                wts.x += a.y;
+                wts.y += a.x;
+            }
         }
         return wts;
     }
@@ -352,29 +347,57 @@ struct Blend {
         wts.y *= sat_(fy);
     }
 
-    // SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) for the pixel at (x, y); returns the RGBA8 texel
+    // The four horizontal / vertical searches of SMAABlendingWeightCalculationPS (SMAA.h:1171-1179,1211-1219), k = 0 left, 1 right, 2 up,
+    // 3 down: the texel-space coordinate the search ends at. Independent of each other, like the diagonal ones.
+    SM_HDM float ortho_search(int k, float X, float Y) const
+    {
+        const float S = (float)P.max_steps;
+        if (k == 0) return search_x(X - 0.25f, Y - 0.125f, (-2.0f * S) * 1.0f + (X - 0.25f), -1.0f);
+        if (k == 1) return search_x(X + 1.25f, Y - 0.125f, (2.0f * S) * 1.0f + (X + 1.25f), 1.0f);
+        if (k == 2) return search_y(X - 0.125f, Y - 0.25f, (-2.0f * S) * 1.0f + (Y - 0.25f), -1.0f);
+        return search_y(X - 0.125f, Y + 1.25f, (2.0f * S) * 1.0f + (Y + 1.25f), 1.0f);
+    }
+    SM_HDM F2 north_from(float X, float Y, float cx, float cz) const   // weights.rg from the ends of the two x searches
+    {
+        const float cy = Y - 0.25f;
+        const float e1 = edges_at(cx, cy).x;
+        const float d1 = fabsf(rintf(cx - X)), d2 = fabsf(rintf(cz - X));
+        const float e2 = edges_at(cz, cy, 1, 0).x;
+        F2 wgt = area(sqrtf(d1), sqrtf(d2), e1, e2);
+        corners(wgt, cx, Y, cz, Y, d1, d2, true);
+        return wgt;
+    }
+    SM_HDM F2 west_from(float X, float Y, float cy, float cz) const    // weights.ba from the ends of the two y searches
+    {
+        const float cx = X - 0.25f;
+        const float e1 = edges_at(cx, cy).y;
+        const float d1 = fabsf(rintf(cy - Y)), d2 = fabsf(rintf(cz - Y));
+        const float e2 = edges_at(cx, cz, 0, 1).y;
+        F2 wgt = area(sqrtf(d1), sqrtf(d2), e1, e2);
+        corners(wgt, X, cy, X, cz, d1, d2, false);
+        return wgt;
+    }
+    SM_HDM static uint32_t pack_weights(F4 w) { return to_unorm8(w.x) | (to_unorm8(w.y) << 8) | (to_unorm8(w.z) << 16) | (to_unorm8(w.w) << 24); }
+
+    // SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) for the pixel at (x, y); returns the RGBA8 texel. One thread does everything in
+    // the shader's order (host build, reference for the lane-parallel form in smaa_kernel.hip).
     SM_HDM uint32_t weights(int x, int y) const
     {
-        const float X = (float)x, Y = (float)y, S = (float)P.max_steps;
+        const float X = (float)x, Y = (float)y;
         F4 out{0.0f, 0.0f, 0.0f, 0.0f};
         F2 e = texel_rg(V.edges, V.w, V.h, x, y);
         if (e.y > 0.0f) {
             bool hv = true;
             if (P.max_steps_diag > 0) {
-                const F2 dwt = diag_weights(X, Y, e);
+                const F2 dwt = diag_weights_from(X, Y, diag_search(0, X, Y, e), diag_search(1, X, Y, e), diag_search(2, X, Y, e), diag_search(3, X, Y, e));
                 out.x = dwt.x;
                 out.y = dwt.y;
                 hv = (out.x == -out.y);
             }
             if (hv) {
-                const float cx = search_x(X - 0.25f, Y - 0.125f, (-2.0f * S) * 1.0f + (X - 0.25f), -1.0f);
-                const float cy = Y - 0.25f;
-                const float e1 = edges_at(cx, cy).x;
-                const float cz = search_x(X + 1.25f, Y - 0.125f, (2.0f * S) * 1.0f + (X + 1.25f), 1.0f);
-                const float d1 = fabsf(rintf(cx - X)), d2 = fabsf(rintf(cz - X));
-                const float e2 = edges_at(cz, cy, 1, 0).x;
-                F2 wgt = area(sqrtf(d1), sqrtf(d2), e1, e2);
-                corners(wgt, cx, Y, cz, Y, d1, d2, true);
+                const float cx = ortho_search(0, X, Y);
+                const float cz = ortho_search(1, X, Y);
+                const F2 wgt = north_from(X, Y, cx, cz);
                 out.x = wgt.x;
                 out.y = wgt.y;
             } else {
@@ -382,18 +405,13 @@ struct Blend {
             }
         }
         if (e.x > 0.0f) {
-            const float cy = search_y(X - 0.125f, Y - 0.25f, (-2.0f * S) * 1.0f + (Y - 0.25f), -1.0f);
-            const float cx = X - 0.25f;
-            const float e1 = edges_at(cx, cy).y;
-            const float cz = search_y(X - 0.125f, Y + 1.25f, (2.0f * S) * 1.0f + (Y + 1.25f), 1.0f);
-            const float d1 = fabsf(rintf(cy - Y)), d2 = fabsf(rintf(cz - Y));
-            const float e2 = edges_at(cx, cz, 0, 1).y;
-            F2 wgt = area(sqrtf(d1), sqrtf(d2), e1, e2);
-            corners(wgt, X, cy, X, cz, d1, d2, false);
+            const float cy = ortho_search(2, X, Y);
+            const float cz = ortho_search(3, X, Y);
+            const F2 wgt = west_from(X, Y, cy, cz);
             out.z = wgt.x;
             out.w = wgt.y;
         }
-        return to_unorm8(out.x) | (to_unorm8(out.y) << 8) | (to_unorm8(out.z) << 16) | (to_unorm8(out.w) << 24);
+        return pack_weights(out);
     }
 };
 
