@@ -911,6 +911,7 @@ int rtx_draw(rtx_context* ctx)
     if (ctx->owner) return fail(RTX_ERR_INVALID, "rtx_draw on a peer of a multi-device context: draw through the root");
     int st;
     if (!ctx->peers.empty()) {
+        if (ctx->smaa_preset >= 0 && !(ctx->gather_targets & 2)) return fail(RTX_ERR_ORDER, "SMAA needs the RGBA8 target on the root: RTX_OPT_GATHER_TARGETS must include 2");
         st = multi_draw(ctx);
         if (st == RTX_OK && ctx->smaa_preset >= 0) {   // the post-process runs on the root once the frame is assembled
             st = use_device(ctx);
@@ -962,6 +963,7 @@ int rtx_smaa_resolve(rtx_context* ctx)
     if (ctx->smaa_preset < 0) return fail(RTX_ERR_ORDER, "rtx_smaa_resolve: SMAA is not enabled (rtx_enable_smaa)");
     int st = use_device(ctx);
     if (st) return st;
+    if ((st = multi_sync(ctx)) != RTX_OK) return st;   // a multi-device root: the RGBA8 target is assembled on the transfer stream
     return smaa_resolve(ctx, ctx->stream);
 }
 
