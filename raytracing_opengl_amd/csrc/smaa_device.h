@@ -86,7 +86,13 @@ SM_HD F2 sample_rg(const uint16_t* t, int w, int h, float tx, float ty, int ox =
     const float a = tx - fx, b = ty - fy;
     const int i0 = clampi((int)fx + ox, w - 1), i1 = clampi((int)fx + ox + 1, w - 1);
     const int j0 = clampi((int)fy + oy, h - 1), j1 = clampi((int)fy + oy + 1, h - 1);
-    const uint32_t p00 = t[(size_t)j0 * w + i0], p10 = t[(size_t)j0 * w + i1], p01 = t[(size_t)j1 * w + i0], p11 = t[(size_t)j1 * w + i1];
+    // A tap whose weight is exactly 0 is not fetched: 0 * texel is +0 for every texel and x + 0 = x, so the sum is the same bits. Most of
+    // SMAA's fetches sit on a texel row, column or centre (a == 0 and / or b == 0); the weight kernel is bound by cache-line look-ups of
+    // scattered 2-byte taps, not by arithmetic, so this is worth up to 4x fewer of them.
+    const uint32_t p00 = t[(size_t)j0 * w + i0];
+    const uint32_t p10 = a != 0.0f ? t[(size_t)j0 * w + i1] : 0u;
+    const uint32_t p01 = b != 0.0f ? t[(size_t)j1 * w + i0] : 0u;
+    const uint32_t p11 = (a != 0.0f && b != 0.0f) ? t[(size_t)j1 * w + i1] : 0u;
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     F2 r;
     r.x = w00 * unorm8(p00 & 255u) + w10 * unorm8(p10 & 255u) + w01 * unorm8(p01 & 255u) + w11 * unorm8(p11 & 255u);
@@ -109,7 +115,8 @@ SM_HD F4 sample_rgba(const uint32_t* t, int w, int h, float tx, float ty)
     const float a = tx - fx, b = ty - fy;
     const int i0 = clampi((int)fx, w - 1), i1 = clampi((int)fx + 1, w - 1);
     const int j0 = clampi((int)fy, h - 1), j1 = clampi((int)fy + 1, h - 1);
-    const F4 t00 = unpack4(t[(size_t)j0 * w + i0]), t10 = unpack4(t[(size_t)j0 * w + i1]), t01 = unpack4(t[(size_t)j1 * w + i0]), t11 = unpack4(t[(size_t)j1 * w + i1]);
+    const F4 t00 = unpack4(t[(size_t)j0 * w + i0]), t10 = unpack4(a != 0.0f ? t[(size_t)j0 * w + i1] : 0u), t01 = unpack4(b != 0.0f ? t[(size_t)j1 * w + i0] : 0u),
+             t11 = unpack4((a != 0.0f && b != 0.0f) ? t[(size_t)j1 * w + i1] : 0u);   // zero-weight taps are not fetched (see sample_rg)
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     F4 r;
     r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
@@ -125,7 +132,8 @@ SM_HD float sample_r8(const uint8_t* t, int w, int h, float tx, float ty)
     const int i0 = clampi((int)fx, w - 1), i1 = clampi((int)fx + 1, w - 1);
     const int j0 = clampi((int)fy, h - 1), j1 = clampi((int)fy + 1, h - 1);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-    return w00 * unorm8(t[j0 * w + i0]) + w10 * unorm8(t[j0 * w + i1]) + w01 * unorm8(t[j1 * w + i0]) + w11 * unorm8(t[j1 * w + i1]);
+    const uint32_t p10 = a != 0.0f ? t[j0 * w + i1] : 0u, p01 = b != 0.0f ? t[j1 * w + i0] : 0u, p11 = (a != 0.0f && b != 0.0f) ? t[j1 * w + i1] : 0u;
+    return w00 * unorm8(t[j0 * w + i0]) + w10 * unorm8(p10) + w01 * unorm8(p01) + w11 * unorm8(p11);
 }
 
 // ---- pass 1: luma edges (SMAA.h:689-741) ----------------------------------------------------------------------

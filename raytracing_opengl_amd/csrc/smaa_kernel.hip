@@ -246,12 +246,10 @@ __global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned
     }
 }
 
-// Blending weights, FOUR lanes per edge pixel. The weight computation is a chain of searches along the edge, each a chain of dependent
-// fetches (up to 2 x 16 diagonal + 2 x 32 axial steps at ULTRA), and a frame has only ~1 200 waves' worth of edge pixels -- one or two
-// waves per SIMD, nothing to hide the latency behind: one thread per pixel ran 50 us at 4K on a pipe that was idle. The four diagonal
-// searches are independent of each other, and so are the four axial ones; here lane k of a pixel's quad runs search k of each round and
-// the quad exchanges the results with cross-lane moves. Every value is computed by the same operations as in the one-thread form
-// (smaa::Blend::weights, which the host build and the oracle comparison use), merely in another lane.
+// Blending weights, one thread per listed pixel. (A four-lanes-per-pixel form -- the four searches of a round in parallel lanes, results
+// exchanged by cross-lane moves; smaa::Blend keeps the pieces it used: diag_search / ortho_search / north_from / west_from -- was byte-exact
+// and no faster on sparse frames, twice slower on dense ones: the kernel is bound by the cache-line look-ups of its scattered 2-byte taps,
+// not by the length of a pixel's dependent chain. profiles/r02_smaa_ablation.txt)
 __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int preset, unsigned cur)
 {
     __shared__ SegmentedList L;
@@ -260,48 +258,10 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
     const smaa::Preset P = smaa::preset_of(preset);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
     const smaa::Blend B{V, P};
-    const int role = threadIdx.x & 3;
-    const int quad0 = (threadIdx.x & 63) & ~3;                                 // first lane of this pixel's quad within the wave
-    const unsigned per_pass = gridDim.x * blockDim.x / 4u;
-    for (unsigned base = 0; base < n; base += per_pass) {                       // wave-uniform trip count: the cross-lane moves need every lane
-        const unsigned i = base + (blockIdx.x * blockDim.x + threadIdx.x) / 4u;
-        const bool live = i < n;
-        const uint32_t p = live ? L.entry(b, i) : 0u;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = L.entry(b, i);
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
-        const float X = (float)x, Y = (float)y;
-        smaa::F2 e = smaa::texel_rg(V.edges, V.w, V.h, x, y);
-        if (!live) e = smaa::F2{0.0f, 0.0f};
-        smaa::F4 out{0.0f, 0.0f, 0.0f, 0.0f};
-        bool north = e.y > 0.0f, diag_found = false;
-        if (P.max_steps_diag > 0) {                                             // round 1: the four diagonal searches, one per lane
-            smaa::F2 mine{0.0f, 0.0f};
-            if (north) mine = B.diag_search(role, X, Y, e);
-            smaa::F2 r[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { r[k].x = __shfl(mine.x, quad0 + k, 64); r[k].y = __shfl(mine.y, quad0 + k, 64); }
-            if (north) {
-                const smaa::F2 dwt = B.diag_weights_from(X, Y, r[0], r[1], r[2], r[3]);
-                out.x = dwt.x;
-                out.y = dwt.y;
-                diag_found = !(out.x == -out.y);
-            }
-        }
-        const bool do_north = north && !diag_found, do_west = e.x > 0.0f && !diag_found;   // "else e.r = 0": a diagonal skips the vertical part
-        float end = 0.0f;                                                       // round 2: the four axial searches, one per lane
-        if (role < 2 ? do_north : do_west) end = B.ortho_search(role, X, Y);
-        float c[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = __shfl(end, quad0 + k, 64);
-        if (role == 0 && do_north) {
-            const smaa::F2 wgt = B.north_from(X, Y, c[0], c[1]);
-            out.x = wgt.x;
-            out.y = wgt.y;
-        }
-        smaa::F2 west{0.0f, 0.0f};
-        if (role == 1 && do_west) west = B.west_from(X, Y, c[2], c[3]);        // the two halves on two lanes
-        out.z = __shfl(west.x, quad0 + 1, 64);
-        out.w = __shfl(west.y, quad0 + 1, 64);
-        if (live && role == 0) b.blend[p] = smaa::Blend::pack_weights(out);
+        b.blend[p] = B.weights(x, y);
     }
 }
 
@@ -356,7 +316,7 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     if (strip_h == 4) hipLaunchKernelGGL(smaa_edges_kernel<4>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
     else if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
     else hipLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
-    hipLaunchKernelGGL(smaa_weights_kernel, dim3(4096), dim3(256), 0, stream, b, preset, cur);   // four lanes per listed pixel
+    hipLaunchKernelGGL(smaa_weights_kernel, sparse, dim3(256), 0, stream, b, preset, cur);
     hipLaunchKernelGGL(smaa_blend_kernel, sparse, dim3(256), 0, stream, b, cur);
     return hipGetLastError();
 }
