@@ -114,7 +114,8 @@ def test_scaled_quaternion_scene_on_gpu(built, small_textures, seed):
     gl.stop()
     fin = np.isfinite(img) & np.isfinite(ref)
     assert (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all(), seed
-    assert float(np.abs(np.where(fin, img - ref, 0.0)).max()) <= 1e-4, seed
+    with np.errstate(invalid="ignore", over="ignore"):       # non-unit quaternions scale normals: pixels can reach 1e13 -> relative above 1
+        assert float((np.abs(np.where(fin, img - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()) <= 1e-4, seed
     assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"], seed
 
 
@@ -148,7 +149,8 @@ def test_fuzz_sweep_on_gpu(built, small_textures, gen):
         st = gl.stats()
         fin = np.isfinite(img) & np.isfinite(ref)
         ok = (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all()
-        ok = ok and float(np.abs(np.where(fin, img - ref, 0.0)).max()) <= 1e-4
+        with np.errstate(invalid="ignore", over="ignore"):   # 1e-4 on colours; relative to the pixel where a degenerate scene's values exceed 1
+            ok = ok and float((np.abs(np.where(fin, img - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()) <= 1e-4
         ok = ok and st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
         if not ok:
             bad.append(seed)

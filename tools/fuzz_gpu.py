@@ -46,12 +46,17 @@ def main():
         for im in (img, img_product):
             nan_bad += int((np.isnan(im) ^ np.isnan(ref)).sum()) + int((np.isinf(im) ^ np.isinf(ref)).sum())
             fin = np.isfinite(im) & np.isfinite(ref)
-            mx = max(mx, float(np.abs(np.where(fin, im - ref, 0.0)).max()))
+            with np.errstate(invalid="ignore", over="ignore"):
+                # the bar is 1e-4 on colours; a scene whose pixels reach 1e13 (non-unit quaternions scale normals, pow() of values > 1)
+                # is judged relative to the pixel: 1e-4 * max(1, |reference|)
+                mx = max(mx, float((np.abs(np.where(fin, im - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()))
         rays_ok = st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
         worst = max(worst, mx)
         if nan_bad or mx > 1e-4 or not rays_ok:
             bad += 1
-            print(f"seed {seed}: max {mx:.3e} nan-mismatch {nan_bad} rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
+            print(f"seed {seed}: max (relative above 1) {mx:.3e} nan-mismatch {nan_bad} rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
+        if (seed - first + 1) % 1000 == 0:
+            print(f"... {seed - first + 1} scenes, {bad} outside the bar so far, worst {worst:.3e}", flush=True)
     print(f"{os.environ.get('FUZZ_GEN', 'random_scene')}: {count} scenes from seed {first} ({'%dx%d' % fixed if fixed else 'mixed sizes'}): {bad} outside the bar, worst max-abs difference {worst:.3e}")
 
 
