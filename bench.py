@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds", type=int, default=0)
     ap.add_argument("--cull", type=int, default=1)
+    ap.add_argument("--pencils", type=int, default=1, help="1: ray-pencil candidate masks for scenes with long quadric / torus tables; 0: two-level scans only")
     ap.add_argument("--xcd", type=int, default=0, help="1: XCD-aware super-tile workgroup order; 0: row-major")
     ap.add_argument("--lod", type=int, default=1, help="1: mip chain + quad-derivative LOD (reference texture state); 0: level-0 bilinear")
     ap.add_argument("--target", choices=("rgba32f", "rgba8"), default="rgba32f",
@@ -85,6 +86,7 @@ def main():
     gl.set_option(wrapper.RTX_OPT_CULL, args.cull)
     gl.set_option(wrapper.RTX_OPT_SCENE_LDS, args.lds)
     gl.set_option(wrapper.RTX_OPT_XCD_REMAP, args.xcd)
+    gl.set_option(wrapper.RTX_OPT_RAY_PENCILS, args.pencils)
 
     band_rows = ((H + 7) // 8) * 8 if world == 1 else bands.choose_band_rows(H, world)
     target = args.target
@@ -143,6 +145,7 @@ def main():
 
     n_ev = min(args.steps, 128)
     kernel_ms = gl.sum_recent_draw_ms(n_ev) / n_ev  # HIP events on the launch stream
+    st_end = gl.stats()
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -170,7 +173,10 @@ def main():
                                    f"{target.upper()} target, seeded synthetic textures at reference sizes/{args.texture_scale}",
                        "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
                        "parallelism": "single GPU" if world == 1 else f"{world} GPUs, interleaved {band_rows}-row bands, RCCL gather of the {target.upper()} frame to rank 0",
-                       "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd},
+                       "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd,
+                       # ray pencils: candidate masks built on the device when the scene changes (not per frame: the bench scene is static,
+                       # like its packed tables); build_ms is the cost a scene update adds
+                       "ray_pencils": {"count": st_end["pencils"], "build_ms": round(st_end["last_pencil_build_ms"], 4)}},
             "ms_per_frame": round(ms_per_step, 4),
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

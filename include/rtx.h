@@ -85,6 +85,10 @@ typedef enum rtx_option {
                                 that they do not form the tail of the launch; 0: plain row order. Same results either way. */
     RTX_OPT_GATHER_TARGETS = 7, /* multi-device contexts: which colour targets travel to the root each draw: 1 = RGBA32F only, 2 = RGBA8
                                 only (what the reference's framebuffer holds: a quarter of the bytes), 3 (default) = both */
+    RTX_OPT_RAY_PENCILS = 8,  /* 1 (default): scenes with a long quadric / torus table (16 .. 128 entries) get per-pencil candidate masks --
+                                camera rays by direction, shadow rays by direction from a point light or by position across a directional
+                                light -- built on the device whenever the scene changes; scans of such rays walk the wave's candidates
+                                instead of the whole table. 0: two-level scans only. Same results. */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which register budget of the trace kernel runs: 0 = 6 waves/SIMD,
                                 1 = 7 waves/SIMD (spills to scratch, hides the scalar table walks of scenes with many
                                 primitives), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
@@ -100,6 +104,8 @@ typedef struct rtx_stats {
     float last_smaa_ms;        /* HIP-event time of the last SMAA resolve (all of its kernels), 0 if none ran */
     float last_gather_ms;      /* multi-device contexts: transfer + band placement of the last frame on the root (0 otherwise) */
     uint32_t smaa_edge_pixels; /* pixels with an edge in the last resolve (the sparse passes' work list) */
+    float last_pencil_build_ms; /* HIP-event time of the last ray-pencil mask build (runs when the scene changed; 0: scene has none) */
+    uint32_t pencils;          /* ray pencils of the current scene (RTX_OPT_RAY_PENCILS) */
 } rtx_stats;
 
 RTX_API const char* rtx_last_error(void);

@@ -15,7 +15,7 @@ RTX_OK = 0
 RTX_RGBA32F, RTX_RGBA8, RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_WEIGHTS_RGBA8 = 0, 1, 2, 3, 4
 RTX_SMAA_OFF, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_HIGH, RTX_SMAA_ULTRA = -1, 0, 1, 2, 3
 RTX_WRAP_REPEAT, RTX_WRAP_CLAMP_TO_EDGE = 0, 1
-RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_GATHER_TARGETS = 0, 1, 2, 3, 4, 5, 6, 7
+RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_GATHER_TARGETS, RTX_OPT_RAY_PENCILS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 RTX_GATHER_RCCL, RTX_GATHER_PEER_COPY = 0, 1
 
 # every symbol include/rtx.h declares (tests/test_capi_symbols.py checks the .so against this list)
@@ -39,7 +39,8 @@ class Defines(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("last_draw_ms", ctypes.c_float), ("launches", ctypes.c_uint32), ("rays_closest", ctypes.c_uint64),
                 ("rays_shadow", ctypes.c_uint64), ("rays_shadow_cast", ctypes.c_uint64), ("torus_solves", ctypes.c_uint64),
-                ("last_smaa_ms", ctypes.c_float), ("last_gather_ms", ctypes.c_float), ("smaa_edge_pixels", ctypes.c_uint32)]
+                ("last_smaa_ms", ctypes.c_float), ("last_gather_ms", ctypes.c_float), ("smaa_edge_pixels", ctypes.c_uint32),
+                ("last_pencil_build_ms", ctypes.c_float), ("pencils", ctypes.c_uint32)]
 
 
 _lib = None

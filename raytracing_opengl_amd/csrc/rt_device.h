@@ -267,13 +267,16 @@ struct SceneView {
     RT_HDM const f4* ring_bound() const { return at<f4>(h->off_ring_bound); }
     RT_HDM const f4* surf_group() const { return at<f4>(h->off_surf_group); }
     RT_HDM const f4* torus_group() const { return at<f4>(h->off_torus_group); }
+    RT_HDM const DevPencil* pencils() const { return at<DevPencil>(h->off_pencil); }
+    const uint32_t* pen;       // pencil masks (a buffer of their own, built on the device), nullptr = none
 };
 // `hdr` normally is the blob's own first record; with the tables staged in LDS it stays in global memory.
-RT_HD SceneView make_view(const char* blob, const DevSceneHeader* hdr)
+RT_HD SceneView make_view(const char* blob, const DevSceneHeader* hdr, const uint32_t* pencil_masks = nullptr)
 {
     SceneView S;
     S.h = hdr;
     S.blob = blob;
+    S.pen = pencil_masks;
     return S;
 }
 RT_HD SceneView make_view(const char* blob) { return make_view(blob, reinterpret_cast<const DevSceneHeader*>(blob)); }
@@ -920,16 +923,165 @@ RT_HD bool surface_group_cull(f4 g, f3 ro, f3 rd)
     const float d2 = dot3_fma(oc, oc);
     return fmaf(b, b, -(a * (d2 - g.w))) < -1e-5f * a * d2;
 }
-RT_HD bool quadric_may_degenerate(const DevSurfaceCull& Q, f3 rd)
+RT_HD float quadric_p2(const DevSurfaceCull& Q, f3 rd)
 {
     const float dxx = rd.x * rd.x, dyy = rd.y * rd.y, dzz = rd.z * rd.z;
     const float dxy = 2.0f * (rd.x * rd.y), dxz = 2.0f * (rd.x * rd.z), dyz = 2.0f * (rd.y * rd.z);
-    const float p2 = fmaf(Q.sym1.x, dyz, fmaf(Q.sym0.z, dxz, fmaf(Q.sym0.y, dxy, fmaf(Q.sym1.y, dzz, fmaf(Q.sym0.w, dyy, Q.sym0.x * dxx)))));
-    return !(fabsf(p2) > Q.sym1.z);
+    return fmaf(Q.sym1.x, dyz, fmaf(Q.sym0.z, dxz, fmaf(Q.sym0.y, dxy, fmaf(Q.sym1.y, dzz, fmaf(Q.sym0.w, dyy, Q.sym0.x * dxx)))));
+}
+RT_HD bool quadric_may_degenerate(const DevSurfaceCull& Q, f3 rd)
+{
+    return !(fabsf(quadric_p2(Q, rd)) > Q.sym1.z);
 }
 #ifndef RT_GROUP_MIN
 #define RT_GROUP_MIN 16   /* tables shorter than this keep the one-level scan */
 #endif
+
+// ---- third level: ray pencils (rt_scene_dev.h DevPencil) ----
+// A cell's mask promises: bit i clear => for EVERY ray of the cell that passes the lane-level preconditions below, primitive i's own
+// first-level test (surface_cull / torus_cull) would return "culled". The scans only ever visit FEWER primitives than the two-level
+// scan would, in the same index order, and every visited primitive still runs its own first-level test: results cannot change.
+//  * cube-map cells (APEX): a ray of the pencil lies on a line through the apex whose direction is in the cell; the builder compares
+//    the angle between the cell's axis and the centre of the primitive's bound with (cell half-angle + angular radius of the bound).
+//    A shadow ray ends at the light only up to rounding: it passes the apex within ulp(|origin|) + 1e-7 * length, which the lane-level
+//    limits (|origin| <= 1e3, length <= 1e3) keep below the 4e-3 the builder adds to every radius.
+//  * plane cells (PARALLEL): the ray is the line origin + t * a with the pencil's own direction a, i.e. ONE point of the plane across
+//    a; the builder compares the projected bound with the cell's rectangle (the outermost cells reach to infinity).
+//  * quadrics also need "not on the degenerate branch" (trap T4, see surface_cull): p2 = d^T M d varies by at most 2 |M| theta over unit
+//    directions within theta of the cell axis, so |p2(axis)| > 2 |M| theta + margin rules the branch out for the whole cell; for a
+//    PARALLEL pencil the direction is the same for every ray and the test is the kernel's own.
+//  * preconditions every lane checks itself: unit direction (|d.d - 1| <= 1e-3: the torus premise, and what the p2 bound assumes);
+//    anything else -- NaNs included -- reads the all-ones cell, i.e. falls back to the full table.
+RT_HD f3 pencil_face_dir(int face, float u, float v)
+{
+    const float s = (face & 1) ? -1.0f : 1.0f;
+    return (face >> 1) == 0 ? mk3(s, u, v) : ((face >> 1) == 1 ? mk3(u, s, v) : mk3(u, v, s));
+}
+RT_HD uint32_t pencil_cell_apex(const DevPencil& P, uint32_t stride, f3 w_in, bool ok)
+{
+    const f3 w = ok ? w_in : mk3(1.0f, 0.0f, 0.0f);
+    const float ax = fabsf(w.x), ay = fabsf(w.y), az = fabsf(w.z);
+    int face;
+    float m, a, b;
+    if (ax >= ay && ax >= az) { face = w.x < 0.0f ? 1 : 0; m = ax; a = w.y; b = w.z; }
+    else if (ay >= az) { face = w.y < 0.0f ? 3 : 2; m = ay; a = w.x; b = w.z; }
+    else { face = w.z < 0.0f ? 5 : 4; m = az; a = w.x; b = w.y; }
+    const int R = P.res;
+    const float half = 0.5f * (float)R, top = (float)(R - 1);
+    const float k = half / m;
+    const int i = (int)gl_min(gl_max(a * k + half, 0.0f), top), j = (int)gl_min(gl_max(b * k + half, 0.0f), top);
+    const uint32_t cell = ok ? (uint32_t)((face * R + j) * R + i) : P.cells;
+    return P.mask_off + cell * stride;
+}
+RT_HD uint32_t pencil_cell_parallel(const DevPencil& P, uint32_t stride, f3 pt_in, bool ok)
+{
+    const f3 pt = ok ? pt_in : mk3(0.0f, 0.0f, 0.0f);
+    const float top = (float)(P.res - 1);
+    const float u = (dot3_fma(pt, xyz(P.e1)) - P.e1.w) * P.grid.x, v = (dot3_fma(pt, xyz(P.e2)) - P.e2.w) * P.grid.y;
+    const int i = (int)gl_min(gl_max(u, 0.0f), top), j = (int)gl_min(gl_max(v, 0.0f), top);
+    const uint32_t cell = ok ? (uint32_t)(j * P.res + i) : P.cells;
+    return P.mask_off + cell * stride;
+}
+// lane-level preconditions (see above); false for NaN
+RT_HD bool pencil_ray_ok(f3 ro, f3 rd, float len) { return unit_direction(dot3_fma(rd, rd)) && dot3_fma(ro, ro) <= 1.0e6f && len <= 1.0e3f; }
+
+// OR over the wave's participating lanes (wave-uniform result). Lanes of a wave mostly share a handful of cells, so "take the first
+// lane that still has something new" finishes in a few rounds; butterfly reductions would need every lane of the wave enabled.
+RT_HD uint32_t wave_or(uint32_t own, bool on)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t rem = on ? own : 0u, uni = 0u;
+    unsigned long long b;
+    while ((b = __ballot(rem != 0u)) != 0ull) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)rem, __builtin_ctzll(b));
+        uni |= s;
+        rem &= ~s;
+    }
+    return uni;
+#else
+    return on ? own : 0u;
+#endif
+}
+
+// ---- the builder: one cell of one pencil (one thread per cell on the device, rt_kernel.hip; a loop in the host build) ----
+struct PencilCell {      // geometry of a cell
+    f3 axis;             // APEX: unit direction of the cell centre
+    float theta;         // APEX: half-angle of the cone around `axis` that contains the cell, plus slack
+    float ulo, uhi, vlo, vhi;   // PARALLEL: the cell's rectangle (outer cells: +-inf)
+};
+RT_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_HD float angle_between(f3 a, f3 b) { return atan2f(length3(cross3(a, b)), dot3(a, b)); }   // well-conditioned at 0 and pi, unlike acos
+RT_HD bool pencil_bound_misses(const DevPencil& P, const PencilCell& C, f3 c, float r2)
+{
+    const float r = sqrtf(r2) + 4.0e-3f + 1.0e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
+    if (P.kind == RT_PENCIL_APEX) {
+        const f3 v = c - xyz(P.a);
+        const float D2 = dot3(v, v);
+        if (!(D2 > 1.01f * r * r)) return false;          // apex inside (or almost inside) the bound: every direction may hit. NaN too.
+        const float alpha = asinf(r / sqrtf(D2));          // r/D < 0.996: well-conditioned
+        return angle_between(C.axis, v) > C.theta + alpha;
+    }
+    const float cu = dot3(c, xyz(P.e1)), cv = dot3(c, xyz(P.e2));
+    const float rr = r + 1.0e-3f * gl_max(P.grid.z, P.grid.w);
+    return cu + rr < C.ulo || cu - rr > C.uhi || cv + rr < C.vlo || cv - rr > C.vhi;   // NaN -> false
+}
+RT_HD void pencil_build_cell(const SceneView& S, const DevPencil& P, uint32_t cell, uint32_t* out)
+{
+    const int ns = S.h->n_surface, nt = S.h->n_torus;
+    const int nws = (ns + 31) >> 5, nwt = (nt + 31) >> 5;
+    if (cell >= P.cells) {                                  // the all-ones cell: every primitive that exists
+        for (int w = 0; w < nws; w++) out[w] = ns - w * 32 >= 32 ? ~0u : (1u << (ns - w * 32)) - 1u;
+        for (int w = 0; w < nwt; w++) out[nws + w] = nt - w * 32 >= 32 ? ~0u : (1u << (nt - w * 32)) - 1u;
+        return;
+    }
+    PencilCell C;
+    C.axis = mk3(0.0f, 0.0f, 1.0f); C.theta = 0.0f; C.ulo = C.uhi = C.vlo = C.vhi = 0.0f;
+    const int R = P.res;
+    if (P.kind == RT_PENCIL_APEX) {
+        const int face = (int)cell / (R * R), j = ((int)cell / R) % R, i = (int)cell % R;
+        const float step = 2.0f / (float)R;
+        const float u0 = -1.0f + step * (float)i, u1 = -1.0f + step * (float)(i + 1), v0 = -1.0f + step * (float)j, v1 = -1.0f + step * (float)(j + 1);
+        C.axis = normalize3(pencil_face_dir(face, 0.5f * (u0 + u1), 0.5f * (v0 + v1)));
+        float th = angle_between(C.axis, pencil_face_dir(face, u0, v0));
+        th = gl_max(th, angle_between(C.axis, pencil_face_dir(face, u1, v0)));
+        th = gl_max(th, angle_between(C.axis, pencil_face_dir(face, u0, v1)));
+        th = gl_max(th, angle_between(C.axis, pencil_face_dir(face, u1, v1)));
+        C.theta = th + 2.0e-3f;   // slack: the lookup's rounding at cell borders, |d| within 1e-3 of 1, the builder's own arithmetic
+    } else {
+        const int j = (int)cell / R, i = (int)cell % R;
+        const float inf = __builtin_huge_valf();
+        C.ulo = i == 0 ? -inf : P.e1.w + P.grid.z * (float)i;
+        C.uhi = i == R - 1 ? inf : P.e1.w + P.grid.z * (float)(i + 1);
+        C.vlo = j == 0 ? -inf : P.e2.w + P.grid.w * (float)j;
+        C.vhi = j == R - 1 ? inf : P.e2.w + P.grid.w * (float)(j + 1);
+    }
+    for (int w = 0; w < nws; w++) {
+        uint32_t bits = 0u;
+        for (int b = 0; b < 32 && w * 32 + b < ns; b++) {
+            const DevSurfaceCull Q = S.surf_cull()[w * 32 + b];
+            bool clear = false;
+            if (Q.bound.w >= 0.0f) {
+                const float normF = sqrtf(Q.sym0.x * Q.sym0.x + Q.sym0.w * Q.sym0.w + Q.sym1.y * Q.sym1.y +
+                                          2.0f * (Q.sym0.y * Q.sym0.y + Q.sym0.z * Q.sym0.z + Q.sym1.x * Q.sym1.x));
+                const bool apex = P.kind == RT_PENCIL_APEX;
+                const float p2 = fabsf(quadric_p2(Q, apex ? C.axis : xyz(P.a)));
+                const float vary = apex ? 2.01f * normF * C.theta : 0.0f;
+                if (p2 > vary + 1.01f * Q.sym1.z + 1.0e-5f * normF) clear = pencil_bound_misses(P, C, xyz(Q.bound), Q.bound.w);
+            }
+            if (!clear) bits |= 1u << b;
+        }
+        out[w] = bits;
+    }
+    for (int w = 0; w < nwt; w++) {
+        uint32_t bits = 0u;
+        for (int b = 0; b < 32 && w * 32 + b < nt; b++) {
+            const f4 tb = S.torus_bound()[w * 32 + b];
+            const bool clear = tb.w >= 0.0f && pencil_bound_misses(P, C, xyz(tb), tb.w);   // inf radius: sqrt(inf) = inf, never "misses"
+            if (!clear) bits |= 1u << b;
+        }
+        out[nws + w] = bits;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // closest hit (rt.frag:587-628) and any-hit (rt.frag:630-658)
@@ -963,13 +1115,39 @@ RT_HD int lane_pop(unsigned long long& m)
 
 // GROUPS: compile the second-level group culls in. Only the many-primitive kernel variant (and the host build) does: in the default
 // variant the extra code cost 2.5 % of the default scene's frame time through the instruction cache without ever being executed.
+// The pencil of a scan, if it has one: wave-uniform `use`, the lane's cell (dword offset of its first mask word) and the mask word
+// fetched ahead (the next word is requested before the current one is walked; words of a cell: quadrics first, then tori).
+struct PencilScan {
+    bool use;
+    uint32_t cell, cur;
+    int word;
+    RT_HDM uint32_t next(const SceneView& S) { const uint32_t own = cur; word++; cur = S.pen[cell + word]; return own; }   // (a spare word follows the table)
+};
+template <bool ENABLED>
+RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float len, bool from_apex)
+{
+    PencilScan ps;
+    ps.use = false; ps.cell = 0u; ps.cur = 0u; ps.word = 0;
+    if (!ENABLED || pencil < 0 || S.pen == nullptr || pencil >= (int)S.h->n_pencil) return ps;
+    const DevPencil& P = S.pencils()[pencil];
+    if (P.kind == RT_PENCIL_OFF) return ps;
+    const uint32_t stride = S.h->pencil_stride;
+    // from_apex: the ray starts AT the apex (camera rays: exactly, nothing to check about its origin); otherwise it runs towards it
+    const bool ok = from_apex ? unit_direction(dot3_fma(rd, rd)) : pencil_ray_ok(ro, rd, P.kind == RT_PENCIL_APEX ? len : 0.0f);
+    ps.cell = P.kind == RT_PENCIL_APEX ? pencil_cell_apex(P, stride, from_apex ? rd : -rd, ok) : pencil_cell_parallel(P, stride, ro, ok);
+    ps.cur = S.pen[ps.cell];
+    ps.use = true;
+    return ps;
+}
+
 template <bool CULL, bool COUNT, bool GROUPS = true>
-RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt)
+RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1)
 {
     float tmin = RT_MAXDIST;
     float t = 0.0f;
     if (COUNT) cnt.closest++;
     RT_PH_DECL;
+    PencilScan ps = pencil_open<GROUPS && CULL>(S, pencil, ro, rd, 0.0f, true);
     for (int i = 0; i < S.h->n_plane; i++) {
         if (intersect_plane(ro, rd, xyz(S.planes()[i].normal), xyz(S.planes()[i].pos), tmin, t)) { num = i; tmin = t; type = TYPE_PLANE; }
     }
@@ -983,7 +1161,23 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         }
     }
     RT_PH_LAP(cnt, PH_C_SPH);
-    {
+    if (ps.use) {
+        const int nws = (S.h->n_surface + 31) >> 5;
+        const DevSurfaceCull* cullrec = S.surf_cull();
+        for (int w = 0; w < nws; w++) {
+            const uint32_t own = ps.next(S);
+            uint32_t u = wave_or(own, true);
+            while (u != 0u) {
+                const int b = __builtin_ctz(u), i = (w << 5) + b;
+                u &= u - 1u;
+                const DevSurfaceCull c0 = cullrec[i];
+                const bool need = ((own >> b) & 1u) != 0u && !surface_cull(c0, ro, rd);
+                if (RT_ANY(need)) {
+                    if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
+                }
+            }
+        }
+    } else {
         const int n = S.h->n_surface;
         const DevSurfaceCull* cullrec = S.surf_cull();
         const bool grouped = GROUPS && CULL && n >= RT_GROUP_MIN;
@@ -1025,6 +1219,17 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             const int end = base + 64 < n ? base + 64 : n;
             const bool grouped = GROUPS && n >= RT_GROUP_MIN;
             bool group_live = true;
+            if (ps.use) {   // phase 1 over the wave's pencil candidates only
+                for (int w = base >> 5; w << 5 < end; w++) {
+                    const uint32_t own = ps.next(S);
+                    uint32_t u = wave_or(own, true);
+                    while (u != 0u) {
+                        const int b = __builtin_ctz(u), i = (w << 5) + b;
+                        u &= u - 1u;
+                        if (((own >> b) & 1u) != 0u && !torus_cull(bound[i], ro, rd, tmin)) cand |= 1ull << (i - base);
+                    }
+                }
+            } else
             for (int i = base; i < end; i += 4) {
                 if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin));
                 if (!group_live) continue;   // wave-uniform: no lane can reach any of the group's tori
@@ -1095,11 +1300,12 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
 // early exit is exact. The any-hit scan is an OR (a float sum for textured rings only), so the
 // cheap classes go first; ring order is kept for the sum.
 template <bool CULL, bool COUNT, bool GROUPS = true>
-RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt)
+RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt, int pencil = -1)
 {
     float shadow = 0.0f;
     float t = 0.0f;
     if (COUNT && on) cnt.shadow_cast++;
+    PencilScan ps = pencil_open<GROUPS && CULL>(S, RT_ANY(on) ? pencil : -1, ro, rd, dist, false);
     if (RT_ANY(on)) {
         const int n = S.h->n_sphere;
         const f4* geom = S.sph_geom();
@@ -1117,7 +1323,25 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             if (!RT_ANY(on)) break;
         }
     }
-    if (RT_ANY(on)) {
+    if (ps.use) {
+        // the word counter must advance past the quadric words even when every lane is already in shadow
+        const int nws = (S.h->n_surface + 31) >> 5;
+        const DevSurfaceCull* cullrec = S.surf_cull();
+        for (int w = 0; w < nws; w++) {
+            const uint32_t own = ps.next(S);
+            uint32_t u = wave_or(own, on);
+            while (u != 0u) {
+                const int b = __builtin_ctz(u), i = (w << 5) + b;
+                u &= u - 1u;
+                const DevSurfaceCull c0 = cullrec[i];
+                const bool need = on && ((own >> b) & 1u) != 0u && !surface_cull(c0, ro, rd);
+                if (RT_ANY(need)) {
+                    if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; }
+                    if (!RT_ANY(on)) u = 0u;
+                }
+            }
+        }
+    } else if (RT_ANY(on)) {
         const int n = S.h->n_surface;
         const DevSurfaceCull* cullrec = S.surf_cull();
         const bool grouped = GROUPS && CULL && n >= RT_GROUP_MIN;
@@ -1152,6 +1376,17 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 const int end = base + 64 < n ? base + 64 : n;
                 const bool grouped = GROUPS && n >= RT_GROUP_MIN;
                 bool group_live = true;
+                if (ps.use) {
+                    for (int w = base >> 5; w << 5 < end; w++) {
+                        const uint32_t own = ps.next(S);
+                        uint32_t u = wave_or(own, on);
+                        while (u != 0u) {
+                            const int b = __builtin_ctz(u), i = (w << 5) + b;
+                            u &= u - 1u;
+                            if (on && ((own >> b) & 1u) != 0u && !torus_cull(bound[i], ro, rd, dist)) cand |= 1ull << (i - base);
+                        }
+                    }
+                } else
                 for (int i = base; i < end; i += 4) {
                     if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, dist));
                     if (!group_live) continue;
@@ -1277,7 +1512,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         // (NaN dp must still take the full path so that it propagates like in the shader.)
         const bool cast = on && !(dp == 0.0f);
         RT_PH_BEGIN(_sh0);
-        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS>(S, T, cast, on, pt, light_dir, dist, cnt);
+        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS>(S, T, cast, on, pt, light_dir, dist, cnt, 1 + li);   // pencil 0 is the camera's
         RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
@@ -1538,6 +1773,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
     const int iterations = S.h->iterations;
     bool side = false;  // the NEXT trip traces getReflectedColor's ray; the refracted continuation of the main path waits
                         // in PS_CONT_RO / PS_CONT_RD while it runs
+    int cam_pencil = 0; // the first trip traces the camera rays: pencil 0; every later ray starts somewhere else
 
     alive = alive && iterations > 0;
     RT_PH_DECL;
@@ -1551,7 +1787,8 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- one closest-hit ray per live lane ----
         int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
         float tm = RT_MAXDIST;
-        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt);
+        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt, cam_pencil);
+        cam_pencil = -1;
         const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
         RT_PH_LAP(cnt, PH_SCAN);
         const f3 pt = ro + rd * tm;

@@ -18,8 +18,11 @@ struct RtLaunchParams {
     float* out_f32;           // RGBA32F, 16 B/pixel, or nullptr
     uint32_t* out_u8;         // RGBA8, 4 B/pixel, or nullptr
     unsigned long long* counters;  // 4 x u64 (COUNT variant) or nullptr
+    const uint32_t* pencil_masks;  // ray-pencil masks of this scene (rt_launch_pencil_build) or nullptr
     rtdev::TexTable tex;
 };
 
 hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream);
+// Fills the ray-pencil masks of the scene at d_scene (host copy of its header and pencil records: n_pencil, cells). One thread per cell.
+hipError_t rt_launch_pencil_build(const char* d_scene, const rtdev::DevSceneHeader& hdr, const rtdev::DevPencil* pencils, uint32_t* d_masks, hipStream_t stream);
 hipError_t rt_launch_selftest(int* d_result, hipStream_t stream);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     // A copy in the kernel arguments was measured slower: the compiler keeps all of it in SGPRs, runs out,
     // and parks the excess in VGPR lanes -- v_writelane/v_readlane are VALU issue slots, and VALU issue
     // is what bounds this kernel (4K default scene: 765 -> 741 us without the copy).
-    const SceneView S = make_view(blob, reinterpret_cast<const DevSceneHeader*>(p.scene));
+    const SceneView S = make_view(blob, reinterpret_cast<const DevSceneHeader*>(p.scene), p.pencil_masks);
 
     LaneCounters cnt = {};
 #ifdef RT_PHASE_TIMERS
@@ -212,6 +212,17 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     }
 }
 
+// Ray-pencil masks (rt_device.h pencil_build_cell): blockIdx.y = pencil, one thread per cell (+ the all-ones cell). Runs when the scene
+// changes, in front of the first trace launch that uses it, on the same stream.
+__global__ __launch_bounds__(256) void rt_pencil_build_kernel(const char* scene, uint32_t* masks)
+{
+    const SceneView S = make_view(scene);
+    const DevPencil P = S.pencils()[blockIdx.y];
+    const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
+    if (P.kind == RT_PENCIL_OFF || cell > P.cells) return;
+    pencil_build_cell(S, P, cell, masks + P.mask_off + (size_t)cell * S.h->pencil_stride);
+}
+
 // device-side exhaustive check of unorm8 (result[0] = number of mismatching byte values)
 __global__ void rt_selftest_kernel(int* result)
 {
@@ -262,6 +273,16 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
         case 6: return launch_variant<true, true, false>(p, grid, shmem, stream);
         default: return launch_variant<true, true, true>(p, grid, shmem, stream);
     }
+}
+
+hipError_t rt_launch_pencil_build(const char* d_scene, const DevSceneHeader& hdr, const DevPencil* pencils, uint32_t* d_masks, hipStream_t stream)
+{
+    uint32_t most = 0;
+    for (uint32_t k = 0; k < hdr.n_pencil; k++)
+        if (pencils[k].kind != RT_PENCIL_OFF && pencils[k].cells > most) most = pencils[k].cells;
+    if (most == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_pencil_build_kernel, dim3((most + 1 + 255) / 256, hdr.n_pencil), dim3(256), 0, stream, d_scene, d_masks);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_selftest(int* d_result, hipStream_t stream)

@@ -224,6 +224,14 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     h.off_ring_bound = reserve(sizeof(f4) * pad(d.ring_size, 4));
     h.off_surf_group = reserve(sizeof(f4) * pad(d.surface_size, RT_GROUP) / RT_GROUP + 16);
     h.off_torus_group = reserve(sizeof(f4) * pad(d.torus_size, RT_GROUP) / RT_GROUP + 16);
+    // ray pencils (rt_scene_dev.h): the camera, then every point light, then every directional light -- as many as fit. Only for
+    // scenes with a long quadric or torus table (and at most RT_PENCIL_MAX_PRIMS of each: four mask words per class).
+    const bool long_tables = (d.surface_size >= RT_PENCIL_MIN_PRIMS || d.torus_size >= RT_PENCIL_MIN_PRIMS) &&
+                             d.surface_size <= RT_PENCIL_MAX_PRIMS && d.torus_size <= RT_PENCIL_MAX_PRIMS;
+    const int n_pencil = !long_tables ? 0 : (1 + d.light_point_size + d.light_direct_size < RT_MAX_PENCILS ? 1 + d.light_point_size + d.light_direct_size : RT_MAX_PENCILS);
+    h.n_pencil = static_cast<uint32_t>(n_pencil);
+    h.off_pencil = reserve(sizeof(DevPencil) * (n_pencil + 1));
+    h.pencil_stride = static_cast<uint32_t>((d.surface_size + 31) / 32 + (d.torus_size + 31) / 32);
     h.total_bytes = static_cast<int32_t>(off);
     blob.assign(off, 0);
     std::memcpy(blob.data(), &h, sizeof h);
@@ -416,6 +424,66 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const f3 ln = normalize3(-xyz(s.direction));
         s.dir_n = mk4(ln.x, ln.y, ln.z, 0.0f);
         std::memcpy(reinterpret_cast<DevLightDirect*>(blob.data() + h.off_light_direct) + i, &s, sizeof s);
+    }
+    // pencil headers (the masks are built on the device from these and the cull records above)
+    {
+        uint32_t mask_words = 0;
+        auto finite3 = [](f4 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
+        auto small3 = [&](f4 v) { return finite3(v) && std::fabs(v.x) <= 1.0e3f && std::fabs(v.y) <= 1.0e3f && std::fabs(v.z) <= 1.0e3f; };
+        for (int k = 0; k < n_pencil; k++) {
+            DevPencil P;
+            std::memset(&P, 0, sizeof P);
+            P.kind = RT_PENCIL_OFF;
+            if (k == 0 || k - 1 < d.light_point_size) {
+                const f4 apex = k == 0 ? h.cam_pos : (reinterpret_cast<const DevLightPoint*>(blob.data() + h.off_light_point) + (k - 1))->pos_r2;
+                if (small3(apex)) {   // a far-away apex loses the float precision the builder's margins assume: no pencil then
+                    P.kind = RT_PENCIL_APEX;
+                    P.a = mk4(apex.x, apex.y, apex.z, 0.0f);
+                    P.res = RT_PENCIL_APEX_RES;
+                    P.cells = 6u * RT_PENCIL_APEX_RES * RT_PENCIL_APEX_RES;
+                }
+            } else {
+                const f4 dn = (reinterpret_cast<const DevLightDirect*>(blob.data() + h.off_light_direct) + (k - 1 - d.light_point_size))->dir_n;
+                const double ax = dn.x, ay = dn.y, az = dn.z, n2 = ax * ax + ay * ay + az * az;
+                if (finite3(dn) && std::fabs(n2 - 1.0) <= 1e-5) {
+                    // e1, e2: an orthonormal pair across the direction, in double
+                    double bx = 0, by = 0, bz = 0;
+                    if (std::fabs(ax) <= std::fabs(ay) && std::fabs(ax) <= std::fabs(az)) bx = 1; else if (std::fabs(ay) <= std::fabs(az)) by = 1; else bz = 1;
+                    double e1x = ay * bz - az * by, e1y = az * bx - ax * bz, e1z = ax * by - ay * bx;
+                    const double l1 = std::sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
+                    e1x /= l1; e1y /= l1; e1z /= l1;
+                    double e2x = ay * e1z - az * e1y, e2y = az * e1x - ax * e1z, e2z = ax * e1y - ay * e1x;
+                    const double l2 = std::sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
+                    e2x /= l2; e2y /= l2; e2z /= l2;
+                    // extent of the bounded quadrics / tori in that plane
+                    double ulo = 1e300, uhi = -1e300, vlo = 1e300, vhi = -1e300;
+                    auto add = [&](f4 b) {
+                        if (!(b.w >= 0.0f) || !std::isfinite(b.w) || !finite3(b)) return;
+                        const double r = std::sqrt(static_cast<double>(b.w)), u = b.x * e1x + b.y * e1y + b.z * e1z, v = b.x * e2x + b.y * e2y + b.z * e2z;
+                        ulo = std::fmin(ulo, u - r); uhi = std::fmax(uhi, u + r); vlo = std::fmin(vlo, v - r); vhi = std::fmax(vhi, v + r);
+                    };
+                    for (int i = 0; i < d.surface_size; i++) add((reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + i)->bound);
+                    for (int i = 0; i < d.torus_size; i++) add(reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i]);
+                    if (!(ulo <= uhi)) { ulo = vlo = -1.0; uhi = vhi = 1.0; }
+                    const int R = RT_PENCIL_PAR_RES;
+                    const double su = std::fmax((uhi - ulo) / (R - 2), 1e-3), sv = std::fmax((vhi - vlo) / (R - 2), 1e-3);   // cells 1 .. R-2 tile the extent
+                    if (std::isfinite(su) && std::isfinite(sv) && su < 1e6 && sv < 1e6 && std::fabs(ulo) < 1e6 && std::fabs(vlo) < 1e6) {
+                        P.kind = RT_PENCIL_PARALLEL;
+                        P.a = mk4(dn.x, dn.y, dn.z, 0.0f);
+                        P.e1 = mk4(static_cast<float>(e1x), static_cast<float>(e1y), static_cast<float>(e1z), static_cast<float>(ulo - su));
+                        P.e2 = mk4(static_cast<float>(e2x), static_cast<float>(e2y), static_cast<float>(e2z), static_cast<float>(vlo - sv));
+                        P.grid = mk4(static_cast<float>(1.0 / su), static_cast<float>(1.0 / sv), static_cast<float>(su), static_cast<float>(sv));
+                        P.res = R;
+                        P.cells = static_cast<uint32_t>(R) * R;
+                    }
+                }
+            }
+            P.mask_off = mask_words;
+            if (P.kind != RT_PENCIL_OFF) mask_words += (P.cells + 1u) * h.pencil_stride;
+            std::memcpy(reinterpret_cast<DevPencil*>(blob.data() + h.off_pencil) + k, &P, sizeof P);
+        }
+        DevSceneHeader* hp = reinterpret_cast<DevSceneHeader*>(blob.data());
+        hp->pencil_mask_words = n_pencil > 0 ? mask_words + 4u : 0u;   // + spare words: the scans request one word ahead
     }
     return true;
 }

@@ -114,6 +114,29 @@ struct alignas(16) DevSceneHeader {
     // first-level bounds (centre, radius^2; w < 0 or inf: the group has an unbounded member and is never culled)
     uint32_t off_surf_group;
     uint32_t off_torus_group;
+    // ray pencils (DevPencil below): n_pencil = 0 when the scene has none. The masks themselves are built on the device (rt_kernel.hip
+    // pencil_build_kernel) into a buffer of their own; pencil_stride = mask words per cell (quadric words first, then torus words)
+    uint32_t n_pencil, off_pencil, pencil_stride, pencil_mask_words;
+};
+
+// ---- ray pencils: third-level cull for long tables ---------------------------------------------
+// Most rays of a frame belong to one of a few PENCILS: camera rays all start at the eye, shadow rays towards a point light all end at
+// the light, shadow rays towards a directional light are all parallel. A pencil's rays are indexed by two numbers (a direction from the
+// apex: cube-map cell; or a position in the plane across the common direction: grid cell), and for every cell the builder records which
+// quadrics / tori a ray of that cell could possibly need -- one bit per primitive, conservative (bit clear = the primitive's own
+// first-level cull would provably reject every ray of the cell). A scan then visits the set bits of the wave's OR of its lanes' cells
+// instead of walking the whole table. Rays outside any pencil (mirror / refracted rays) keep the two-level scan.
+enum { RT_MAX_PENCILS = 8, RT_PENCIL_APEX_RES = 64, RT_PENCIL_PAR_RES = 128, RT_PENCIL_MAX_PRIMS = 128, RT_PENCIL_MIN_PRIMS = 16 };
+enum { RT_PENCIL_OFF = 0, RT_PENCIL_APEX = 1, RT_PENCIL_PARALLEL = 2 };
+struct alignas(16) DevPencil {
+    f4 a;          // APEX: the common point; PARALLEL: the common (unit) direction
+    f4 e1;         // PARALLEL: first in-plane axis xyz, w = coordinate of the low edge of cell 0
+    f4 e2;         // PARALLEL: second axis, w likewise
+    f4 grid;       // PARALLEL: x, y = cells per unit length along e1, e2; z, w = cell sizes
+    int32_t kind;  // RT_PENCIL_*
+    int32_t res;   // cells per cube-face edge (APEX) / per axis (PARALLEL)
+    uint32_t cells;     // number of cells; cell number `cells` is the all-ones cell for rays the pencil cannot vouch for
+    uint32_t mask_off;  // first dword of cell 0 in the mask buffer
 };
 
 // ---- textures --------------------------------------------------------------------------------

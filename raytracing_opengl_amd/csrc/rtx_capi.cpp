@@ -102,6 +102,13 @@ struct rtx_context {
     int opt_cull = 1, opt_count = 0, opt_lds = 0, opt_lod = 1, opt_xcd = 0;
     int opt_occ = -1;   // RTX_OPT_HIGH_OCCUPANCY: -1 auto (by primitive count), 0 off, 1 on
     int opt_hot = 1;    // RTX_OPT_HOT_ROWS_FIRST
+    int opt_pencils = 1;  // RTX_OPT_RAY_PENCILS
+    // ray-pencil masks of the device scene (built by upload_scene on its stream, right behind the copy)
+    uint32_t* d_pencil = nullptr;
+    size_t d_pencil_cap = 0;      // dwords
+    uint32_t n_pencil = 0;
+    hipEvent_t pencil_start = nullptr, pencil_stop = nullptr;
+    bool pencil_timed = false;
     unsigned long long* d_counters = nullptr;
     // SMAA post-process (GLWrapper::enable_SMAA + the three passes of GLWrapper.cpp:173-204): smaa_preset < 0 = off
     int smaa_preset = -1;
@@ -191,6 +198,27 @@ int upload_scene(rtx_context* ctx, hipStream_t stream)
     HIP_TRY(hipEventSynchronize(ctx->stage_done[k]));  // staging buffer k is free again
     std::memcpy(ctx->h_stage[k], ctx->blob.data(), n);
     HIP_TRY(hipMemcpyAsync(ctx->d_scene, ctx->h_stage[k], n, hipMemcpyHostToDevice, stream));
+    // the scene's ray pencils: masks built on the device from the blob just copied, ordered like the copy (before stage_done[k], which
+    // every later launch on another stream waits for)
+    const DevSceneHeader* hd = reinterpret_cast<const DevSceneHeader*>(ctx->blob.data());
+    ctx->n_pencil = 0;
+    ctx->pencil_timed = false;
+    if (hd->n_pencil > 0 && ctx->opt_pencils) {
+        if (hd->pencil_mask_words > ctx->d_pencil_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (ctx->d_pencil) HIP_TRY(hipFree(ctx->d_pencil));
+            ctx->d_pencil = nullptr;
+            const size_t cap = (static_cast<size_t>(hd->pencil_mask_words) + 1023) & ~static_cast<size_t>(1023);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_pencil), cap * sizeof(uint32_t)));
+            ctx->d_pencil_cap = cap;
+        }
+        if (!ctx->pencil_start) { HIP_TRY(hipEventCreate(&ctx->pencil_start)); HIP_TRY(hipEventCreate(&ctx->pencil_stop)); }
+        HIP_TRY(hipEventRecord(ctx->pencil_start, stream));
+        HIP_TRY(rt_launch_pencil_build(ctx->d_scene, *hd, reinterpret_cast<const DevPencil*>(ctx->blob.data() + hd->off_pencil), ctx->d_pencil, stream));
+        HIP_TRY(hipEventRecord(ctx->pencil_stop, stream));
+        ctx->n_pencil = hd->n_pencil;
+        ctx->pencil_timed = true;
+    }
     HIP_TRY(hipEventRecord(ctx->stage_done[k], stream));
     ctx->upload_stream = stream;
     ctx->last_stage = k;
@@ -317,6 +345,7 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     p.out_f32 = out_f32;
     p.out_u8 = out_u8;
     p.counters = ctx->d_counters;
+    p.pencil_masks = ctx->opt_pencils && ctx->n_pencil > 0 ? ctx->d_pencil : nullptr;
     fill_tex_table(ctx, p.tex);
     if (ctx->opt_count) HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), stream));
     if (ctx->ev_pending == EVENT_RING) {  // ring full: retire the oldest pair only (recorded EVENT_RING launches ago, long finished)
@@ -686,6 +715,9 @@ void rtx_destroy(rtx_context* ctx)
     for (auto& kv : ctx->textures)
         if (kv.second.d_texels) (void)hipFree(kv.second.d_texels);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
+    if (ctx->d_pencil) (void)hipFree(ctx->d_pencil);
+    if (ctx->pencil_start) (void)hipEventDestroy(ctx->pencil_start);
+    if (ctx->pencil_stop) (void)hipEventDestroy(ctx->pencil_stop);
     for (int k = 0; k < 2; k++) {
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
@@ -882,6 +914,7 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_XCD_REMAP: ctx->opt_xcd = value != 0; break;
         case RTX_OPT_HIGH_OCCUPANCY: ctx->opt_occ = value < 0 ? -1 : (value != 0); break;
         case RTX_OPT_HOT_ROWS_FIRST: ctx->opt_hot = value != 0; break;
+        case RTX_OPT_RAY_PENCILS: if (ctx->opt_pencils != (value != 0)) ctx->scene_dirty = true; ctx->opt_pencils = value != 0; break;   // masks are (re)built with the scene
         case RTX_OPT_GATHER_TARGETS: if (value < 1 || value > 3) return fail(RTX_ERR_INVALID, "RTX_OPT_GATHER_TARGETS: 1, 2 or 3"); ctx->gather_targets = value; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
@@ -899,6 +932,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_XCD_REMAP: *value = ctx->opt_xcd; break;
         case RTX_OPT_HIGH_OCCUPANCY: *value = ctx->opt_occ; break;
         case RTX_OPT_HOT_ROWS_FIRST: *value = ctx->opt_hot; break;
+        case RTX_OPT_RAY_PENCILS: *value = ctx->opt_pencils; break;
         case RTX_OPT_GATHER_TARGETS: *value = ctx->gather_targets; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
@@ -1058,6 +1092,11 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
     if (ctx->gather_timed) {
         HIP_TRY(hipEventSynchronize(ctx->gather_stop));
         HIP_TRY(hipEventElapsedTime(&out->last_gather_ms, ctx->gather_start, ctx->gather_stop));
+    }
+    out->pencils = ctx->n_pencil;
+    if (ctx->pencil_timed) {
+        HIP_TRY(hipEventSynchronize(ctx->pencil_stop));
+        HIP_TRY(hipEventElapsedTime(&out->last_pencil_build_ms, ctx->pencil_start, ctx->pencil_stop));
     }
     if (ctx->smaa_timed) {
         HIP_TRY(hipEventSynchronize(ctx->smaa_stop));

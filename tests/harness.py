@@ -50,7 +50,7 @@ def lib():
     return _lib
 
 
-def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=0, y1=None):
+def _frame(scene_blocks, fb_w, fb_h, textures, cubemap, cull):
     keep = []
     fr = Frame()
     fr.fb_width, fr.fb_height = fb_w, fb_h
@@ -76,7 +76,23 @@ def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=
         fr.sky_size, fr.sky_channels = first.shape[0], first.shape[2]
         for i, f in enumerate(faces):
             fr.sky_faces[i] = None if f is None else f.ctypes.data
-    fr.cull = 1 if cull else 0
+    fr.cull = int(cull) if cull in (0, 1, 2) else (1 if cull else 0)   # 1 / True: all culls; 2: culls without the ray pencils; 0: none
+    return fr, keep
+
+
+def pencil_stats(scene_blocks, fb_w=64, fb_h=64):
+    """The scene's ray pencils as the packer lays them out and the builder fills them: {'pencils', 'stride', 'each': [(kind, cells, mean
+    set bits per cell)]}."""
+    fr, _keep = _frame(scene_blocks, fb_w, fb_h, None, None, 1)
+    out = (ctypes.c_double * 32)()
+    n = lib().harness_pencil_stats(ctypes.byref(fr), out, 32)
+    if n < 2:
+        raise RuntimeError("harness_pencil_stats failed")
+    return {"pencils": int(out[0]), "stride": int(out[1]), "each": [(int(out[k]), int(out[k + 1]), out[k + 2]) for k in range(2, n, 3)]}
+
+
+def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=0, y1=None):
+    fr, _keep = _frame(scene_blocks, fb_w, fb_h, textures, cubemap, cull)
     y1 = fb_h if y1 is None else y1
     out = np.empty((y1 - y0, fb_w, 4), dtype=np.float32)
     cnt = (ctypes.c_uint64 * 4)()

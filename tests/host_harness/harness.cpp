@@ -47,7 +47,21 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
     // 16-byte aligned copy
     std::vector<f4> aligned((blob.size() + 15) / 16);
     std::memcpy(aligned.data(), blob.data(), blob.size());
-    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    // pencil masks, built by the product's own per-cell builder (a kernel on the device, a loop here). cull == 2: culls without pencils
+    const DevSceneHeader* hdr = reinterpret_cast<const DevSceneHeader*>(aligned.data());
+    std::vector<uint32_t> pencil_masks;
+    if (fr->cull == 1 && hdr->n_pencil > 0) {
+        pencil_masks.assign(hdr->pencil_mask_words, 0u);
+        const SceneView S0 = make_view(reinterpret_cast<const char*>(aligned.data()));
+        for (uint32_t k = 0; k < hdr->n_pencil; k++) {
+            const DevPencil P = S0.pencils()[k];
+            if (P.kind == RT_PENCIL_OFF) continue;
+#pragma omp parallel for schedule(static, 256)
+            for (int64_t cell = 0; cell <= static_cast<int64_t>(P.cells); cell++)
+                pencil_build_cell(S0, P, static_cast<uint32_t>(cell), pencil_masks.data() + P.mask_off + static_cast<size_t>(cell) * hdr->pencil_stride);
+        }
+    }
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()), hdr, pencil_masks.empty() ? nullptr : pencil_masks.data());
 
     TexTable T;
     std::memset(&T, 0, sizeof T);
@@ -94,6 +108,38 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
     }
     if (counters) std::memcpy(counters, tot, sizeof tot);
     return 0;
+}
+
+// Pencil diagnostics for the tests: out[0] = pencils, out[1] = mask words per cell, then per pencil (kind, cells, mean set bits per cell).
+int harness_pencil_stats(const harness_frame* fr, double* out, int max_out)
+{
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    for (int b = 0; b < 9; b++) {
+        const unsigned char* p = static_cast<const unsigned char*>(fr->blocks[b]);
+        if (p && fr->block_sizes[b]) blocks[b].assign(p, p + fr->block_sizes[b]);
+    }
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(fr->defines, blocks, blob, err)) return -1;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    int n = 0;
+    if (max_out < 2) return -1;
+    out[n++] = S.h->n_pencil;
+    out[n++] = S.h->pencil_stride;
+    std::vector<uint32_t> cellw(S.h->pencil_stride + 1);
+    for (uint32_t k = 0; k < S.h->n_pencil && n + 3 <= max_out; k++) {
+        const DevPencil P = S.pencils()[k];
+        double bits = 0.0;
+        if (P.kind != RT_PENCIL_OFF)
+            for (uint32_t cell = 0; cell < P.cells; cell++) {
+                pencil_build_cell(S, P, cell, cellw.data());
+                for (uint32_t w = 0; w < S.h->pencil_stride; w++) bits += __builtin_popcount(cellw[w]);
+            }
+        out[n++] = P.kind; out[n++] = P.cells; out[n++] = P.cells ? bits / P.cells : 0.0;
+    }
+    return n;
 }
 
 // Single-primitive entry points on the DEVICE functions (packed through rt_pack.h like the product does).

@@ -133,7 +133,7 @@ def scaled_quat_scene(seed: int, w: int, h: int):
     return type(sc)(defines=sc.defines, blocks=blocks)
 
 
-def crowd_scene(seed: int, w: int, h: int):
+def crowd_scene(seed: int, w: int, h: int, lights=None, camera=None):
     """Long primitive tables (16 ... 100 quadrics and / or tori, plus a few of everything else): exercises the second-level group culls
     (rt_device.h RT_GROUP) -- groups with an unbounded member, members with non-unit quaternions, quadrics of every kind incl. ones whose
     degenerate branch (trap T4) fires for axis-parallel rays, clusters spread far apart so that whole groups are skipped."""
@@ -175,5 +175,31 @@ def crowd_scene(seed: int, w: int, h: int):
     lights_point = [light_point((3.0, 5.0, 0.0), 0.1, intensity=25.5)]
     lights_direct = [light_direct((3.0, -1.0, 1.0))] if rng.random() < 0.7 else []
     cam_quat = quat_euler(float(rng.normal() * 0.1), float(rng.normal() * 0.2), 0.0) if rng.random() < 0.5 else (0.0, 0.0, 0.0, 1.0)
+    cam_pos = (0.0, 0.0, -5.0)
+    if lights is not None:      # pencil_scene: its own lights and camera, drawn after everything else so that the crowd stays the same
+        lights_point, lights_direct = lights
+    if camera is not None:
+        cam_pos, cam_quat = camera
     return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, lights_point=lights_point,
-                      lights_direct=lights_direct, cam_pos=(0.0, 0.0, -5.0), cam_quat=cam_quat)
+                      lights_direct=lights_direct, cam_pos=cam_pos, cam_quat=cam_quat)
+
+
+def pencil_scene(seed: int, w: int, h: int):
+    """crowd_scene's long tables under lights and cameras chosen to stress the ray pencils (rt_scene_dev.h DevPencil): 0-4 point lights --
+    in front of, inside and behind the crowd, inside a primitive's bound, thousands of units away (no pencil: precision), more lights
+    than pencils -- 0-3 directional lights incl. axis-parallel ones and the zero vector, cameras inside the crowd, far away, rotated."""
+    rng = np.random.default_rng(seed ^ 0x9e2c11)
+    spots = [(3.0, 5.0, 0.0), (0.0, 0.0, 15.0), (0.5, -0.3, 18.0), (-6.0, 9.0, 30.0), (2500.0, 900.0, -4000.0), (0.0, 40.0, 14.0), (1.0e5, 0.0, 0.0)]
+    n_point = int(rng.choice([0, 1, 1, 2, 4, 9]))
+    lights_point = []
+    for _ in range(n_point):
+        p = spots[int(rng.integers(len(spots)))]
+        p = tuple(float(v + rng.normal() * 0.5) for v in p)
+        lights_point.append(light_point(p, float(rng.choice([0.1, 0.5])), intensity=float(rng.choice([25.5, 400.0]))))
+    dirs = [(3.0, -1.0, 1.0), (0.0, -1.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0), (0.0, 0.0, 0.0), (-0.3, -0.2, -1.0)]
+    lights_direct = [light_direct(dirs[int(rng.integers(len(dirs)))]) for _ in range(int(rng.choice([0, 1, 1, 2, 3])))]
+    cams = [(0.0, 0.0, -5.0), (0.3, -0.4, 15.0), (0.0, 0.0, 40.0), (20.0, 3.0, 14.0), (0.0, 0.0, -3000.0)]
+    cam_pos = cams[int(rng.integers(len(cams)))]
+    yaw = {2: math.pi, 3: -math.pi / 2}.get(cams.index(cam_pos), 0.0)
+    cam_quat = quat_euler(float(rng.normal() * 0.1), float(yaw + rng.normal() * 0.2), 0.0)
+    return crowd_scene(seed, w, h, lights=(lights_point, lights_direct), camera=(cam_pos, cam_quat))

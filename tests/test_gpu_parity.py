@@ -353,15 +353,18 @@ def test_culls_and_kernel_variants_change_nothing_at_full_size(kind, w, h, depth
     from raytracing_opengl_amd import textures
     ts = textures.default_texture_set(scale=4)
     sc = scenes.build_scene(kind, w, h, depth)
-    frames, counts = [], []
-    for cull, count in ((1, 0), (1, 1), (0, 1)):          # product variant (no counters), counting variant, literal scans
+    frames, counts, pencils = [], [], []
+    for cull, count, pen in ((1, 0, 1), (1, 0, 0), (1, 1, 1), (0, 1, 1)):   # product variant with / without ray pencils, counting variant, literal scans
         gl = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
         gl.set_option(wrapper.RTX_OPT_CULL, cull)
         gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, count)
+        gl.set_option(wrapper.RTX_OPT_RAY_PENCILS, pen)
         gl.draw()
         frames.append(gl.read_pixels(wrapper.RTX_RGBA32F).view(np.uint32))
         st = gl.stats()
         counts.append((st["rays_closest"], st["rays_shadow"]))
+        pencils.append(st["pencils"])
         gl.stop()
-    assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[1], frames[2])
-    assert counts[1] == counts[2] and counts[1][0] > w * h
+    assert all(np.array_equal(f, frames[3]) for f in frames[:3])
+    assert pencils[0] == (0 if kind == "default" else 3) and pencils[1] == 0      # camera, point light, directional light
+    assert counts[2] == counts[3] and counts[2][0] > w * h

@@ -2,7 +2,7 @@
 """GPU box: many random scenes (tests/random_scenes.py) through the C ABI against the oracle -- max pixel difference and
 ray counts -- beyond the seeds the test suite runs. Each scene is drawn twice: with the counting kernel variant (ray counts) and with the
 PRODUCT variant (no counters; the many-primitive variant with its group culls where it is selected); both frames must be within the bar.
-usage: [FUZZ_GEN=random_scene|nasty_scene|scaled_quat_scene|crowd_scene] tools/fuzz_gpu.py first_seed count [width height]"""
+usage: [FUZZ_GEN=random_scene|nasty_scene|scaled_quat_scene|crowd_scene|pencil_scene] tools/fuzz_gpu.py first_seed count [width height]"""
 import os
 import sys
 
@@ -50,11 +50,14 @@ def main():
                 # the bar is 1e-4 on colours; a scene whose pixels reach 1e13 (non-unit quaternions scale normals, pow() of values > 1)
                 # is judged relative to the pixel: 1e-4 * max(1, |reference|)
                 mx = max(mx, float((np.abs(np.where(fin, im - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()))
+        # the product variant (group culls, ray pencils) against the counting variant (first-level culls only): bit for bit
+        variants_differ = int((img.view(np.uint32) != img_product.view(np.uint32)).any(-1).sum())
+        nan_bad += variants_differ
         rays_ok = st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
         worst = max(worst, mx)
         if nan_bad or mx > 1e-4 or not rays_ok:
             bad += 1
-            print(f"seed {seed}: max (relative above 1) {mx:.3e} nan-mismatch {nan_bad} rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
+            print(f"seed {seed}: max (relative above 1) {mx:.3e} nan-mismatch {nan_bad} (pixels that differ between kernel variants: {variants_differ}) rays gpu {st['rays_closest']}+{st['rays_shadow']} oracle {cnt['rays_closest']}+{cnt['rays_shadow']}", flush=True)
         if (seed - first + 1) % 1000 == 0:
             print(f"... {seed - first + 1} scenes, {bad} outside the bar so far, worst {worst:.3e}", flush=True)
     print(f"{os.environ.get('FUZZ_GEN', 'random_scene')}: {count} scenes from seed {first} ({'%dx%d' % fixed if fixed else 'mixed sizes'}): {bad} outside the bar, worst max-abs difference {worst:.3e}")
