@@ -893,6 +893,7 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
     const f3 oc = ro - xyz(Q.bound);
     const float b = dot3_fma(oc, rd);
     const float d2 = dot3_fma(oc, oc);
+    if (!(d2 <= Q.sym1.w)) return false;        // a clip box open along some axis: the bound only holds for origins this near (rt_pack.h)
     const float cc = d2 - Q.bound.w;
     return fmaf(b, b, -(a * cc)) < -1e-5f * a * d2;  // rounding-safe (see sphere_cull); NaN -> false -> not culled
 }
@@ -1003,39 +1004,62 @@ RT_HD uint32_t wave_or(uint32_t own, bool on)
 #endif
 }
 
-// ---- the builder: one cell of one pencil (one thread per cell on the device, rt_kernel.hip; a loop in the host build) ----
-struct PencilCell {      // geometry of a cell
-    f3 axis;             // APEX: unit direction of the cell centre
-    float theta;         // APEX: half-angle of the cone around `axis` that contains the cell, plus slack
-    float ulo, uhi, vlo, vhi;   // PARALLEL: the cell's rectangle (outer cells: +-inf)
+// ---- the builder: per pencil one record per primitive (pencil_prim), then one mask word of one cell at a time (pencil_cell_word). On the device a
+// workgroup prepares the records in LDS and each of its threads fills one cell (rt_kernel.hip); the host build loops. ----
+struct PencilPrim {
+    f4 a;   // APEX: unit vector from the apex to the centre of the bound, w = sin(alpha), alpha = angular radius of the (padded) bound
+            // PARALLEL: x, y = the centre across the direction, z = padded radius, w = |p2| of the pencil's direction (quadrics)
+    f4 b;   // x = cos(alpha); y = 1: set in every cell (no finite bound / the apex is inside it / NaNs); z = |M|_F, w = p2 margin (quadrics)
 };
 RT_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RT_HD float angle_between(f3 a, f3 b) { return atan2f(length3(cross3(a, b)), dot3(a, b)); }   // well-conditioned at 0 and pi, unlike acos
-RT_HD bool pencil_bound_misses(const DevPencil& P, const PencilCell& C, f3 c, float r2)
+RT_HD PencilPrim pencil_prim(const DevPencil& P, f4 bound, const DevSurfaceCull* Q)
 {
-    const float r = sqrtf(r2) + 4.0e-3f + 1.0e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
+    PencilPrim r;
+    r.a = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.b = mk4(0.0f, 1.0f, 0.0f, 0.0f);
+    if (Q) {
+        r.b.z = sqrtf(Q->sym0.x * Q->sym0.x + Q->sym0.w * Q->sym0.w + Q->sym1.y * Q->sym1.y +
+                      2.0f * (Q->sym0.y * Q->sym0.y + Q->sym0.z * Q->sym0.z + Q->sym1.x * Q->sym1.x));
+        r.b.w = 1.01f * Q->sym1.z + 1.0e-5f * r.b.z;
+        if (P.kind == RT_PENCIL_PARALLEL) r.a.w = fabsf(quadric_p2(*Q, xyz(P.a)));
+    }
+    if (!(bound.w >= 0.0f)) return r;                                  // no bound (or NaN): every cell
+    if (Q && !(Q->sym1.w > 1.0e30f)) return r;                         // a bound that only holds for origins near the quadric: every cell
+    const f3 c = xyz(bound);
+    const float rad = sqrtf(bound.w) + 4.0e-3f + 1.0e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
     if (P.kind == RT_PENCIL_APEX) {
         const f3 v = c - xyz(P.a);
         const float D2 = dot3(v, v);
-        if (!(D2 > 1.01f * r * r)) return false;          // apex inside (or almost inside) the bound: every direction may hit. NaN too.
-        const float alpha = asinf(r / sqrtf(D2));          // r/D < 0.996: well-conditioned
-        return angle_between(C.axis, v) > C.theta + alpha;
+        if (!(D2 > 1.01f * rad * rad) || !(D2 < 1.0e30f)) return r;    // apex inside (or almost inside) the bound, infinite radius, NaN
+        const float D = sqrtf(D2), sa = rad / D;                        // sin(alpha) < 0.996: alpha is well-conditioned
+        r.a = mk4(v.x / D, v.y / D, v.z / D, sa);
+        r.b.x = sqrtf(1.0f - sa * sa);
+    } else {
+        const float cu = dot3(c, xyz(P.e1)), cv = dot3(c, xyz(P.e2));
+        const float rr = rad + 1.0e-3f * gl_max(P.grid.z, P.grid.w);
+        if (!(fabsf(cu) < 1.0e30f && fabsf(cv) < 1.0e30f && rr < 1.0e30f)) return r;
+        r.a.x = cu; r.a.y = cv; r.a.z = rr;
     }
-    const float cu = dot3(c, xyz(P.e1)), cv = dot3(c, xyz(P.e2));
-    const float rr = r + 1.0e-3f * gl_max(P.grid.z, P.grid.w);
-    return cu + rr < C.ulo || cu - rr > C.uhi || cv + rr < C.vlo || cv - rr > C.vhi;   // NaN -> false
+    r.b.y = 0.0f;
+    return r;
 }
-RT_HD void pencil_build_cell(const SceneView& S, const DevPencil& P, uint32_t cell, uint32_t* out)
+// record k of pencil P: quadrics 0 .. n_surface-1, then tori
+RT_HD PencilPrim pencil_prim_at(const SceneView& S, const DevPencil& P, int k)
 {
-    const int ns = S.h->n_surface, nt = S.h->n_torus;
-    const int nws = (ns + 31) >> 5, nwt = (nt + 31) >> 5;
-    if (cell >= P.cells) {                                  // the all-ones cell: every primitive that exists
-        for (int w = 0; w < nws; w++) out[w] = ns - w * 32 >= 32 ? ~0u : (1u << (ns - w * 32)) - 1u;
-        for (int w = 0; w < nwt; w++) out[nws + w] = nt - w * 32 >= 32 ? ~0u : (1u << (nt - w * 32)) - 1u;
-        return;
-    }
+    const int ns = S.h->n_surface;
+    if (k < ns) { const DevSurfaceCull Q = S.surf_cull()[k]; return pencil_prim(P, Q.bound, &Q); }
+    return pencil_prim(P, S.torus_bound()[k - ns], nullptr);
+}
+struct PencilCell {     // geometry of one cell
+    f3 axis;            // APEX: unit direction of the cell centre ...
+    float theta, ct, st;   // ... and the half-angle (plus slack) of the cone around it that holds the cell, its cosine and sine
+    float ulo, uhi, vlo, vhi;   // PARALLEL: the cell's rectangle (outer cells: +-inf)
+};
+RT_HD PencilCell pencil_cell_geometry(const DevPencil& P, uint32_t cell)
+{
     PencilCell C;
-    C.axis = mk3(0.0f, 0.0f, 1.0f); C.theta = 0.0f; C.ulo = C.uhi = C.vlo = C.vhi = 0.0f;
+    C.axis = mk3(0.0f, 0.0f, 1.0f); C.theta = 0.0f; C.ct = 1.0f; C.st = 0.0f; C.ulo = C.uhi = C.vlo = C.vhi = 0.0f;
     const int R = P.res;
     if (P.kind == RT_PENCIL_APEX) {
         const int face = (int)cell / (R * R), j = ((int)cell / R) % R, i = (int)cell % R;
@@ -1047,6 +1071,7 @@ RT_HD void pencil_build_cell(const SceneView& S, const DevPencil& P, uint32_t ce
         th = gl_max(th, angle_between(C.axis, pencil_face_dir(face, u0, v1)));
         th = gl_max(th, angle_between(C.axis, pencil_face_dir(face, u1, v1)));
         C.theta = th + 2.0e-3f;   // slack: the lookup's rounding at cell borders, |d| within 1e-3 of 1, the builder's own arithmetic
+        C.ct = cosf(C.theta); C.st = sinf(C.theta);
     } else {
         const int j = (int)cell / R, i = (int)cell % R;
         const float inf = __builtin_huge_valf();
@@ -1055,32 +1080,40 @@ RT_HD void pencil_build_cell(const SceneView& S, const DevPencil& P, uint32_t ce
         C.vlo = j == 0 ? -inf : P.e2.w + P.grid.w * (float)j;
         C.vhi = j == R - 1 ? inf : P.e2.w + P.grid.w * (float)(j + 1);
     }
-    for (int w = 0; w < nws; w++) {
-        uint32_t bits = 0u;
-        for (int b = 0; b < 32 && w * 32 + b < ns; b++) {
-            const DevSurfaceCull Q = S.surf_cull()[w * 32 + b];
-            bool clear = false;
-            if (Q.bound.w >= 0.0f) {
-                const float normF = sqrtf(Q.sym0.x * Q.sym0.x + Q.sym0.w * Q.sym0.w + Q.sym1.y * Q.sym1.y +
-                                          2.0f * (Q.sym0.y * Q.sym0.y + Q.sym0.z * Q.sym0.z + Q.sym1.x * Q.sym1.x));
-                const bool apex = P.kind == RT_PENCIL_APEX;
-                const float p2 = fabsf(quadric_p2(Q, apex ? C.axis : xyz(P.a)));
-                const float vary = apex ? 2.01f * normF * C.theta : 0.0f;
-                if (p2 > vary + 1.01f * Q.sym1.z + 1.0e-5f * normF) clear = pencil_bound_misses(P, C, xyz(Q.bound), Q.bound.w);
+    return C;
+}
+// mask word w (quadric words first, then torus words) of cell `cell`; cell == P.cells is the all-ones cell: every primitive that exists
+RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const PencilPrim* prims, const PencilCell& C, uint32_t cell, int w)
+{
+    const int ns = S.h->n_surface, nt = S.h->n_torus;
+    const int nws = (ns + 31) >> 5;
+    const bool quadrics = w < nws;
+    const int first = quadrics ? w * 32 : (w - nws) * 32, count = (quadrics ? ns : nt) - first;   // primitives first .. of this class
+    if (cell >= P.cells) return count >= 32 ? ~0u : (1u << count) - 1u;
+    const bool apex = P.kind == RT_PENCIL_APEX;
+    // "the cell's rays miss the bound": APEX -- the angle between the cell axis and the centre exceeds theta + alpha, compared through
+    // cosines (cos(theta + alpha) = ct * cos(alpha) - st * sin(alpha); theta + alpha < pi/2 + 0.1; the 4e-6 covers the rounding of both
+    // sides, 3e-4 rad at the smallest theta + alpha there is, inside theta's slack); PARALLEL -- rectangle against padded disc.
+    auto misses = [&](const PencilPrim& pp) {
+        if (apex) return dot3_fma(C.axis, xyz(pp.a)) < fmaf(C.ct, pp.b.x, -(C.st * pp.a.w)) - 4.0e-6f;
+        return pp.a.x + pp.a.z < C.ulo || pp.a.x - pp.a.z > C.uhi || pp.a.y + pp.a.z < C.vlo || pp.a.y - pp.a.z > C.vhi;
+    };
+    uint32_t bits = 0u;
+    for (int b = 0; b < 32 && b < count; b++) {
+        const PencilPrim pp = prims[(quadrics ? 0 : ns) + first + b];
+        bool clear = false;
+        if (pp.b.y == 0.0f) {
+            if (quadrics) {
+                // not on the degenerate branch for any direction of the cell (p2 varies by at most 2 |M| theta around the axis' value)
+                const float p2 = apex ? fabsf(quadric_p2(S.surf_cull()[first + b], C.axis)) : pp.a.w;
+                if (p2 > 2.01f * pp.b.z * C.theta + pp.b.w) clear = misses(pp);
+            } else {
+                clear = misses(pp);
             }
-            if (!clear) bits |= 1u << b;
         }
-        out[w] = bits;
+        if (!clear) bits |= 1u << b;
     }
-    for (int w = 0; w < nwt; w++) {
-        uint32_t bits = 0u;
-        for (int b = 0; b < 32 && w * 32 + b < nt; b++) {
-            const f4 tb = S.torus_bound()[w * 32 + b];
-            const bool clear = tb.w >= 0.0f && pencil_bound_misses(P, C, xyz(tb), tb.w);   // inf radius: sqrt(inf) = inf, never "misses"
-            if (!clear) bits |= 1u << b;
-        }
-        out[nws + w] = bits;
-    }
+    return bits;
 }
 
 // ------------------------------------------------------------------------------------------

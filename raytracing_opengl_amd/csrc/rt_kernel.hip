@@ -212,15 +212,21 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     }
 }
 
-// Ray-pencil masks (rt_device.h pencil_build_cell): blockIdx.y = pencil, one thread per cell (+ the all-ones cell). Runs when the scene
+// Ray-pencil masks (rt_device.h pencil_cell_word): blockIdx.y = pencil, blockIdx.z = mask word, one thread per cell (+ the all-ones cell). Runs when the scene
 // changes, in front of the first trace launch that uses it, on the same stream.
 __global__ __launch_bounds__(256) void rt_pencil_build_kernel(const char* scene, uint32_t* masks)
 {
+    __shared__ PencilPrim prims[2 * RT_PENCIL_MAX_PRIMS];
     const SceneView S = make_view(scene);
     const DevPencil P = S.pencils()[blockIdx.y];
+    if (P.kind == RT_PENCIL_OFF || blockIdx.x * 256u > P.cells) return;     // whole workgroup
+    const int n = S.h->n_surface + S.h->n_torus;
+    for (int k = threadIdx.x; k < n; k += 256) prims[k] = pencil_prim_at(S, P, k);
+    __syncthreads();
     const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
-    if (P.kind == RT_PENCIL_OFF || cell > P.cells) return;
-    pencil_build_cell(S, P, cell, masks + P.mask_off + (size_t)cell * S.h->pencil_stride);
+    if (cell > P.cells) return;
+    const PencilCell C = pencil_cell_geometry(P, cell);
+    masks[P.mask_off + (size_t)cell * S.h->pencil_stride + blockIdx.z] = pencil_cell_word(S, P, prims, C, cell, (int)blockIdx.z);
 }
 
 // device-side exhaustive check of unorm8 (result[0] = number of mismatching byte values)
@@ -281,7 +287,7 @@ hipError_t rt_launch_pencil_build(const char* d_scene, const DevSceneHeader& hdr
     for (uint32_t k = 0; k < hdr.n_pencil; k++)
         if (pencils[k].kind != RT_PENCIL_OFF && pencils[k].cells > most) most = pencils[k].cells;
     if (most == 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_pencil_build_kernel, dim3((most + 1 + 255) / 256, hdr.n_pencil), dim3(256), 0, stream, d_scene, d_masks);
+    hipLaunchKernelGGL(rt_pencil_build_kernel, dim3((most + 1 + 255) / 256, hdr.n_pencil, hdr.pencil_stride), dim3(256), 0, stream, d_scene, d_masks);
     return hipGetLastError();
 }
 

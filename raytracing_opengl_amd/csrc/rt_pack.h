@@ -99,9 +99,12 @@ inline bool solve_sym(const double* M, int n, const double* rhs, double* x)  // 
     for (int i = 0; i < n; i++) x[i] = a[i][n] / a[i][i];
     return true;
 }
+// tau fattens the surface: the bounds are those of { |x^T A x + B^T x + C| <= tau } inside the clip box (see pack_scene: what the float
+// evaluation of the quadratic can mistake for the surface). from_surface: some axis of the result rests on the surface's own extent.
 inline bool quadric_clip_bounds(const double A[3][3], const double w[3], const double p[3], double f, const double lo[3], const double hi[3],
-                                double out_lo[3], double out_hi[3])
+                                double out_lo[3], double out_hi[3], double tau, bool& from_surface)
 {
+    from_surface = false;
     const double big = 1.0e30;
     int U[3], F[3], nu = 0, nf = 0;
     for (int k = 0; k < 3; k++) {
@@ -110,6 +113,7 @@ inline bool quadric_clip_bounds(const double A[3][3], const double w[3], const d
     }
     for (int k = 0; k < nf; k++) { out_lo[F[k]] = lo[F[k]]; out_hi[F[k]] = hi[F[k]]; }
     if (nu == 0) return true;
+    from_surface = true;
     for (int k = 0; k < nu; k++) if (std::fabs(lo[U[k]]) < big || std::fabs(hi[U[k]]) < big) return false;  // half-bounded axis: treat as unbounded
     double B[3], C = f;
     for (int r = 0; r < 3; r++) {
@@ -160,7 +164,7 @@ inline bool quadric_clip_bounds(const double A[3][3], const double w[3], const d
         grad[a_] = L[a_];
         for (int b_ = 0; b_ < nf; b_++) { gc += vc[a_] * Q[a_][b_] * vc[b_]; grad[a_] += (Q[a_][b_] + Q[b_][a_]) * vc[b_]; }
     }
-    double Gmax = sgn * gc;
+    double Gmax = sgn * gc + tau;
     for (int a_ = 0; a_ < nf; a_++) {
         Gmax += std::fabs(grad[a_]) * hv[a_];
         for (int b_ = 0; b_ < nf; b_++) {
@@ -299,11 +303,41 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             const double lo[3] = {vmin.x, vmin.y, vmin.z}, hi[3] = {vmax.x, vmax.y, vmax.z};
             double clo[3], chi[3];
             sc.bound = mk4(0.0f, 0.0f, 0.0f, -1.0f);
-            if (quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi)) {
-                const double cx = 0.5 * (clo[0] + chi[0]), cy = 0.5 * (clo[1] + chi[1]), cz = 0.5 * (clo[2] + chi[2]);
-                const double hx = 0.5 * (chi[0] - clo[0]), hy = 0.5 * (chi[1] - clo[1]), hz = 0.5 * (chi[2] - clo[2]);
-                const double rad = std::sqrt(hx * hx + hy * hy + hz * hz) * 1.01 + 0.01;
-                if (rad == rad && rad < 1.0e15) sc.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
+            sc.sym1.w = std::numeric_limits<float>::infinity();     // the bound holds for origins at any distance
+            bool from_surface = false;
+            if (quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi, 0.0, from_surface)) {
+                auto sphere = [&](double& cx, double& cy, double& cz) {
+                    cx = 0.5 * (clo[0] + chi[0]); cy = 0.5 * (clo[1] + chi[1]); cz = 0.5 * (clo[2] + chi[2]);
+                    const double hx = 0.5 * (chi[0] - clo[0]), hy = 0.5 * (chi[1] - clo[1]), hz = 0.5 * (chi[2] - clo[2]);
+                    return std::sqrt(hx * hx + hy * hy + hz * hz) * 1.01 + 0.01;
+                };
+                double cx, cy, cz, rad = sphere(cx, cy, cz);
+                bool ok = true;
+                double far2 = std::numeric_limits<double>::infinity();
+                if (from_surface) {
+                    // A clip box that is open along some axis leaves it to the SURFACE to end the piece, and the reference evaluates the
+                    // surface in float: at its computed hit point x the quadratic is not 0 but anything up to
+                    //     |F(x)| <~ 8 * 2^-24 * (|a| + |b| + |c| + |d| + |e| + |f|) * (|o| + t + 1)^2        (o, t: local origin, distance)
+                    // -- from 3000 units away a cylinder of radius 0.5 is "hit" by rays that pass 0.8 units beside it, and where its
+                    // axis runs nearly parallel to the open slab such a hit lies hundreds of units beyond the end of the true piece (found
+                    // by the pencil-scene fuzz: camera at z = -3000). The bound is therefore taken of the FATTENED surface |F| <= tau for
+                    // origins up to `far` units from the bound's centre, and the cull stands aside beyond that distance (sym1.w).
+                    // A closed clip box needs none of this: a hit must lie in the box, the box lies in the sphere.
+                    const double coef = std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(dd) + std::fabs(e) + std::fabs(f);
+                    const double far = 64.0;
+                    for (int pass = 0; pass < 3 && ok; pass++) {     // the fattened piece is larger, which raises tau a little: iterate
+                        const double reach = 2.0 * (far + rad) + 3.0 * std::sqrt((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2])) + 1.0;
+                        const double tau = 64.0 / 16777216.0 * coef * reach * reach;     // the estimate above with the rotation into the local frame and
+                                                                                 // the solve on top (~22 * 2^-24), times three
+                        ok = quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi, tau, from_surface);
+                        if (ok) rad = sphere(cx, cy, cz);
+                    }
+                    far2 = far * far;
+                }
+                if (ok && rad == rad && rad < 1.0e15) {
+                    sc.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
+                    sc.sym1.w = static_cast<float>(far2);
+                }
             }
         }
         std::memcpy(reinterpret_cast<DevSurface*>(blob.data() + h.off_surface) + i, &s, sizeof s);
@@ -405,7 +439,10 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             std::memcpy(reinterpret_cast<f4*>(blob.data() + off_group) + g, &out, sizeof out);
         }
     };
-    group_bounds(d.surface_size, h.off_surf_group, [&](int i) { return (reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + i)->bound; });
+    group_bounds(d.surface_size, h.off_surf_group, [&](int i) {
+        const DevSurfaceCull* q = reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + i;
+        return std::isinf(q->sym1.w) ? q->bound : mk4(0.0f, 0.0f, 0.0f, -1.0f);     // a bound that only holds near the quadric: no group cull
+    });
     group_bounds(d.torus_size, h.off_torus_group, [&](int i) { return reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i]; });
     for (int i = 0; i < d.light_point_size; i++) {
         const unsigned char* p = blocks[BLK_LIGHTS_POINT].data() + static_cast<size_t>(i) * SZ_LIGHT_POINT;

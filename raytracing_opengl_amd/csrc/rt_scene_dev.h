@@ -56,7 +56,7 @@ struct alignas(16) DevSurface {
 struct alignas(16) DevSurfaceCull {  // first-level record of a quadric (surface_cull)
     f4 bound;          // cull sphere of the CLIPPED surface: centre xyz (world), w = radius^2 (inflated); w < 0: unbounded
     f4 sym0;           // symmetric M = R^T diag(a,b,c) R : m00, m01, m02, m11
-    f4 sym1;           // m12, m22, |p2| margin, unused        (p2 ~ d^T M d)
+    f4 sym1;           // m12, m22, |p2| margin, w = squared distance from the bound's centre up to which the bound holds (inf: any)
 };
 struct alignas(16) DevBox {
     f4 quat;

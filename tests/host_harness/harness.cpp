@@ -3,6 +3,7 @@
 // oracle pixel by pixel without a GPU (tests/test_host_harness.py, -m "not gpu").
 // It is not a product path: nothing in raytracing_opengl_amd/ or librtx_hip.so uses it, and the
 // product has no CPU fallback. Built by tests/host_harness/Makefile with g++ -ffp-contract=off.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -56,9 +57,14 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
         for (uint32_t k = 0; k < hdr->n_pencil; k++) {
             const DevPencil P = S0.pencils()[k];
             if (P.kind == RT_PENCIL_OFF) continue;
+            std::vector<PencilPrim> prims(hdr->n_surface + hdr->n_torus);
+            for (size_t i = 0; i < prims.size(); i++) prims[i] = pencil_prim_at(S0, P, static_cast<int>(i));
 #pragma omp parallel for schedule(static, 256)
-            for (int64_t cell = 0; cell <= static_cast<int64_t>(P.cells); cell++)
-                pencil_build_cell(S0, P, static_cast<uint32_t>(cell), pencil_masks.data() + P.mask_off + static_cast<size_t>(cell) * hdr->pencil_stride);
+            for (int64_t cell = 0; cell <= static_cast<int64_t>(P.cells); cell++) {
+                const PencilCell C = pencil_cell_geometry(P, static_cast<uint32_t>(cell));
+                for (uint32_t w = 0; w < hdr->pencil_stride; w++)
+                    pencil_masks[P.mask_off + static_cast<size_t>(cell) * hdr->pencil_stride + w] = pencil_cell_word(S0, P, prims.data(), C, static_cast<uint32_t>(cell), static_cast<int>(w));
+            }
         }
     }
     const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()), hdr, pencil_masks.empty() ? nullptr : pencil_masks.data());
@@ -110,6 +116,134 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
     return 0;
 }
 
+// The torus culls rest on a premise about the reference's solver ("no root reported for a ray the cull rejects"), which can only be
+// checked statistically: n random rays around the torus `record` from distances [dist_lo, dist_hi] (log-uniform), aimed at or near it.
+// counts: [0] rays, [1] culled, [2] reference hits, [3] VIOLATIONS (culled but the un-culled solver reports a hit); the first
+// violating rays (ro, rd, tmin: 7 floats each, at most max_bad) go to bad.
+int harness_torus_premise(const void* record, int64_t n, uint64_t seed, float dist_lo, float dist_hi, int64_t counts[4], float* bad, int max_bad)
+{
+    rtpack::Defines d;
+    std::memset(&d, 0, sizeof d);
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    blocks[rtpack::BLK_SCENE].assign(64, 0);
+    d.torus_size = 1;
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    blocks[rtpack::BLK_TORUSES].assign(p, p + rtpack::kRecordSize[rtpack::BLK_TORUSES]);
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(d, blocks, blob, err)) return -2;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    const DevTorus T = S.tori()[0];
+    const double ext = std::fabs(T.radii.x) + std::fabs(T.radii.y);
+    int64_t c_cull = 0, c_hit = 0, c_bad = 0;
+    int n_bad = 0;
+#pragma omp parallel for schedule(static, 4096) reduction(+ : c_cull, c_hit, c_bad)
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t x = seed * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(k) * 0xbf58476d1ce4e5b9ull + 1;
+        auto u01 = [&]() { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return (x >> 11) * (1.0 / 9007199254740992.0); };
+        auto gauss = [&]() { double a = 0; for (int i = 0; i < 6; i++) a += u01(); return (a - 3.0) * 1.41421356; };
+        const double dist = dist_lo * std::pow(static_cast<double>(dist_hi) / dist_lo, u01());
+        double dx = gauss(), dy = gauss(), dz = gauss();
+        const double dl = std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30;
+        const double ox = T.pos.x + dx / dl * dist, oy = T.pos.y + dy / dl * dist, oz = T.pos.z + dz / dl * dist;
+        const double spread = ext * (u01() < 0.6 ? 1.2 : 6.0);
+        const double tx = T.pos.x + gauss() * spread, ty = T.pos.y + gauss() * spread, tz = T.pos.z + gauss() * spread;
+        double rx = tx - ox, ry = ty - oy, rz = tz - oz;
+        const double rl = std::sqrt(rx * rx + ry * ry + rz * rz) + 1e-30;
+        const f3 ro = mk3((float)ox, (float)oy, (float)oz);
+        f3 rd = mk3((float)(rx / rl), (float)(ry / rl), (float)(rz / rl));
+        if (u01() < 0.1) rd = -rd;
+        const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
+        bool solved = false;
+        float t = 0.0f, t2 = 0.0f;
+        bool cull = torus_cull(S.torus_bound()[0], ro, rd, tmin);
+        if (!cull) { intersect_torus_c<true>(T, ro, rd, tmin, t2, solved); cull = !solved; }
+        const bool hit = intersect_torus(T, ro, rd, tmin, t);
+        c_cull += cull; c_hit += hit;
+        if (cull && hit) {
+            c_bad++;
+#pragma omp critical
+            if (n_bad < max_bad) { float* o = bad + 7 * n_bad++; o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = tmin; }
+        }
+    }
+    counts[0] = n; counts[1] = c_cull; counts[2] = c_hit; counts[3] = c_bad;
+    return n_bad;
+}
+
+// The packed first-level cull record of one quadric: out = bound xyz, radius^2 (negative: none), |p2| margin.
+int harness_surface_bound(const void* record, float out[5])
+{
+    rtpack::Defines d;
+    std::memset(&d, 0, sizeof d);
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    blocks[rtpack::BLK_SCENE].assign(64, 0);
+    d.surface_size = 1;
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    blocks[rtpack::BLK_SURFACES].assign(p, p + rtpack::kRecordSize[rtpack::BLK_SURFACES]);
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(d, blocks, blob, err)) return -2;
+    const DevSceneHeader* h = reinterpret_cast<const DevSceneHeader*>(blob.data());
+    DevSurfaceCull C;
+    std::memcpy(&C, blob.data() + h->off_surf_cull, sizeof C);
+    out[0] = C.bound.x; out[1] = C.bound.y; out[2] = C.bound.z; out[3] = C.bound.w; out[4] = C.sym1.z;
+    return 0;
+}
+
+// The same for a quadric (`record`: one std140 rt_surface): rays around its position from distances [dist_lo, dist_hi].
+// extent: the size of the region the rays are aimed at. counts / bad as above.
+int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float dist_lo, float dist_hi, float extent, int64_t counts[4], float* bad, int max_bad)
+{
+    rtpack::Defines d;
+    std::memset(&d, 0, sizeof d);
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    blocks[rtpack::BLK_SCENE].assign(64, 0);
+    d.surface_size = 1;
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    blocks[rtpack::BLK_SURFACES].assign(p, p + rtpack::kRecordSize[rtpack::BLK_SURFACES]);
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(d, blocks, blob, err)) return -2;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    const DevSurface Q = S.surfaces()[0];
+    const DevSurfaceCull C = S.surf_cull()[0];
+    int64_t c_cull = 0, c_hit = 0, c_bad = 0;
+    int n_bad = 0;
+#pragma omp parallel for schedule(static, 4096) reduction(+ : c_cull, c_hit, c_bad)
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t x = seed * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(k) * 0xbf58476d1ce4e5b9ull + 1;
+        auto u01 = [&]() { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return (x >> 11) * (1.0 / 9007199254740992.0); };
+        auto gauss = [&]() { double a = 0; for (int i = 0; i < 6; i++) a += u01(); return (a - 3.0) * 1.41421356; };
+        const double dist = dist_lo * std::pow(static_cast<double>(dist_hi) / dist_lo, u01());
+        double dx = gauss(), dy = gauss(), dz = gauss();
+        const double dl = std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30;
+        const double ox = Q.pos_a.x + dx / dl * dist, oy = Q.pos_a.y + dy / dl * dist, oz = Q.pos_a.z + dz / dl * dist;
+        const double spread = extent * (u01() < 0.6 ? 1.5 : 8.0);
+        const double tx = Q.pos_a.x + gauss() * spread, ty = Q.pos_a.y + gauss() * spread, tz = Q.pos_a.z + gauss() * spread;
+        double rx = tx - ox, ry = ty - oy, rz = tz - oz;
+        const double rl = std::sqrt(rx * rx + ry * ry + rz * rz) + 1e-30;
+        const f3 ro = mk3((float)ox, (float)oy, (float)oz);
+        f3 rd = mk3((float)(rx / rl), (float)(ry / rl), (float)(rz / rl));
+        if (u01() < 0.1) rd = -rd;
+        const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
+        float t = 0.0f;
+        const bool cull = surface_cull(C, ro, rd);
+        const bool hit = intersect_surface(Q, ro, rd, tmin, t);
+        c_cull += cull; c_hit += hit;
+        if (cull && hit) {
+            c_bad++;
+#pragma omp critical
+            if (n_bad < max_bad) { float* o = bad + 7 * n_bad++; o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = tmin; }
+        }
+    }
+    counts[0] = n; counts[1] = c_cull; counts[2] = c_hit; counts[3] = c_bad;
+    return n_bad;
+}
+
 // Pencil diagnostics for the tests: out[0] = pencils, out[1] = mask words per cell, then per pencil (kind, cells, mean set bits per cell).
 int harness_pencil_stats(const harness_frame* fr, double* out, int max_out)
 {
@@ -132,10 +266,12 @@ int harness_pencil_stats(const harness_frame* fr, double* out, int max_out)
     for (uint32_t k = 0; k < S.h->n_pencil && n + 3 <= max_out; k++) {
         const DevPencil P = S.pencils()[k];
         double bits = 0.0;
+        std::vector<PencilPrim> prims(S.h->n_surface + S.h->n_torus);
+        for (size_t i = 0; i < prims.size(); i++) prims[i] = pencil_prim_at(S, P, static_cast<int>(i));
         if (P.kind != RT_PENCIL_OFF)
             for (uint32_t cell = 0; cell < P.cells; cell++) {
-                pencil_build_cell(S, P, cell, cellw.data());
-                for (uint32_t w = 0; w < S.h->pencil_stride; w++) bits += __builtin_popcount(cellw[w]);
+                const PencilCell C = pencil_cell_geometry(P, cell);
+                for (uint32_t w = 0; w < S.h->pencil_stride; w++) bits += __builtin_popcount(pencil_cell_word(S, P, prims.data(), C, cell, static_cast<int>(w)));
             }
         out[n++] = P.kind; out[n++] = P.cells; out[n++] = P.cells ? bits / P.cells : 0.0;
     }

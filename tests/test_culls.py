@@ -227,3 +227,83 @@ def test_identity_rotation_shortcut_is_exact(built):
     lib.harness_identity_rotation_mismatches.restype = ctypes.c_int
     lib.harness_identity_rotation_mismatches.argtypes = [ctypes.c_int, ctypes.c_uint]
     assert lib.harness_identity_rotation_mismatches(300000, 12345) == 0
+
+
+# ---- the premises behind the torus and quadric culls, with statistics (C++ batches in the host harness) ----
+def _premise_lib():
+    import ctypes
+    L = harness.lib()
+    L.harness_torus_premise.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    L.harness_quadric_premise.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    return L
+
+
+@pytest.mark.parametrize("lo,hi", [(0.1, 10), (10, 100), (100, 1000), (1000, 1e5)])
+def test_torus_cull_premise_in_bulk(built, lo, hi):
+    """'Durand-Kerner reports no root for a ray the culls reject' on 1.2 M random rays per distance decade (origins out to 1e5 units)."""
+    import ctypes
+    L = _premise_lib()
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        R, r = rng.uniform(0.5, 3.0), rng.uniform(0.1, 0.9)
+        pos = rng.uniform(-20, 20, 3)
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        rec = _mat() + struct.pack("<4f", *q) + struct.pack("<3f f 2f 2f", *pos, 0, R, r, 0, 0)
+        cnt, bad = (ctypes.c_int64 * 4)(), (ctypes.c_float * 28)()
+        L.harness_torus_premise(ctypes.create_string_buffer(rec, len(rec)), 200000, k + 1, lo, hi, cnt, bad, 4)
+        assert cnt[3] == 0, (R, r, list(bad[:7]))
+        assert cnt[1] > 50000 and (hi > 100 or cnt[2] > 1000), list(cnt)
+
+
+def _clipped_quadric(rng, coef, clip, pos=None, quat=None):
+    from scene_util import FLT_MAX
+    pos = rng.uniform(-20, 20, 3) if pos is None else np.asarray(pos, dtype=np.float64)
+    if quat is None:
+        quat = rng.normal(size=4)
+        quat /= np.linalg.norm(quat)
+    lo, hi = [-FLT_MAX] * 3, [FLT_MAX] * 3
+    for ax in clip:
+        lo[ax], hi[ax] = pos[ax] - 1.0, pos[ax] + 1.0
+    c = dict(a=0, b=0, c=0, d=0, e=0, f=0)
+    c.update(coef)
+    r = _mat() + struct.pack("<4f", *quat) + struct.pack("<3f f", *lo, 0) + struct.pack("<3f f", *hi, 0) + struct.pack("<3f", *pos) + \
+        struct.pack("<6f", c["a"], c["b"], c["c"], c["d"], c["e"], c["f"])
+    return r + b"\0" * (160 - len(r))
+
+
+_QUADRICS = [dict(a=1, b=1, c=1, f=-0.6), dict(a=4, b=4, c=-1), dict(a=4, b=4, f=-1), dict(a=1.5, b=1.5, d=-1), dict(a=1.5, b=-1.5, d=-1), dict(a=4, b=4, c=-1, f=-1)]
+
+
+@pytest.mark.parametrize("clip", [(1,), (0, 1), (0, 1, 2)])
+def test_quadric_cull_premise_in_bulk(built, clip):
+    """'The reference reports no hit for a ray the quadric cull rejects' on random rays from 0.1 to 1e4 units, for clip boxes open along
+    two axes, one axis, none. With an open axis the bound only holds near the quadric, so beyond that distance nothing may be culled."""
+    import ctypes
+    L = _premise_lib()
+    rng = np.random.default_rng(7)
+    for lo, hi in ((0.1, 10), (10, 50), (100, 1000), (1000, 1e4)):
+        culled = 0
+        for k in range(6):
+            rec = _clipped_quadric(rng, _QUADRICS[k], clip)
+            cnt, bad = (ctypes.c_int64 * 4)(), (ctypes.c_float * 28)()
+            L.harness_quadric_premise(ctypes.create_string_buffer(rec, len(rec)), 100000, k + 1, lo, hi, 3.0, cnt, bad, 4)
+            assert cnt[3] == 0, (k, clip, lo, list(bad[:7]))
+            culled += cnt[1]
+        assert (culled > 50000) if (hi <= 50 or len(clip) == 3) else (culled == 0), (clip, lo, culled)
+
+
+def test_open_clip_box_far_origin_regression(built):
+    """The pencil-scene fuzz case (seed 966): an elliptic cylinder of radius 0.5 clipped in world y only, its axis 1.4e-3 rad off the
+    slab, seen from 3000 units away. The reference's float arithmetic reports a hit 1400 units along the axis -- 300 beyond the end of the
+    true piece, 0.8 units beside the infinite cylinder. The cull must not reject what the reference hits."""
+    quat = (-0.48753002285957336, 0.5114487409591675, 0.4889416992664337, 0.5115375518798828)
+    rec = _clipped_quadric(None, dict(a=4, b=4, f=-1), (1,), pos=(5.779757022857666, 2.268878936767578, 18.741127014160156), quat=quat)
+    ro = np.array([0.0, 0.0, -3000.0], dtype=np.float32)
+    rd = np.array([-4.1959375e-01, 8.5331633e-04, 9.0771163e-01], dtype=np.float32)
+    ohit, ot, _ = _isect(oracle.TYPE_SURFACE, rec, ro, rd, 1e6)
+    dhit, dt, dcull = harness.kat(oracle.TYPE_SURFACE, rec, ro, rd, 1e6)
+    assert ohit and dhit and dt == ot and 3300 < ot < 3350
+    assert not dcull
