@@ -268,6 +268,7 @@ struct SceneView {
     RT_HDM const f4* surf_group() const { return at<f4>(h->off_surf_group); }
     RT_HDM const f4* torus_group() const { return at<f4>(h->off_torus_group); }
     RT_HDM const DevPencil* pencils() const { return at<DevPencil>(h->off_pencil); }
+    RT_HDM const DevSlabs* slabs() const { return at<DevSlabs>(h->off_slabs); }
     const uint32_t* pen;       // pencil masks (a buffer of their own, built on the device), nullptr = none
 };
 // `hdr` normally is the blob's own first record; with the tables staged in LDS it stays in global memory.
@@ -1061,7 +1062,7 @@ RT_HD PencilCell pencil_cell_geometry(const DevPencil& P, uint32_t cell)
     PencilCell C;
     C.axis = mk3(0.0f, 0.0f, 1.0f); C.theta = 0.0f; C.ct = 1.0f; C.st = 0.0f; C.ulo = C.uhi = C.vlo = C.vhi = 0.0f;
     const int R = P.res;
-    if (P.kind == RT_PENCIL_APEX) {
+    if (P.kind == RT_PENCIL_APEX || P.kind == RT_PENCIL_DIRECTION) {   // cube-map cells
         const int face = (int)cell / (R * R), j = ((int)cell / R) % R, i = (int)cell % R;
         const float step = 2.0f / (float)R;
         const float u0 = -1.0f + step * (float)i, u1 = -1.0f + step * (float)(i + 1), v0 = -1.0f + step * (float)j, v1 = -1.0f + step * (float)(j + 1);
@@ -1090,6 +1091,14 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
     const bool quadrics = w < nws;
     const int first = quadrics ? w * 32 : (w - nws) * 32, count = (quadrics ? ns : nt) - first;   // primitives first .. of this class
     if (cell >= P.cells) return count >= 32 ? ~0u : (1u << count) - 1u;
+    if (P.kind == RT_PENCIL_DIRECTION) {      // quadrics only: "some direction of the cell may take the degenerate branch"
+        uint32_t deg = 0u;
+        for (int b = 0; quadrics && b < 32 && b < count; b++) {
+            const PencilPrim pp = prims[first + b];
+            if (!(fabsf(quadric_p2(S.surf_cull()[first + b], C.axis)) > 2.01f * pp.b.z * C.theta + pp.b.w)) deg |= 1u << b;
+        }
+        return deg;
+    }
     const bool apex = P.kind == RT_PENCIL_APEX;
     // "the cell's rays miss the bound": APEX -- the angle between the cell axis and the centre exceeds theta + alpha, compared through
     // cosines (cos(theta + alpha) = ct * cos(alpha) - st * sin(alpha); theta + alpha < pi/2 + 0.1; the 4e-6 covers the rounding of both
@@ -1152,15 +1161,82 @@ RT_HD int lane_pop(unsigned long long& m)
 // fetched ahead (the next word is requested before the current one is walked; words of a cell: quadrics first, then tori).
 struct PencilScan {
     bool use;
+    bool mem;            // words come from a pencil cell (fetched one ahead); otherwise from the caller's array (slab_ray_mask)
     uint32_t cell, cur;
     int word;
-    RT_HDM uint32_t next(const SceneView& S) { const uint32_t own = cur; word++; cur = S.pen[cell + word]; return own; }   // (a spare word follows the table)
+    RT_HDM uint32_t next(const SceneView& S, const uint32_t* words)   // (a spare word follows the pencil tables)
+    {
+        const uint32_t own = mem ? cur : words[word];
+        word++;
+        if (mem) cur = S.pen[cell + word];
+        return own;
+    }
 };
+
+// ---- rays of no pencil: slab tables (rt_scene_dev.h DevSlabs) + the direction table ----
+// words[0 .. stride): the lane's candidate mask. A lane the tables cannot vouch for (not a unit direction, far-away or non-finite origin)
+// gets every primitive. tlimit: hits beyond it do not matter (the closest hit so far / the distance to the light).
+RT_HD int slab_index(float p, float lo, float inv) { return (int)gl_min(gl_max((p - lo) * inv, 0.0f), (float)(RT_SLABS - 1)); }
+RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_t* words)
+{
+    const DevSlabs& B = *S.slabs();
+    const int W = (int)S.h->pencil_stride;
+    const uint32_t* T = S.at<uint32_t>(B.table_off);
+    const bool ok = unit_direction(dot3_fma(rd, rd)) && dot3_fma(ro, ro) <= 1.0e8f;    // false for NaN
+    const f3 o = ok ? ro : mk3(0.0f, 0.0f, 0.0f), d = ok ? rd : mk3(0.0f, 0.0f, 1.0f);
+    // the part of the ray inside the box
+    float tA = 0.0f, tB = gl_min(tlimit, 1.0e6f);
+    bool inside = true;
+    const float ov[3] = {o.x, o.y, o.z}, dv[3] = {d.x, d.y, d.z}, lov[3] = {B.lo.x, B.lo.y, B.lo.z}, hiv[3] = {B.hi.x, B.hi.y, B.hi.z};
+    for (int a = 0; a < 3; a++) {
+        if (fabsf(dv[a]) > 1.0e-9f) {
+            const float inv = 1.0f / dv[a], t0 = (lov[a] - ov[a]) * inv, t1 = (hiv[a] - ov[a]) * inv;
+            tA = gl_max(tA, gl_min(t0, t1));
+            tB = gl_min(tB, gl_max(t0, t1));
+        } else if (ov[a] < lov[a] || ov[a] > hiv[a]) {
+            inside = false;       // moves less than 1e-3 along this axis over any length that matters, and starts outside
+        }
+    }
+    inside = inside && tA <= tB;
+    uint32_t acc[RT_SLAB_MAX_WORDS] = {0u, 0u, 0u, 0u};
+    if (RT_ANY(inside)) {
+        const float dt = (tB - tA) * (1.0f / RT_SLAB_SEGMENTS);
+        const float invv[3] = {B.inv.x, B.inv.y, B.inv.z};
+        int i0[3];
+        for (int a = 0; a < 3; a++) i0[a] = slab_index(fmaf(dv[a], tA, ov[a]), lov[a], invv[a]);
+        for (int j = 1; j <= RT_SLAB_SEGMENTS; j++) {
+            const float t = j == RT_SLAB_SEGMENTS ? tB : fmaf(dt, (float)j, tA);
+            uint32_t seg[RT_SLAB_MAX_WORDS] = {~0u, ~0u, ~0u, ~0u};
+            for (int a = 0; a < 3; a++) {
+                const int i1 = slab_index(fmaf(dv[a], t, ov[a]), lov[a], invv[a]);
+                const int lo = i0[a] < i1 ? i0[a] : i1, hi = i0[a] < i1 ? i1 : i0[a];
+                const int lvl = 31 - __builtin_clz((unsigned)(hi - lo + 1));
+                const uint32_t* e0 = T + (size_t)((a * RT_SLAB_LEVELS + lvl) * RT_SLABS + lo) * W;
+                const uint32_t* e1 = T + (size_t)((a * RT_SLAB_LEVELS + lvl) * RT_SLABS + hi - (1 << lvl) + 1) * W;
+                for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)
+                    if (w < W) seg[w] &= e0[w] | e1[w];
+                i0[a] = i1;
+            }
+            for (int w = 0; w < RT_SLAB_MAX_WORDS; w++) acc[w] |= inside ? seg[w] : 0u;
+        }
+    }
+    // + the quadrics this direction may put on their degenerate branch
+    uint32_t deg[RT_SLAB_MAX_WORDS] = {0u, 0u, 0u, 0u};
+    if (S.h->pencil_dir != 0xffffffffu) {
+        const uint32_t cell = pencil_cell_apex(S.pencils()[S.h->pencil_dir], S.h->pencil_stride, d, ok);
+        for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)
+            if (w < W) deg[w] = S.pen[cell + w];
+    }
+    for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)
+        if (w < W) words[w] = ok ? (acc[w] | deg[w] | B.always[w]) : B.valid[w];
+}
+RT_HD bool slabs_available(const SceneView& S) { return S.pen != nullptr && S.h->off_slabs != 0u; }
+
 template <bool ENABLED>
 RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float len, bool from_apex)
 {
     PencilScan ps;
-    ps.use = false; ps.cell = 0u; ps.cur = 0u; ps.word = 0;
+    ps.use = false; ps.mem = true; ps.cell = 0u; ps.cur = 0u; ps.word = 0;
     if (!ENABLED || pencil < 0 || S.pen == nullptr || pencil >= (int)S.h->n_pencil) return ps;
     const DevPencil& P = S.pencils()[pencil];
     if (P.kind == RT_PENCIL_OFF) return ps;
@@ -1194,11 +1270,17 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         }
     }
     RT_PH_LAP(cnt, PH_C_SPH);
+    uint32_t slabw[RT_SLAB_MAX_WORDS];
+    if (GROUPS && CULL && !ps.use && slabs_available(S)) {   // a ray of no pencil: its candidates from the slab tables, up to the closest hit so far
+        slab_ray_mask(S, ro, rd, tmin, slabw);
+        ps.use = true;
+        ps.mem = false;
+    }
     if (ps.use) {
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
         for (int w = 0; w < nws; w++) {
-            const uint32_t own = ps.next(S);
+            const uint32_t own = ps.next(S, slabw);
             uint32_t u = wave_or(own, true);
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
@@ -1254,7 +1336,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             bool group_live = true;
             if (ps.use) {   // phase 1 over the wave's pencil candidates only
                 for (int w = base >> 5; w << 5 < end; w++) {
-                    const uint32_t own = ps.next(S);
+                    const uint32_t own = ps.next(S, slabw);
                     uint32_t u = wave_or(own, true);
                     while (u != 0u) {
                         const int b = __builtin_ctz(u), i = (w << 5) + b;
@@ -1356,12 +1438,18 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             if (!RT_ANY(on)) break;
         }
     }
+    uint32_t slabw[RT_SLAB_MAX_WORDS];
+    if (GROUPS && CULL && !ps.use && RT_ANY(on) && slabs_available(S)) {   // a light without a pencil
+        slab_ray_mask(S, ro, rd, dist, slabw);
+        ps.use = true;
+        ps.mem = false;
+    }
     if (ps.use) {
         // the word counter must advance past the quadric words even when every lane is already in shadow
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
         for (int w = 0; w < nws; w++) {
-            const uint32_t own = ps.next(S);
+            const uint32_t own = ps.next(S, slabw);
             uint32_t u = wave_or(own, on);
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
@@ -1411,7 +1499,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 bool group_live = true;
                 if (ps.use) {
                     for (int w = base >> 5; w << 5 < end; w++) {
-                        const uint32_t own = ps.next(S);
+                        const uint32_t own = ps.next(S, slabw);
                         uint32_t u = wave_or(own, on);
                         while (u != 0u) {
                             const int b = __builtin_ctz(u), i = (w << 5) + b;

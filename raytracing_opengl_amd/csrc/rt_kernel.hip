@@ -283,11 +283,12 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
 
 hipError_t rt_launch_pencil_build(const char* d_scene, const DevSceneHeader& hdr, const DevPencil* pencils, uint32_t* d_masks, hipStream_t stream)
 {
+    const uint32_t records = hdr.n_pencil + (hdr.pencil_dir != 0xffffffffu ? 1u : 0u);   // the pencils, then the direction table
     uint32_t most = 0;
-    for (uint32_t k = 0; k < hdr.n_pencil; k++)
+    for (uint32_t k = 0; k < records; k++)
         if (pencils[k].kind != RT_PENCIL_OFF && pencils[k].cells > most) most = pencils[k].cells;
     if (most == 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_pencil_build_kernel, dim3((most + 1 + 255) / 256, hdr.n_pencil, hdr.pencil_stride), dim3(256), 0, stream, d_scene, d_masks);
+    hipLaunchKernelGGL(rt_pencil_build_kernel, dim3((most + 1 + 255) / 256, records, hdr.pencil_stride), dim3(256), 0, stream, d_scene, d_masks);
     return hipGetLastError();
 }
 

@@ -234,8 +234,12 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                              d.surface_size <= RT_PENCIL_MAX_PRIMS && d.torus_size <= RT_PENCIL_MAX_PRIMS;
     const int n_pencil = !long_tables ? 0 : (1 + d.light_point_size + d.light_direct_size < RT_MAX_PENCILS ? 1 + d.light_point_size + d.light_direct_size : RT_MAX_PENCILS);
     h.n_pencil = static_cast<uint32_t>(n_pencil);
-    h.off_pencil = reserve(sizeof(DevPencil) * (n_pencil + 1));
     h.pencil_stride = static_cast<uint32_t>((d.surface_size + 31) / 32 + (d.torus_size + 31) / 32);
+    h.off_pencil = reserve(sizeof(DevPencil) * (n_pencil + 2));
+    h.pencil_dir = 0xffffffffu;
+    const bool slabs = n_pencil > 0 && h.pencil_stride <= RT_SLAB_MAX_WORDS;
+    h.off_slabs = slabs ? reserve(sizeof(DevSlabs)) : 0u;
+    const uint32_t off_slab_table = slabs ? reserve(sizeof(uint32_t) * 3 * RT_SLAB_LEVELS * RT_SLABS * h.pencil_stride) : 0u;
     h.total_bytes = static_cast<int32_t>(off);
     blob.assign(off, 0);
     std::memcpy(blob.data(), &h, sizeof h);
@@ -266,6 +270,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         std::memcpy(reinterpret_cast<DevPlane*>(blob.data() + h.off_plane) + i, &s, sizeof s);
         std::memcpy(mat_at(TYPE_PLANE, i), p, 64);
     }
+    std::vector<double> surf_aabb(static_cast<size_t>(d.surface_size) * 6, 0.0);   // lo xyz, hi xyz of the clipped surface (slab tables)
     for (int i = 0; i < d.surface_size; i++) {
         const unsigned char* p = blocks[BLK_SURFACES].data() + static_cast<size_t>(i) * SZ_SURFACE;
         DevSurface s;
@@ -337,6 +342,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                 if (ok && rad == rad && rad < 1.0e15) {
                     sc.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
                     sc.sym1.w = static_cast<float>(far2);
+                    for (int k = 0; k < 3; k++) { surf_aabb[i * 6 + k] = clo[k]; surf_aabb[i * 6 + 3 + k] = chi[k]; }
                 }
             }
         }
@@ -520,6 +526,95 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             std::memcpy(reinterpret_cast<DevPencil*>(blob.data() + h.off_pencil) + k, &P, sizeof P);
         }
         DevSceneHeader* hp = reinterpret_cast<DevSceneHeader*>(blob.data());
+        // slab tables + the direction table, for the rays of no pencil
+        if (slabs) {
+            const int W = static_cast<int>(h.pencil_stride), nws = (d.surface_size + 31) / 32;
+            DevSlabs B;
+            std::memset(&B, 0, sizeof B);
+            auto bit = [&](uint32_t* words, int k) { words[k < d.surface_size ? k / 32 : nws + (k - d.surface_size) / 32] |= 1u << ((k < d.surface_size ? k : k - d.surface_size) & 31); };
+            struct Box { double c[3], r[3]; };   // centre, half extents (padded like the bounding spheres: 1 % + 0.01)
+            std::vector<Box> boxes(d.surface_size + d.torus_size);
+            std::vector<char> bounded(boxes.size(), 0);
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int k = 0; k < d.surface_size + d.torus_size; k++) {
+                bit(B.valid, k);
+                f4 b;
+                bool usable;
+                if (k < d.surface_size) {
+                    const DevSurfaceCull* q = reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + k;
+                    b = q->bound;
+                    usable = std::isinf(q->sym1.w);        // a bound that only holds near the quadric is no bound here
+                } else {
+                    b = reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[k - d.surface_size];
+                    usable = true;
+                }
+                usable = usable && b.w >= 0.0f && std::isfinite(b.w) && finite3(b) && std::fabs(b.x) < 1e6f && std::fabs(b.y) < 1e6f && std::fabs(b.z) < 1e6f && b.w < 1e12f;
+                if (!usable) { bit(B.always, k); continue; }
+                bounded[k] = 1;
+                const double rs = std::sqrt(static_cast<double>(b.w));
+                boxes[k] = {{b.x, b.y, b.z}, {rs, rs, rs}};
+                if (k < d.surface_size) {      // the box the clipped surface lies in (a hit must lie strictly inside the clip box, rt.frag:500-512)
+                    for (int a = 0; a < 3; a++) {
+                        const double l = surf_aabb[k * 6 + a], u = surf_aabb[k * 6 + 3 + a];
+                        boxes[k].c[a] = 0.5 * (l + u);
+                        boxes[k].r[a] = std::fmin(rs + std::fabs(boxes[k].c[a] - b.x * (a == 0) - b.y * (a == 1) - b.z * (a == 2)), 0.5 * (u - l) * 1.01 + 0.01);
+                    }
+                } else {                       // a torus reaches R * sqrt(1 - n_a^2) + r along axis a (n: its axis)
+                    const DevTorus* t = reinterpret_cast<const DevTorus*>(blob.data() + h.off_torus) + (k - d.surface_size);
+                    const f3 n = quat_rotate(t->qinv, mk3(0.0f, 0.0f, 1.0f));
+                    const double nv[3] = {n.x, n.y, n.z}, R = std::fabs(static_cast<double>(t->radii.x)), r = std::fabs(static_cast<double>(t->radii.y));
+                    for (int a = 0; a < 3; a++) {
+                        const double e = (R * std::sqrt(std::fmax(0.0, 1.0 - nv[a] * nv[a])) + r) * 1.01 + 0.01 + 1e-3 * R;   // (n is a float, unit within 1e-4)
+                        if (e == e) boxes[k].r[a] = std::fmin(rs, e);
+                    }
+                }
+                for (int a = 0; a < 3; a++) { lo[a] = std::fmin(lo[a], boxes[k].c[a] - boxes[k].r[a]); hi[a] = std::fmax(hi[a], boxes[k].c[a] + boxes[k].r[a]); }
+            }
+            if (!(lo[0] <= hi[0])) { for (int a = 0; a < 3; a++) { lo[a] = -1.0; hi[a] = 1.0; } }
+            uint32_t* T = reinterpret_cast<uint32_t*>(blob.data() + off_slab_table);
+            double size[3], step[3];
+            for (int a = 0; a < 3; a++) {
+                const double pad = 0.05 + 1e-3 * (hi[a] - lo[a]);      // hit points are computed in float: keep them inside
+                lo[a] -= pad; hi[a] += pad;
+                size[a] = hi[a] - lo[a];
+                step[a] = size[a] / RT_SLABS;
+            }
+            B.lo = mk4(static_cast<float>(lo[0]), static_cast<float>(lo[1]), static_cast<float>(lo[2]), 0.0f);
+            B.hi = mk4(static_cast<float>(hi[0]), static_cast<float>(hi[1]), static_cast<float>(hi[2]), 0.0f);
+            B.inv = mk4(static_cast<float>(1.0 / step[0]), static_cast<float>(1.0 / step[1]), static_cast<float>(1.0 / step[2]), 0.0f);
+            auto entry = [&](int a, int l, int i) { return T + ((static_cast<size_t>(a) * RT_SLAB_LEVELS + l) * RT_SLABS + i) * W; };
+            for (int k = 0; k < d.surface_size + d.torus_size; k++) {
+                if (!bounded[k]) continue;
+                for (int a = 0; a < 3; a++) {
+                    // the slab index of a point is computed in float by the kernel: pad the interval by more than that can be off
+                    const double eps = 2e-3 + 2e-3 * step[a] + 1e-5 * (std::fabs(boxes[k].c[a]) + boxes[k].r[a]);
+                    int i0 = static_cast<int>(std::floor((boxes[k].c[a] - boxes[k].r[a] - eps - lo[a]) / step[a]));
+                    int i1 = static_cast<int>(std::floor((boxes[k].c[a] + boxes[k].r[a] + eps - lo[a]) / step[a]));
+                    i0 = i0 < 0 ? 0 : (i0 > RT_SLABS - 1 ? RT_SLABS - 1 : i0);
+                    i1 = i1 < 0 ? 0 : (i1 > RT_SLABS - 1 ? RT_SLABS - 1 : i1);
+                    for (int i = i0; i <= i1; i++) bit(entry(a, 0, i), k);
+                }
+            }
+            for (int a = 0; a < 3; a++)
+                for (int l = 1; l < RT_SLAB_LEVELS; l++)
+                    for (int i = 0; i < RT_SLABS; i++) {
+                        const int j = i + (1 << (l - 1)) < RT_SLABS ? i + (1 << (l - 1)) : RT_SLABS - 1;
+                        for (int w = 0; w < W; w++) entry(a, l, i)[w] = entry(a, l - 1, i)[w] | entry(a, l - 1, j)[w];
+                    }
+            B.table_off = off_slab_table;
+            std::memcpy(blob.data() + h.off_slabs, &B, sizeof B);
+            if (d.surface_size > 0) {   // the direction table, behind the pencils
+                DevPencil P;
+                std::memset(&P, 0, sizeof P);
+                P.kind = RT_PENCIL_DIRECTION;
+                P.res = RT_PENCIL_DIR_RES;
+                P.cells = 6u * RT_PENCIL_DIR_RES * RT_PENCIL_DIR_RES;
+                P.mask_off = mask_words;
+                mask_words += (P.cells + 1u) * h.pencil_stride;
+                std::memcpy(reinterpret_cast<DevPencil*>(blob.data() + h.off_pencil) + n_pencil, &P, sizeof P);
+                hp->pencil_dir = static_cast<uint32_t>(n_pencil);
+            }
+        }
         hp->pencil_mask_words = n_pencil > 0 ? mask_words + 4u : 0u;   // + spare words: the scans request one word ahead
     }
     return true;

@@ -117,6 +117,9 @@ struct alignas(16) DevSceneHeader {
     // ray pencils (DevPencil below): n_pencil = 0 when the scene has none. The masks themselves are built on the device (rt_kernel.hip
     // pencil_build_kernel) into a buffer of their own; pencil_stride = mask words per cell (quadric words first, then torus words)
     uint32_t n_pencil, off_pencil, pencil_stride, pencil_mask_words;
+    // rays outside every pencil (mirror / refracted rays, shadow rays of lights without one): slab tables (DevSlabs below; 0 = none) and
+    // the direction table of the quadrics' degenerate branch (record n_pencil of the pencil array; 0xffffffff = none)
+    uint32_t off_slabs, pencil_dir, _pad[2];
 };
 
 // ---- ray pencils: third-level cull for long tables ---------------------------------------------
@@ -126,8 +129,11 @@ struct alignas(16) DevSceneHeader {
 // quadrics / tori a ray of that cell could possibly need -- one bit per primitive, conservative (bit clear = the primitive's own
 // first-level cull would provably reject every ray of the cell). A scan then visits the set bits of the wave's OR of its lanes' cells
 // instead of walking the whole table. Rays outside any pencil (mirror / refracted rays) keep the two-level scan.
-enum { RT_MAX_PENCILS = 8, RT_PENCIL_APEX_RES = 64, RT_PENCIL_PAR_RES = 128, RT_PENCIL_MAX_PRIMS = 128, RT_PENCIL_MIN_PRIMS = 16 };
-enum { RT_PENCIL_OFF = 0, RT_PENCIL_APEX = 1, RT_PENCIL_PARALLEL = 2 };
+enum { RT_MAX_PENCILS = 8, RT_PENCIL_APEX_RES = 64, RT_PENCIL_PAR_RES = 128, RT_PENCIL_DIR_RES = 32, RT_PENCIL_MAX_PRIMS = 128, RT_PENCIL_MIN_PRIMS = 16 };
+// RT_PENCIL_DIRECTION is not a pencil of rays but the same kind of table for ANY ray, indexed by its direction alone: bit i set = quadric i
+// might take its degenerate branch (trap T4: |p2| < 1e-6, p2 = d^T M d) for a direction of the cell -- the part of "can this ray need
+// quadric i" that no table over positions can answer, because a quadric on that branch ignores its clip box.
+enum { RT_PENCIL_OFF = 0, RT_PENCIL_APEX = 1, RT_PENCIL_PARALLEL = 2, RT_PENCIL_DIRECTION = 3 };
 struct alignas(16) DevPencil {
     f4 a;          // APEX: the common point; PARALLEL: the common (unit) direction
     f4 e1;         // PARALLEL: first in-plane axis xyz, w = coordinate of the low edge of cell 0
@@ -137,6 +143,23 @@ struct alignas(16) DevPencil {
     int32_t res;   // cells per cube-face edge (APEX) / per axis (PARALLEL)
     uint32_t cells;     // number of cells; cell number `cells` is the all-ones cell for rays the pencil cannot vouch for
     uint32_t mask_off;  // first dword of cell 0 in the mask buffer
+};
+
+// ---- slab tables: candidate masks for rays that belong to no pencil ------------------------------
+// The box around all bounded quadrics / tori is cut into RT_SLABS slabs along each axis; T[axis][0][i] = the primitives whose (padded) bound
+// reaches into slab i, T[axis][l][i] = the OR of 2^l consecutive slabs from i on (a sparse table: the OR over any slab range is two
+// entries). A piece of a ray whose end points lie in slabs [ax..bx] x [ay..by] x [az..bz] can only meet primitives in
+// OR(x range) & OR(y range) & OR(z range); a ray is cut into RT_SLAB_SEGMENTS pieces between its entry into the box and its exit (or its
+// length limit) and the pieces' masks are ORed, together with the primitives that have no usable bound (`always`) and the quadrics the
+// direction table names. Built on the host with the scene (a few hundred interval insertions); read with vector loads.
+enum { RT_SLABS = 64, RT_SLAB_LEVELS = 7, RT_SLAB_MAX_WORDS = 4, RT_SLAB_SEGMENTS = 4 };
+struct alignas(16) DevSlabs {
+    f4 lo, hi;             // the box (padded)
+    f4 inv;                // slabs per unit length along x, y, z
+    uint32_t always[4];    // mask words (quadric words first, then torus words, like a pencil cell) of the primitives in every ray's mask
+    uint32_t valid[4];     // every primitive that exists: the mask of a ray the tables cannot vouch for
+    uint32_t table_off;    // byte offset in the blob of T[axis][level][slab][word]
+    uint32_t _pad[3];
 };
 
 // ---- textures --------------------------------------------------------------------------------

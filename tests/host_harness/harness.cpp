@@ -54,7 +54,7 @@ int harness_render(const harness_frame* fr, int y0, int y1, float* out, uint64_t
     if (fr->cull == 1 && hdr->n_pencil > 0) {
         pencil_masks.assign(hdr->pencil_mask_words, 0u);
         const SceneView S0 = make_view(reinterpret_cast<const char*>(aligned.data()));
-        for (uint32_t k = 0; k < hdr->n_pencil; k++) {
+        for (uint32_t k = 0; k < hdr->n_pencil + (hdr->pencil_dir != 0xffffffffu ? 1u : 0u); k++) {   // pencils, then the direction table
             const DevPencil P = S0.pencils()[k];
             if (P.kind == RT_PENCIL_OFF) continue;
             std::vector<PencilPrim> prims(hdr->n_surface + hdr->n_torus);
@@ -263,7 +263,7 @@ int harness_pencil_stats(const harness_frame* fr, double* out, int max_out)
     out[n++] = S.h->n_pencil;
     out[n++] = S.h->pencil_stride;
     std::vector<uint32_t> cellw(S.h->pencil_stride + 1);
-    for (uint32_t k = 0; k < S.h->n_pencil && n + 3 <= max_out; k++) {
+    for (uint32_t k = 0; k < S.h->n_pencil + (S.h->pencil_dir != 0xffffffffu ? 1u : 0u) && n + 3 <= max_out; k++) {
         const DevPencil P = S.pencils()[k];
         double bits = 0.0;
         std::vector<PencilPrim> prims(S.h->n_surface + S.h->n_torus);

@@ -14,23 +14,36 @@ sys.path.insert(0, ROOT)
 from raytracing_opengl_amd import build_info  # noqa: E402
 
 out, scene, W, H, depth, kept = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+
+
+def newest(pattern):
+    """gpurun MERGES a call's output into gpurun_out/, so a tag that was profiled before still holds the earlier runs' files: per pass
+    directory only the most recent file counts."""
+    by_dir = {}
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        d = f[len(out):].lstrip(os.sep).split(os.sep)[0]
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
 KERNEL = "rt_trace_kernel"
 # the timed variant only: the single launch of the ray-counting variant and nothing else shares the name stem
 names = defaultdict(int)
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest(os.path.join("trace", "**", "*kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         if KERNEL in r.get("Kernel_Name", ""):
             names[r["Kernel_Name"]] += 1
 KERNEL = max(names, key=names.get) if names else KERNEL
 vals, n = defaultdict(float), defaultdict(int)
-for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+for f in newest(os.path.join("pmc_*", "**", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if KERNEL == r.get("Kernel_Name", "") or (not names and KERNEL in r.get("Kernel_Name", "")):
             vals[r["Counter_Name"]] += float(r["Counter_Value"])
             n[r["Counter_Name"]] += 1
 mean = {k: vals[k] / n[k] for k in vals}
 dur = []
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest(os.path.join("trace", "**", "*kernel_trace.csv")):
     dur += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if KERNEL == r.get("Kernel_Name", "")]
 dur = sorted(dur)[: max(1, len(dur) - 2)]   # the first launches after a module load are outliers (clock ramp): drop the two slowest
 suffix = "" if scene == "default" else "_" + scene
