@@ -89,9 +89,9 @@ typedef enum rtx_option {
                                 camera rays by direction, shadow rays by direction from a point light or by position across a directional
                                 light -- built on the device whenever the scene changes; scans of such rays walk the wave's candidates
                                 instead of the whole table. 0: two-level scans only. Same results. */
-    RTX_OPT_HIGH_OCCUPANCY = 5 /* which register budget of the trace kernel runs: 0 = 6 waves/SIMD,
-                                1 = 7 waves/SIMD (spills to scratch, hides the scalar table walks of scenes with many
-                                primitives), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
+    RTX_OPT_HIGH_OCCUPANCY = 5 /* which build of the trace kernel runs: 0 = the default one, 1 = the many-primitive one (group culls, ray
+                                pencils and slab tables compiled in; its own register budget -- 7 waves/SIMD in round 1, hence the
+                                name, 6 now), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
 } rtx_option;
 
 typedef struct rtx_stats {

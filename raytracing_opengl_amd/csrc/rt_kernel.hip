@@ -68,19 +68,22 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 #define RT_WAVES_PER_EU 6
 #endif
 #ifndef RT_WPE_HEAVY
-#define RT_WPE_HEAVY 7
+#define RT_WPE_HEAVY 6
 #endif
 // Two register budgets of the same code (WPE = waves per SIMD the compiler must make room for; numbers for 4K frames,
 // built with -mllvm -disable-machine-licm, see the Makefile):
 //   WPE = RT_WAVES_PER_EU (6: 80 VGPRs, path state in LDS, 44 B of scratch per lane around the torus solver's register
 //         peak) -- the default: 500 us on the default scene (5 waves, no scratch at all: 523 us; 4 waves: 585 us).
-//   WPE = RT_WPE_HEAVY (7: 72 VGPRs, 96 B) -- scenes with many primitives, where every ray walks long tables of scalar
-//         loads and latency hiding is worth more than the spills: quadric-heavy 4K 2530 -> 2440 us, torus-heavy
-//         2710 -> 2650 us against the 6-wave build. Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
+//   HEAVY (WPE = RT_WPE_HEAVY) -- the variant for scenes with many primitives: the candidate tables of rt_device.h (group culls, ray
+//         pencils, slab tables) are compiled in. Round 1 ran it at 7 waves (72 VGPRs, 96 B): every ray walked long tables of scalar
+//         loads and latency hiding was worth more than the spills (quadric-heavy 4K 2530 -> 2440 us). With the tables the scans are
+//         short and carry more state: 6 waves (80 VGPRs, 80 B) 1297 / 2271 us (quadric / torus), 7 (128 B) 1327 / 2266, 5 (no
+//         scratch) 1303 / 2295, 8 (188 B) 1476 / 2298. Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
 
 constexpr bool ps_wide(int wpe) { return wpe <= 6; }   // 6 workgroups x 24 KB fit the CU's 160 KB of LDS, 7 do not
 
-template <bool CULL, bool COUNT, bool LDS, int WPE>
+// HEAVY: the many-primitive variant -- its own register budget and the candidate tables of rt_device.h (group culls, ray pencils, slabs)
+template <bool CULL, bool COUNT, bool LDS, int WPE, bool HEAVY = false>
 __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     path.base = path_lds + threadIdx.x;
     path.fence_slot = p.ps_fence_slot;
 #endif
-    const f4 px = trace_pixel<CULL, COUNT, WIDE, (WPE == RT_WPE_HEAVY && !COUNT && !LDS)>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);   // group culls: the many-primitive variant only
+    const f4 px = trace_pixel<CULL, COUNT, WIDE, HEAVY>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);   // group culls: the many-primitive variant only
 
     // The pixel's coordinates are needed again only here. They are RE-DERIVED from the thread index
     // (laundered through an empty asm so the compiler cannot keep the first copy alive) instead of
@@ -239,17 +242,17 @@ __global__ void rt_selftest_kernel(int* result)
 
 }  // namespace
 
-template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU>
+template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU, bool HEAVY = false>
 static hipError_t launch_variant(const RtLaunchParams& p_in, dim3 grid, size_t shmem, hipStream_t stream)
 {
     RtLaunchParams p = p_in;
     p.ps_fence_slot = rtdev::path_slots(ps_wide(WPE));   // the pad column behind this variant's path-state slots
     if (LDS && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS, WPE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE>), grid, dim3(256), shmem, stream, p);
+    hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>), grid, dim3(256), shmem, stream, p);
     return hipGetLastError();
 }
 
@@ -268,7 +271,7 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
     }
     const size_t shmem = lds ? (size_t)((p.scene_bytes + 15) & ~15) : 0;
     const int sel = (cull ? 4 : 0) | (count ? 2 : 0) | (lds ? 1 : 0);
-    if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY>(p, grid, shmem, stream);  // the product path only
+    if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY, true>(p, grid, shmem, stream);  // the product path only
     switch (sel) {
         case 0: return launch_variant<false, false, false>(p, grid, shmem, stream);
         case 1: return launch_variant<false, false, true>(p, grid, shmem, stream);

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Static facts about the product kernel <CULL=1,COUNT=0,LDS=0>: instruction mix, registers, spills.
-# usage: [ISA_WPE=7] tools/isa_stats.sh [extra hipcc flags]     (ISA_WPE: which waves-per-SIMD instantiation; default 6 = the light one)
+# usage: [ISA_WPE=7] tools/isa_stats.sh [extra hipcc flags]     (ISA_WPE: which waves-per-SIMD instantiation; default 6 = the light one, 7 = the many-primitive variant)
 cd "$(dirname "$0")/.."
 OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
-/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=6 -DRT_WPE_HEAVY=7 --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -disable-machine-licm -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
+/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=6 -DRT_WPE_HEAVY=6 --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -disable-machine-licm -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
 python3 - "$OUT" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
 import os
-m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi(\d+)EEEv14RtLaunchParams:', txt) if x.group(1) == os.environ.get('ISA_WPE', '6')]
+m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi(\d+)ELb[01]EEEv14RtLaunchParams:', txt) if x.group(1) == os.environ.get('ISA_WPE', '6')]
 i=m[0].start()
 j=txt.find('.end_amdhsa_kernel',i)
 body=txt[i:j]

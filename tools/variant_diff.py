@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""GPU box: render fuzz scenes with every kernel variant / option set (counting variant, product variant with and without ray pencils,
+light variant, literal scans) and report which frames differ from the literal scans, with the first differing pixels.
+usage: tools/variant_diff.py <generator> <seed> [seed ...]     (generators: tests/random_scenes.py)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
