@@ -16,6 +16,10 @@
 
 #include "rt_device.h"
 
+#ifndef RT_QUADRIC_FAR
+#define RT_QUADRIC_FAR 64.0   /* quadrics with an open clip box: their bound holds for origins up to this far from its centre (pack_scene) */
+#endif
+
 namespace rtpack {
 using namespace rtdev;
 
@@ -329,7 +333,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                     // origins up to `far` units from the bound's centre, and the cull stands aside beyond that distance (sym1.w).
                     // A closed clip box needs none of this: a hit must lie in the box, the box lies in the sphere.
                     const double coef = std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(dd) + std::fabs(e) + std::fabs(f);
-                    const double far = 64.0;
+                    const double far = RT_QUADRIC_FAR;
                     for (int pass = 0; pass < 3 && ok; pass++) {     // the fattened piece is larger, which raises tau a little: iterate
                         const double reach = 2.0 * (far + rad) + 3.0 * std::sqrt((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2])) + 1.0;
                         const double tau = 64.0 / 16777216.0 * coef * reach * reach;     // the estimate above with the rotation into the local frame and

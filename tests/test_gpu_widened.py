@@ -212,3 +212,54 @@ def test_specialize_refuses_depths_beyond_the_segment_cap_and_unbinds_cubemaps(s
     gl.stop()
     ref, _ = oracle.OracleScene(sc, w, h, small_textures["textures"], None).render()
     assert float(np.abs(without - ref).max()) <= TOL and float(np.abs(with_sky - without).max()) > 0.01
+
+
+def test_candidate_tables_follow_scene_updates(built, small_textures):
+    """Scenes with long tables carry ray-pencil masks and slab tables that are derived from the scene: after update_buffer (a moved
+    camera, a moved light, moved primitives -- what the reference's update_scene does every frame) the next draw must rebuild them.
+    The frame of the updated context equals the frame of a fresh context given the same blocks, bit for bit; the option switches the
+    tables off without changing a pixel; the stats report them."""
+    import struct
+    import random_scenes
+    w, h = 160, 96
+    first = random_scenes.crowd_scene(3, w, h)
+    gl = wrapper.make_renderer(first, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.draw()
+    a0 = gl.read_pixels(wrapper.RTX_RGBA32F).copy()
+    st = gl.stats()
+    assert st["pencils"] >= 2 and st["last_pencil_build_ms"] > 0.0
+    # the same tables, everything moved: camera 6 units to the side and turned, the light to the other side, every quadric / torus shifted
+    blocks = dict(first.blocks)
+    sb = bytearray(blocks["scene_buf"])
+    sb[16:28] = struct.pack("<3f", 6.0, 1.5, -7.0)
+    blocks["scene_buf"] = bytes(sb)
+    lb = bytearray(blocks["lights_point_buf"])
+    lb[0:12] = struct.pack("<3f", -9.0, 2.0, 25.0)
+    blocks["lights_point_buf"] = bytes(lb)
+    for name, rec, pos in (("surfaces_buf", 160, 112), ("toruses_buf", 112, 80)):
+        buf = bytearray(blocks.get(name, b""))
+        for k in range(len(buf) // rec):
+            x, y, z = struct.unpack_from("<3f", buf, k * rec + pos)
+            struct.pack_into("<3f", buf, k * rec + pos, x + 1.5, y - 0.7, z + 2.0)
+            if name == "surfaces_buf":   # the clip box moves with the quadric
+                for off in (80, 96):
+                    v = struct.unpack_from("<3f", buf, k * rec + off)
+                    struct.pack_into("<3f", buf, k * rec + off, *[c + d if abs(c) < 1e30 else c for c, d in zip(v, (1.5, -0.7, 2.0))])
+        blocks[name] = bytes(buf)
+    second = type(first)(blocks=blocks, defines=first.defines)
+    gl.uploader.update(second)
+    gl.draw()
+    a1 = gl.read_pixels(wrapper.RTX_RGBA32F).copy()
+    gl.set_option(wrapper.RTX_OPT_RAY_PENCILS, 0)
+    gl.draw()
+    a2 = gl.read_pixels(wrapper.RTX_RGBA32F).copy()
+    assert gl.stats()["pencils"] == 0
+    gl.stop()
+    fresh = wrapper.make_renderer(second, w, h, small_textures["textures"], small_textures["cubemap"])
+    fresh.set_option(wrapper.RTX_OPT_CULL, 0)
+    fresh.draw()
+    b = fresh.read_pixels(wrapper.RTX_RGBA32F)
+    fresh.stop()
+    assert (a0.view(np.uint32) != a1.view(np.uint32)).any(-1).mean() > 0.2          # the scene did change
+    assert np.array_equal(a1.view(np.uint32), b.view(np.uint32))                   # updated context, tables rebuilt == literal scans of a fresh one
+    assert np.array_equal(a2.view(np.uint32), b.view(np.uint32))                   # tables off
