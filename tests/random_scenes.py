@@ -133,7 +133,7 @@ def scaled_quat_scene(seed: int, w: int, h: int):
     return type(sc)(defines=sc.defines, blocks=blocks)
 
 
-def crowd_scene(seed: int, w: int, h: int, lights=None, camera=None):
+def crowd_scene(seed: int, w: int, h: int, lights=None, camera=None, planes_override=None):
     """Long primitive tables (16 ... 100 quadrics and / or tori, plus a few of everything else): exercises the second-level group culls
     (rt_device.h RT_GROUP) -- groups with an unbounded member, members with non-unit quaternions, quadrics of every kind incl. ones whose
     degenerate branch (trap T4) fires for axis-parallel rays, clusters spread far apart so that whole groups are skipped."""
@@ -180,6 +180,8 @@ def crowd_scene(seed: int, w: int, h: int, lights=None, camera=None):
         lights_point, lights_direct = lights
     if camera is not None:
         cam_pos, cam_quat = camera
+    if planes_override is not None:
+        planes = planes_override
     return make_scene(w, h, depth, spheres=spheres, planes=planes, surfaces=surfaces, boxes=boxes, toruses=toruses, lights_point=lights_point,
                       lights_direct=lights_direct, cam_pos=cam_pos, cam_quat=cam_quat)
 
@@ -202,4 +204,18 @@ def pencil_scene(seed: int, w: int, h: int):
     cam_pos = cams[int(rng.integers(len(cams)))]
     yaw = {2: math.pi, 3: -math.pi / 2}.get(cams.index(cam_pos), 0.0)
     cam_quat = quat_euler(float(rng.normal() * 0.1), float(yaw + rng.normal() * 0.2), 0.0)
-    return crowd_scene(seed, w, h, lights=(lights_point, lights_direct), camera=(cam_pos, cam_quat))
+    # planes (drawn last: the scenes of earlier seeds keep their lights and cameras): in two scenes of three 1-3 mirrors / matt planes with
+    # tilted, non-unit or zero normals -- floors, walls behind the crowd, a plane through the crowd, a plane behind the camera -- for the
+    # mirror-image pencils of reflecting planes
+    planes = None
+    if rng.random() < 0.67:
+        planes = []
+        for _ in range(int(rng.integers(1, 4))):
+            nrm = [(0.0, 1.0, 0.0), (0.0, 2.5, 0.0), (0.1, 1.0, -0.2), (0.0, 0.0, -1.0), (1.0, 0.3, 0.0), (0.0, -1.0, 0.0), (0.0, 0.0, 0.0), (0.6, 0.8, 0.0),
+                   (0.0, 0.6, -0.8), (-0.36, 0.8, -0.48)][int(rng.integers(10))]
+            pos = [(0.0, -12.0, 0.0), (0.0, -3.0, 16.0), (0.0, 0.0, 30.0), (-15.0, 0.0, 15.0), (0.0, 14.0, 0.0), (0.0, 0.0, -8.0)][int(rng.integers(6))]
+            m = _mat(rng)
+            if rng.random() < 0.6:      # a plain mirror (no refraction)
+                m = material(tuple(rng.random(3) * 0.9 + 0.1), int(rng.integers(0, 200)), float(rng.choice([0.1, 0.5, 1.0])))
+            planes.append(plane(nrm, pos, m))
+    return crowd_scene(seed, w, h, lights=(lights_point, lights_direct), camera=(cam_pos, cam_quat), planes_override=planes)
