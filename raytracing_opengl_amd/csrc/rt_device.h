@@ -1157,25 +1157,27 @@ RT_HD int lane_pop(unsigned long long& m)
 
 // GROUPS: compile the second-level group culls in. Only the many-primitive kernel variant (and the host build) does: in the default
 // variant the extra code cost 2.5 % of the default scene's frame time through the instruction cache without ever being executed.
-// The pencil of a scan, if it has one: wave-uniform `use`, the lane's cell (dword offset of its first mask word) and the mask word
-// fetched ahead (the next word is requested before the current one is walked; words of a cell: quadrics first, then tori).
+// The pencil of a scan, if it has one: wave-uniform `use`, the lane's cell (dword offset of its first mask word; words of a cell:
+// quadrics first, then tori) and the next word's number. A word is loaded where it is walked and nothing of it is kept: fetching one
+// word ahead, or keeping the lane's own word to let it skip the other lanes' candidates, each cost a register for the whole scan, and
+// registers are what this kernel is short of (4K quadric-heavy frame 1293 us with both, 1260 without the fetch-ahead, 1247 without
+// either; six waves per SIMD hide the load).
 struct PencilScan {
     bool use;
-    bool mem;            // words come from a pencil cell (fetched one ahead); otherwise from the caller's array (slab_ray_mask)
-    uint32_t cell, cur;
+    bool mem;            // words come from a pencil cell; otherwise from the caller's array (slab_ray_mask)
+    uint32_t cell;
     int word;
-    RT_HDM uint32_t next(const SceneView& S, const uint32_t* words)   // (a spare word follows the pencil tables)
+    RT_HDM uint32_t next(const SceneView& S, const uint32_t* words)
     {
-        const uint32_t own = mem ? cur : words[word];
+        const uint32_t own = mem ? S.pen[cell + word] : words[word];
         word++;
-        if (mem) cur = S.pen[cell + word];
         return own;
     }
 };
 
 // ---- rays of no pencil: slab tables (rt_scene_dev.h DevSlabs) + the direction table ----
 // words[0 .. stride): the lane's candidate mask. A lane the tables cannot vouch for (not a unit direction, far-away or non-finite origin)
-// gets every primitive. tlimit: hits beyond it do not matter (the closest hit so far / the distance to the light).
+// gets every primitive. tlimit: hits beyond it do not matter (the closest hit so far / the distance to the light) -- see below.
 RT_HD int slab_index(float p, float lo, float inv) { return (int)gl_min(gl_max((p - lo) * inv, 0.0f), (float)(RT_SLABS - 1)); }
 RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_t* words)
 {
@@ -1184,8 +1186,19 @@ RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_
     const uint32_t* T = S.at<uint32_t>(B.table_off);
     const bool ok = unit_direction(dot3_fma(rd, rd)) && dot3_fma(ro, ro) <= 1.0e8f;    // false for NaN
     const f3 o = ok ? ro : mk3(0.0f, 0.0f, 0.0f), d = ok ? rd : mk3(0.0f, 0.0f, 1.0f);
-    // the part of the ray inside the box
-    float tA = 0.0f, tB = gl_min(tlimit, 1.0e6f);
+    // the quadrics this direction may put on their degenerate branch
+    uint32_t deg[RT_SLAB_MAX_WORDS] = {0u, 0u, 0u, 0u};
+    bool any_deg = false;
+    if (S.h->pencil_dir != 0xffffffffu) {
+        const uint32_t cell = pencil_cell_apex(S.pencils()[S.h->pencil_dir], S.h->pencil_stride, d, ok);
+        for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)
+            if (w < W) { deg[w] = S.pen[cell + w]; any_deg = any_deg || deg[w] != 0u; }
+    }
+    // the part of the ray inside the box. The length limit only holds while the closest hit so far can only come closer -- and a quadric
+    // on its degenerate branch accepts t > tmin (trap T4: the comparison is inverted), which moves the "closest" hit AWAY and makes
+    // primitives behind the old limit eligible again (pencil-scene fuzz, seed 9038: a floor at t = 2992, a degenerate quadric at 22 925,
+    // then a cylinder at 3018 that the reference therefore shows). A lane with such a quadric among its candidates gets the whole ray.
+    float tA = 0.0f, tB = any_deg ? 1.0e6f : gl_min(tlimit, 1.0e6f);
     bool inside = true;
     const float ov[3] = {o.x, o.y, o.z}, dv[3] = {d.x, d.y, d.z}, lov[3] = {B.lo.x, B.lo.y, B.lo.z}, hiv[3] = {B.hi.x, B.hi.y, B.hi.z};
     for (int a = 0; a < 3; a++) {
@@ -1220,13 +1233,6 @@ RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_
             for (int w = 0; w < RT_SLAB_MAX_WORDS; w++) acc[w] |= inside ? seg[w] : 0u;
         }
     }
-    // + the quadrics this direction may put on their degenerate branch
-    uint32_t deg[RT_SLAB_MAX_WORDS] = {0u, 0u, 0u, 0u};
-    if (S.h->pencil_dir != 0xffffffffu) {
-        const uint32_t cell = pencil_cell_apex(S.pencils()[S.h->pencil_dir], S.h->pencil_stride, d, ok);
-        for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)
-            if (w < W) deg[w] = S.pen[cell + w];
-    }
     for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)
         if (w < W) words[w] = ok ? (acc[w] | deg[w] | B.always[w]) : B.valid[w];
 }
@@ -1236,7 +1242,7 @@ template <bool ENABLED>
 RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float len, bool from_apex)
 {
     PencilScan ps;
-    ps.use = false; ps.mem = true; ps.cell = 0u; ps.cur = 0u; ps.word = 0;
+    ps.use = false; ps.mem = true; ps.cell = 0u; ps.word = 0;
     if (!ENABLED || pencil < 0 || S.pen == nullptr || pencil >= (int)S.h->n_pencil) return ps;
     const DevPencil& P = S.pencils()[pencil];
     if (P.kind == RT_PENCIL_OFF) return ps;
@@ -1244,7 +1250,6 @@ RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float
     // from_apex: the ray starts AT the apex (camera rays: exactly, nothing to check about its origin); otherwise it runs towards it
     const bool ok = from_apex ? unit_direction(dot3_fma(rd, rd)) : pencil_ray_ok(ro, rd, P.kind == RT_PENCIL_APEX ? len : 0.0f);
     ps.cell = P.kind == RT_PENCIL_APEX ? pencil_cell_apex(P, stride, from_apex ? rd : -rd, ok) : pencil_cell_parallel(P, stride, ro, ok);
-    ps.cur = S.pen[ps.cell];
     ps.use = true;
     return ps;
 }
@@ -1280,13 +1285,12 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
         for (int w = 0; w < nws; w++) {
-            const uint32_t own = ps.next(S, slabw);
-            uint32_t u = wave_or(own, true);
+            uint32_t u = wave_or(ps.next(S, slabw), true);
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
                 const DevSurfaceCull c0 = cullrec[i];
-                const bool need = ((own >> b) & 1u) != 0u && !surface_cull(c0, ro, rd);
+                const bool need = !surface_cull(c0, ro, rd);
                 if (RT_ANY(need)) {
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
                 }
@@ -1336,12 +1340,11 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             bool group_live = true;
             if (ps.use) {   // phase 1 over the wave's pencil candidates only
                 for (int w = base >> 5; w << 5 < end; w++) {
-                    const uint32_t own = ps.next(S, slabw);
-                    uint32_t u = wave_or(own, true);
+                    uint32_t u = wave_or(ps.next(S, slabw), true);
                     while (u != 0u) {
                         const int b = __builtin_ctz(u), i = (w << 5) + b;
                         u &= u - 1u;
-                        if (((own >> b) & 1u) != 0u && !torus_cull(bound[i], ro, rd, tmin)) cand |= 1ull << (i - base);
+                        if (!torus_cull(bound[i], ro, rd, tmin)) cand |= 1ull << (i - base);
                     }
                 }
             } else
@@ -1449,13 +1452,12 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
         for (int w = 0; w < nws; w++) {
-            const uint32_t own = ps.next(S, slabw);
-            uint32_t u = wave_or(own, on);
+            uint32_t u = wave_or(ps.next(S, slabw), on);
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
                 const DevSurfaceCull c0 = cullrec[i];
-                const bool need = on && ((own >> b) & 1u) != 0u && !surface_cull(c0, ro, rd);
+                const bool need = on && !surface_cull(c0, ro, rd);
                 if (RT_ANY(need)) {
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; }
                     if (!RT_ANY(on)) u = 0u;
@@ -1499,12 +1501,11 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 bool group_live = true;
                 if (ps.use) {
                     for (int w = base >> 5; w << 5 < end; w++) {
-                        const uint32_t own = ps.next(S, slabw);
-                        uint32_t u = wave_or(own, on);
+                        uint32_t u = wave_or(ps.next(S, slabw), on);
                         while (u != 0u) {
                             const int b = __builtin_ctz(u), i = (w << 5) + b;
                             u &= u - 1u;
-                            if (on && ((own >> b) & 1u) != 0u && !torus_cull(bound[i], ro, rd, dist)) cand |= 1ull << (i - base);
+                            if (on && !torus_cull(bound[i], ro, rd, dist)) cand |= 1ull << (i - base);
                         }
                     }
                 } else

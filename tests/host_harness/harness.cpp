@@ -158,8 +158,20 @@ int harness_torus_premise(const void* record, int64_t n, uint64_t seed, float di
         const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
         bool solved = false;
         float t = 0.0f, t2 = 0.0f;
-        bool cull = torus_cull(S.torus_bound()[0], ro, rd, tmin);
-        if (!cull) { intersect_torus_c<true>(T, ro, rd, tmin, t2, solved); cull = !solved; }
+        bool cull;
+        if (seed >> 63) {
+            // the premise of the ray pencils and slab tables: the ray's LINE passes the (padded) bounding sphere by 4e-3 or more, in
+            // exact arithmetic -- whatever the distance of the origin (torus_cull asks for a margin that grows with the distance)
+            const f4 b = S.torus_bound()[0];
+            const double ocx = ox - b.x, ocy = oy - b.y, ocz = oz - b.z, ddx = rd.x, ddy = rd.y, ddz = rd.z;
+            const double dl2 = ddx * ddx + ddy * ddy + ddz * ddz, bq = ocx * ddx + ocy * ddy + ocz * ddz;
+            const double m2 = ocx * ocx + ocy * ocy + ocz * ocz - bq * bq / dl2, rr = std::sqrt(static_cast<double>(b.w)) + 4e-3;
+            cull = std::isfinite(static_cast<double>(b.w)) && m2 > rr * rr && std::fabs(dl2 - 1.0) <= 1e-3;
+            (void)t2; (void)solved;
+        } else {
+            cull = torus_cull(S.torus_bound()[0], ro, rd, tmin);
+            if (!cull) { intersect_torus_c<true>(T, ro, rd, tmin, t2, solved); cull = !solved; }
+        }
         const bool hit = intersect_torus(T, ro, rd, tmin, t);
         c_cull += cull; c_hit += hit;
         if (cull && hit) {
