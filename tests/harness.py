@@ -91,6 +91,21 @@ def pencil_stats(scene_blocks, fb_w=64, fb_h=64):
     return {"pencils": int(out[0]), "stride": int(out[1]), "each": [(int(out[k]), int(out[k + 1]), out[k + 2]) for k in range(2, n, 3)]}
 
 
+def table_premise(scene_blocks, n_rays, seed=1):
+    """Candidate tables primitive by primitive (harness_table_premise): {'rays', 'hits', 'violations', 'mean_bits', 'all_ones'} or None
+    when the scene has no tables."""
+    fr, _keep = _frame(scene_blocks, 64, 64, None, None, 1)
+    cnt = (ctypes.c_int64 * 5)()
+    fn = lib().harness_table_premise
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int64)]
+    rc = fn(ctypes.byref(fr), n_rays, seed, cnt)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("harness_table_premise failed")
+    return {"rays": cnt[0], "hits": cnt[1], "violations": cnt[2], "mean_bits": cnt[3] / max(1, cnt[0]), "all_ones": cnt[4]}
+
+
 def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=0, y1=None):
     fr, _keep = _frame(scene_blocks, fb_w, fb_h, textures, cubemap, cull)
     y1 = fb_h if y1 is None else y1

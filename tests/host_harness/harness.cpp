@@ -256,6 +256,97 @@ int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float 
     return n_bad;
 }
 
+// The candidate tables (ray pencils, slab tables) primitive by primitive: n random rays of three kinds -- from the camera (pencil 0), from
+// random points towards every light with a pencil, and arbitrary rays (slab tables) -- and for each ray every quadric and torus:
+// if the un-culled intersector reports a hit, the primitive's bit must be set in the ray's candidate mask.
+// counts: [0] rays, [1] hits, [2] VIOLATIONS (hit, bit clear), [3] set bits summed over the rays, [4] rays that read the all-ones cell.
+int harness_table_premise(const harness_frame* fr, int64_t n, uint64_t seed, int64_t counts[5])
+{
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    for (int b = 0; b < 9; b++) {
+        const unsigned char* p = static_cast<const unsigned char*>(fr->blocks[b]);
+        if (p && fr->block_sizes[b]) blocks[b].assign(p, p + fr->block_sizes[b]);
+    }
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(fr->defines, blocks, blob, err)) return -1;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const DevSceneHeader* hdr = reinterpret_cast<const DevSceneHeader*>(aligned.data());
+    if (hdr->n_pencil == 0) return -2;
+    std::vector<uint32_t> masks(hdr->pencil_mask_words, 0u);
+    const SceneView S0 = make_view(reinterpret_cast<const char*>(aligned.data()));
+    for (uint32_t k = 0; k < hdr->n_pencil + (hdr->pencil_dir != 0xffffffffu ? 1u : 0u); k++) {
+        const DevPencil P = S0.pencils()[k];
+        if (P.kind == RT_PENCIL_OFF) continue;
+        std::vector<PencilPrim> prims(hdr->n_surface + hdr->n_torus);
+        for (size_t i = 0; i < prims.size(); i++) prims[i] = pencil_prim_at(S0, P, static_cast<int>(i));
+#pragma omp parallel for schedule(static, 256)
+        for (int64_t cell = 0; cell <= static_cast<int64_t>(P.cells); cell++) {
+            const PencilCell C = pencil_cell_geometry(P, static_cast<uint32_t>(cell));
+            for (uint32_t w = 0; w < hdr->pencil_stride; w++)
+                masks[P.mask_off + static_cast<size_t>(cell) * hdr->pencil_stride + w] = pencil_cell_word(S0, P, prims.data(), C, static_cast<uint32_t>(cell), static_cast<int>(w));
+        }
+    }
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()), hdr, masks.data());
+    const int ns = hdr->n_surface, nt = hdr->n_torus, nws = (ns + 31) >> 5, W = static_cast<int>(hdr->pencil_stride);
+    const int n_lights = hdr->n_light_point + hdr->n_light_direct;
+    int64_t c_hit = 0, c_bad = 0, c_bits = 0, c_all = 0;
+#pragma omp parallel for schedule(static, 4096) reduction(+ : c_hit, c_bad, c_bits, c_all)
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t x = seed * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(k) * 0xbf58476d1ce4e5b9ull + 1;
+        auto u01 = [&]() { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return (x >> 11) * (1.0 / 9007199254740992.0); };
+        auto gauss = [&]() { double a = 0; for (int i = 0; i < 6; i++) a += u01(); return (a - 3.0) * 1.41421356; };
+        // a point in or around the crowd (tests/random_scenes.py: x, y within +-15, z 8 .. 24), sometimes far out
+        auto point = [&]() { const double far = u01() < 0.1 ? 40.0 : 1.0; return mk3((float)(gauss() * 7.0 * far), (float)(gauss() * 6.0 * far), (float)(16.0 + gauss() * 5.0 * far)); };
+        const int kind = static_cast<int>(k % 3);
+        f3 ro, rd;
+        float tlimit = RT_MAXDIST;
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool have = false;
+        if (kind == 0) {                         // camera ray
+            ro = xyz(S.h->cam_pos);
+            rd = normalize3(point() - ro);
+            const PencilScan ps = pencil_open<true>(S, 0, ro, rd, 0.0f, true);
+            if (ps.use) { have = true; for (int w = 0; w < W; w++) words[w] = S.pen[ps.cell + w]; }
+        } else if (kind == 1 && n_lights > 0) {  // shadow ray, built like calc_shade builds it
+            const int li = static_cast<int>(u01() * n_lights) % n_lights;
+            ro = point();
+            if (li < hdr->n_light_point) {
+                const f3 ld = xyz(S.lights_point()[li].pos_r2) - ro;
+                tlimit = length3(ld);
+                rd = normalize3(ld);
+            } else {
+                rd = xyz(S.lights_direct()[li - hdr->n_light_point].dir_n);
+            }
+            const PencilScan ps = pencil_open<true>(S, 1 + li, ro, rd, tlimit, false);
+            if (ps.use) { have = true; for (int w = 0; w < W; w++) words[w] = S.pen[ps.cell + w]; }
+        }
+        if (!have) {                             // any ray: slab tables
+            if (!slabs_available(S)) continue;
+            ro = point();
+            rd = normalize3(point() - ro);
+            tlimit = u01() < 0.5 ? RT_MAXDIST : (float)(1.0 + 40.0 * u01());
+            slab_ray_mask(S, ro, rd, tlimit, words);
+            have = true;
+        }
+        int bits = 0;
+        for (int w = 0; w < W; w++) bits += __builtin_popcount(words[w]);
+        c_bits += bits;
+        c_all += bits == ns + nt;
+        for (int i = 0; i < ns + nt; i++) {
+            float t = 0.0f;
+            const bool hit = i < ns ? intersect_surface(S.surfaces()[i], ro, rd, tlimit, t) : intersect_torus(S.tori()[i - ns], ro, rd, tlimit, t);
+            if (!hit) continue;
+            c_hit++;
+            const int w = i < ns ? i >> 5 : nws + ((i - ns) >> 5), b = (i < ns ? i : i - ns) & 31;
+            if (!((words[w] >> b) & 1u)) c_bad++;
+        }
+    }
+    counts[0] = n; counts[1] = c_hit; counts[2] = c_bad; counts[3] = c_bits; counts[4] = c_all;
+    return 0;
+}
+
 // Pencil diagnostics for the tests: out[0] = pencils, out[1] = mask words per cell, then per pencil (kind, cells, mean set bits per cell).
 int harness_pencil_stats(const harness_frame* fr, double* out, int max_out)
 {

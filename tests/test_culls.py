@@ -307,3 +307,22 @@ def test_open_clip_box_far_origin_regression(built):
     dhit, dt, dcull = harness.kat(oracle.TYPE_SURFACE, rec, ro, rd, 1e6)
     assert ohit and dhit and dt == ot and 3300 < ot < 3350
     assert not dcull
+
+
+@pytest.mark.parametrize("case", ["quadric", "torus"] + [f"crowd{k}" for k in range(6)] + [f"pencil{k}" for k in range(6)])
+def test_candidate_tables_in_bulk(built, case):
+    """Ray pencils and slab tables primitive by primitive (harness_table_premise): camera rays, shadow rays built like calc_shade builds
+    them, arbitrary rays with and without a length limit -- 150 000 rays against every quadric and torus of the scene: whatever the
+    un-culled intersector hits (degenerate-branch 'hits' beyond the limit included) must be in the ray's candidate mask."""
+    import random_scenes
+    from raytracing_opengl_amd import scenes
+    if case in ("quadric", "torus"):
+        sc = scenes.build_scene(case, 64, 64, 4)
+    else:
+        gen = random_scenes.crowd_scene if case.startswith("crowd") else random_scenes.pencil_scene
+        sc = gen(int(case[-1]), 64, 64)
+    r = harness.table_premise(sc, 150000, seed=7)
+    assert r is not None, "a long-table scene without tables"
+    assert r["violations"] == 0, r
+    n_prims = sc.defines[2] + sc.defines[4]
+    assert r["hits"] > 2000 and r["mean_bits"] < 0.6 * n_prims, (r, n_prims)     # the rays do hit things, and the masks do prune
