@@ -7,11 +7,16 @@ closest-hit scan (calcInter) or one shadow scan (inShadow) as the REFERENCE woul
 (SURVEY.md section 8(d)); the per-frame count is exact (kernel counter == oracle counter, see
 tests/test_gpu_parity.py) and is measured once, untimed, with the counting kernel variant.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is split into
-interleaved row bands (raytracing_opengl_amd/bands.py), every rank traces its bands, and the frame
-is gathered to rank 0 over RCCL each step -> "scaling": "strong". The target is the same at every N (default: the RGBA32F
-parity buffer the metric is defined on; --target rgba8 traces and gathers what the reference's framebuffer holds,
-GLWrapper.cpp:127,209-222, a quarter of the bytes), so a 1/2/4/8 series is one workload.
+N > 1: the SAME frame is split into interleaved 8-row bands (band b -> rank b mod N), every rank traces its bands, and the frame is
+gathered to rank 0 over RCCL each step -> "scaling": "strong". The draw goes through the C boundary north_star names ("GLWrapper dispatch
+-> HIP launch + RCCL tile gather", reference GLWrapper.cpp:155-165 called from main.cpp:188) in both launch forms:
+  python bench.py --gpus N                      one process drives N devices: rtx_create_multi(..., RTX_GATHER_RCCL), one rtx_draw per step
+  python -m torch.distributed.run ... bench.py  one process per GPU: every rank holds an rtx_create_rank context (RCCL communicator from a
+                                                unique id that torch.distributed only hands round), one rtx_draw per step on every rank
+(--launcher torch makes the first form re-exec itself as the second; --transport torch keeps the round-1/2 Python path, bands.py +
+dist.gather, for comparison.) The target is the same at every N (default: the RGBA32F parity buffer the metric is defined on; --target
+rgba8 traces and gathers what the reference's framebuffer holds, GLWrapper.cpp:127,209-222, a quarter of the bytes), so a 1/2/4/8 series
+is one workload. A box with fewer than N GPUs answers --gpus N with one line and exit code 2.
 
 Extra objects on the JSON line:
   roofline     HBM-write roofline of the trace kernel: W*H*16 B of RGBA32F per launch / mean kernel
@@ -40,6 +45,141 @@ WIDTH, HEIGHT, DEPTH, SCENE = 3840, 2160, 4, "default"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+def emit(out):
+    """The ONE JSON line, last on stdout: libraries that print through C stdio (RCCL's version banner at communicator creation) sit in a
+    buffer of their own when stdout is a pipe and would otherwise come out after Python's line, at exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
+    """N > 1 through the C boundary: one rtx_draw per step on a context that splits the frame itself (rtx_create_multi in one process,
+    rtx_create_rank in one process per GPU). Timed exactly like the single-GPU line: W warm-up draws, barrier + finish, K draws, finish +
+    barrier, max over ranks."""
+    from raytracing_opengl_amd import bands, scenes, textures, wrapper
+
+    W, H = args.width, args.height
+    per_process = mode == "ranks"
+    multi_proc = per_process and n_ranks > 1
+
+    def barrier():
+        if multi_proc:
+            dist.barrier()
+
+    def reduce_(values, op):
+        if not multi_proc:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return [float(v) for v in t]
+
+    gather_kind = {"rccl": wrapper.RTX_GATHER_RCCL, "peer": wrapper.RTX_GATHER_PEER_COPY, "loopback": wrapper.RTX_GATHER_RCCL_LOOPBACK}[args.transport]
+    sc = scenes.build_scene(args.scene, W, H, args.depth)
+    ts = textures.default_texture_set(scale=args.texture_scale)
+    if per_process:
+        uid = [wrapper.rccl_unique_id() if rank == 0 else None]
+        if multi_proc:
+            dist.broadcast_object_list(uid, src=0)
+        gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank, texture_lod=args.lod,
+                                   gather=gather_kind, rank=(rank, n_ranks, uid[0]))
+    else:
+        gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod, devices=list(range(n_ranks)), gather=gather_kind)
+    target = args.target
+    px_bytes = 16 if target == "rgba32f" else 4
+    gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 1 if target == "rgba32f" else 2)
+    gl.set_option(wrapper.RTX_OPT_CULL, args.cull)
+    gl.set_option(wrapper.RTX_OPT_SCENE_LDS, args.lds)
+    gl.set_option(wrapper.RTX_OPT_XCD_REMAP, args.xcd)
+    gl.set_option(wrapper.RTX_OPT_RAY_PENCILS, args.pencils)
+
+    # exact reference-defined ray count of the frame (untimed, counting kernel variant; summed over the ranks)
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    gl.draw()
+    gl.finish()
+    st = gl.stats()
+    rays_frame, rays_cast_frame = (int(v) for v in reduce_([st["rays_closest"] + st["rays_shadow"], st["rays_closest"] + st["rays_shadow_cast"]], dist.ReduceOp.SUM))
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 0)
+
+    for _ in range(args.warmup):
+        gl.draw()
+    gl.finish()
+    gl.stats()   # retire warm-up events
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gl.draw()
+    gl.finish()   # every device's launch and transfer streams, incl. the placement of the last frame on rank 0
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    n_ev = min(args.steps, 128)
+    trace_ms = gl.sum_recent_draw_ms(n_ev) / n_ev   # HIP events on the launch streams; the slowest rank of this process
+    st_end = gl.stats()
+    elapsed, trace_ms_max = reduce_([elapsed, trace_ms], dist.ReduceOp.MAX)
+    if rank != 0:
+        gl.stop()
+        return
+    # the assembled frame against ONE device tracing all of it (untimed): bit-identical or the split is wrong
+    fmt = wrapper.RTX_RGBA32F if target == "rgba32f" else wrapper.RTX_RGBA8
+    got = gl.read_pixels(fmt)
+    gl.stop()
+    one = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank, texture_lod=args.lod)
+    for o, v in ((wrapper.RTX_OPT_CULL, args.cull), (wrapper.RTX_OPT_SCENE_LDS, args.lds), (wrapper.RTX_OPT_XCD_REMAP, args.xcd), (wrapper.RTX_OPT_RAY_PENCILS, args.pencils)):
+        one.set_option(o, v)
+    one.draw()
+    want = one.read_pixels(fmt)
+    one.stop()
+    same = bool(np.array_equal(got.view(np.uint32 if target == "rgba32f" else np.uint8), want.view(np.uint32 if target == "rgba32f" else np.uint8)))
+    ms_per_step = elapsed / args.steps * 1e3
+    rows0 = bands.local_rows(H, 8, 0, n_ranks)
+    achieved = rows0 * W * px_bytes / (trace_ms_max * 1e-3) / 1e9
+    moved = sum(bands.local_rows(H, 8, r, n_ranks) for r in range(0 if args.transport == "loopback" else 1, n_ranks)) * W * px_bytes
+    out = {
+        "metric": f"Mray/s at {W}x{H} depth-{args.depth} {args.scene} scene (reference-defined rays: closest-hit + shadow scans)",
+        "value": round(rays_frame * args.steps / elapsed / 1e6, 2),
+        "unit": "Mray/s",
+        "n_gpus": n_ranks,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.scene} scene (reference main.cpp:43-132, t=0), {W}x{H}, reflection depth {args.depth}, "
+                               f"{target.upper()} target, seeded synthetic textures at reference sizes/{args.texture_scale}",
+                   "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
+                   "parallelism": f"{n_ranks} GPU{'s' if n_ranks > 1 else ''}, interleaved 8-row bands, one rtx_draw per frame on "
+                                  + ("one rtx_create_rank context per process" if per_process else "one rtx_create_multi context")
+                                  + f", gather of the {target.upper()} frame to rank 0",
+                   "launcher": "torch.distributed.run, one process per GPU" if per_process else "one process, N devices",
+                   "transport": {"rccl": "RCCL: grouped ncclSend/ncclRecv, every peer straight to rank 0 (librtx_hip.so)",
+                                 "loopback": "RCCL incl. rank 0 -> rank 0 (diagnostic)",
+                                 "peer": "hipMemcpyPeerAsync issued by rank 0 (librtx_hip.so)"}[args.transport],
+                   "trace_ms_max_rank": round(trace_ms_max, 4), "gather_ms": round(st_end["last_gather_ms"], 4),
+                   "gather_bytes_per_frame": int(moved),
+                   "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd},
+        "ms_per_frame": round(ms_per_step, 4),
+        "kernel_ms": round(trace_ms_max, 4),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "note": f"rank 0's launch: its {rows0} rows of the {target.upper()} frame ({px_bytes} B/pixel) / the slowest rank's mean kernel time; "
+                             "the path is bound by VALU issue (DESIGN.md); gather_ms = transfer + band placement of the last frame on rank 0's "
+                             "transfer stream (overlaps the next frame's trace)"},
+        "parity": {"vs_one_device_tracing_the_whole_frame": "bit-identical" if same else "DIFFERENT", "checked": target.upper()},
+    }
+    emit(out)
+    if not same:
+        raise SystemExit("bench.py: the gathered frame differs from the single-device frame")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,21 +201,63 @@ def main():
                          "workload: rgba32f (default) = the 16 B/pixel parity buffer of the BASELINE metric; rgba8 = what the reference's "
                          "framebuffer holds (GLWrapper.cpp:127,209-222), a quarter of the gather traffic")
     ap.add_argument("--no-smaa", action="store_true", help="skip the untimed SMAA post-process measurement (N = 1)")
+    ap.add_argument("--launcher", choices=("auto", "torch"), default="auto",
+                    help="N > 1 without torch.distributed.run around it: auto = one process drives the N devices through rtx_create_multi; "
+                         "torch = re-exec this script under torch.distributed.run (one process per GPU, rtx_create_rank)")
+    ap.add_argument("--transport", choices=("rccl", "peer", "torch", "loopback"), default="rccl",
+                    help="how the bands reach rank 0: rccl = grouped ncclSend/ncclRecv inside the C library (default); peer = hipMemcpyPeerAsync by "
+                         "the root (single-process form only); torch = the Python path (bands.py, dist.gather; torch.distributed.run form only); "
+                         "loopback = rccl with rank 0's own bands sent to itself as well -- a diagnostic that runs the N > 1 code, RCCL included, "
+                         "on a box with one GPU (--gpus 1 --transport loopback)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if under_torchrun and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but torch.distributed.run started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP tracer has no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    if args.gpus < 1 or (not under_torchrun and args.gpus > n_dev) or (under_torchrun and local_rank >= n_dev):
+        print(f"bench.py: --gpus {args.gpus} requested but this box has {n_dev} GPU{'s' if n_dev != 1 else ''}", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    if not under_torchrun and args.gpus > 1 and (args.launcher == "torch" or args.transport == "torch"):
+        # the one-process-per-GPU form, started from here (what the driver does itself for N > 1)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    # how the N ranks are driven: "single" = plain context (N = 1); "multi" = one process, rtx_create_multi; "ranks" = one process per GPU,
+    # rtx_create_rank; "torch" = one process per GPU, rtx_draw_bands + dist.gather (the Python path)
+    if args.gpus == 1 and args.transport != "loopback":
+        mode = "single"
+    elif not under_torchrun:
+        mode = "multi"
+    else:
+        mode = "torch" if args.transport == "torch" else "ranks"
+    if mode == "ranks" and args.transport == "peer":
+        raise SystemExit("bench.py: --transport peer needs the single-process form (ranks in separate processes exchange their bands over RCCL)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if under_torchrun and world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if mode == "torch":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            # torch.distributed is only the rendezvous here (unique id, barrier, max / sum of a few numbers, all on CPU tensors over gloo):
+            # the frame's bytes move inside the C library, on its own RCCL communicator
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode in ("multi", "ranks"):
+        try:
+            bench_c_boundary(args, mode, world if mode == "ranks" else args.gpus, rank, local_rank)
+        finally:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        return
 
     from raytracing_opengl_amd import bands, scenes, textures, wrapper
 
@@ -223,9 +405,7 @@ def main():
         if world == 1 and not args.no_smaa:
             # the post-process that follows the tracer in the reference's draw(). Untimed addition to the line: ULTRA (main.cpp:32)
             # on the frame just traced, HIP events around the four kernels of one resolve. Algorithmic bytes: W*H*4 read + W*H*4 written.
-            from raytracing_opengl_amd import smaa_tables
-            gl.enable_SMAA(wrapper.ULTRA)
-            gl.set_smaa_tables(smaa_tables.area_table(), smaa_tables.search_table())
+            gl.enable_SMAA(wrapper.ULTRA)   # the library's own area / search tables (== the reference's arrays, include/rtx/smaa_tables.h)
             gl.draw()
             ts_ms = []
             for _ in range(12):
@@ -237,8 +417,9 @@ def main():
             out["smaa"] = {"preset": "ULTRA", "ms_per_resolve": round(smaa_ms, 4), "edge_pixels": int(sm["smaa_edge_pixels"]),
                            "roofline": {"bound": "hbm", "achieved": round(W * H * 8 / smaa_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(W * H * 8 / smaa_ms / 1e6 / HBM_PEAK_GBS, 4)},
-                           "note": "all four kernels of one resolve of the traced frame (RGBA8 in, RGBA8 screen out); synthetic area table, "
-                                   "search table from its definition; byte-exact against the oracle in tests/test_gpu_smaa.py"}
+                           "note": "all kernels of one resolve of the traced frame (RGBA8 in, RGBA8 screen out); area and search tables generated "
+                                   "by the library, byte-identical to the reference's AreaTex.h / SearchTex.h (tests/test_smaa_tables.py); "
+                                   "byte-exact against the oracle in tests/test_gpu_smaa.py"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod)
@@ -285,7 +466,7 @@ def main():
                 out["parity"] = {"max_abs_diff": float(np.nanmax(d)), "over_1e-4": int((d > 1e-4).sum()),
                                  "nan_mismatch": int((np.isnan(img) != np.isnan(ref)).sum()),
                                  "rays_match": bool(cnt["rays_closest"] + cnt["rays_shadow"] == rays_frame)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     gl.stop()
     if world > 1:
         dist.destroy_process_group()

@@ -120,10 +120,31 @@ RTX_API int rtx_create(int width, int height, int device, rtx_context** out);
  * splits the frame into interleaved 8-row bands (band b -> device b mod N), every device traces its bands, and the root (device_ids[0])
  * receives them and assembles the colour targets that rtx_read_pixels / the SMAA resolve see. `gather`: how the bands reach the root --
  * RTX_GATHER_RCCL: one grouped ncclSend/ncclRecv pair per peer (librccl.so is loaded at this call; one device per rank);
- * RTX_GATHER_PEER_COPY: hipMemcpyPeerAsync by the root (no library; ranks may share a device). n_devices = 1 is a plain context. */
-typedef enum rtx_gather { RTX_GATHER_RCCL = 0, RTX_GATHER_PEER_COPY = 1 } rtx_gather;
+ * RTX_GATHER_PEER_COPY: hipMemcpyPeerAsync by the root (no library; ranks may share a device). n_devices = 1 is a plain context
+ * (except with RTX_GATHER_RCCL_LOOPBACK). Only the colour targets RTX_OPT_GATHER_TARGETS names are traced and moved. */
+typedef enum rtx_gather {
+    RTX_GATHER_RCCL = 0,
+    RTX_GATHER_PEER_COPY = 1,
+    RTX_GATHER_RCCL_LOOPBACK = 2 /* as RTX_GATHER_RCCL, and the root's OWN bands also travel through ncclSend / ncclRecv (to itself) instead of
+                                    being placed directly: a diagnostic with which a box that has a single GPU executes the RCCL transport
+                                    end to end (library load, communicator, grouped send/recv, stream ordering). n_devices may be 1. */
+} rtx_gather;
 RTX_API int rtx_create_multi(int width, int height, int n_devices, const int* device_ids, int gather, rtx_context** out);
+/* The same frame split with ONE PROCESS PER GPU (the launch model of torch.distributed.run / mpirun): every process creates the context of
+ * its own rank on its own device and then drives it exactly like a single-device context -- the host program is the same on every rank, so
+ * blocks, textures and options are replicated by construction. rtx_draw traces the rank's interleaved 8-row bands (band b -> rank b mod N)
+ * and, on the rank's transfer stream, sends them to rank 0 (ncclSend); rank 0 receives every peer's bands inside one ncclGroup and
+ * assembles the colour targets, which only rank 0 can read (rtx_read_pixels on another rank is RTX_ERR_ORDER). The RCCL communicator is
+ * bootstrapped from a unique id: rank 0 calls rtx_rccl_unique_id and hands the 128 bytes to the other processes by whatever means the
+ * launcher offers (a torch.distributed / MPI broadcast, a file). `gather`: RTX_GATHER_RCCL or RTX_GATHER_RCCL_LOOPBACK. Collective: every
+ * rank must make the call, and every rank must call rtx_draw the same number of times. rtx_get_stats reports the rank's own counters. */
+#define RTX_RCCL_ID_BYTES 128
+RTX_API int rtx_rccl_unique_id(uint8_t id[RTX_RCCL_ID_BYTES]);
+RTX_API int rtx_create_rank(int width, int height, int device, int rank, int n_ranks, const uint8_t id[RTX_RCCL_ID_BYTES], int gather,
+                            rtx_context** out);
+/* Number of ranks the frame is split over (1 for a plain context) and this context's rank (0 for a plain or single-process context). */
 RTX_API int rtx_device_count(rtx_context* ctx, int* n_devices);
+RTX_API int rtx_rank(rtx_context* ctx, int* rank);
 /* GLWrapper::~GLWrapper / stop()  [GLWrapper.cpp:25-44,143-147] */
 RTX_API void rtx_destroy(rtx_context* ctx);
 /* The reference's update_buffer / load_cubemap are static and act on "the current GL context";
@@ -190,9 +211,13 @@ RTX_API int rtx_finish(rtx_context* ctx);
 RTX_API int rtx_enable_smaa(rtx_context* ctx, int preset);
 /* SMAA_Builder::load_area_texture / load_search_texture  [SMAA_Builder.h:52-83]: the two look-up tables as the caller's
  * bytes -- area: 160 x 560 texels of RG8, search: 64 x 16 texels of R8, row 0 first (the arrays of the reference's AreaTex.h /
- * SearchTex.h have exactly this form). The library holds no copy of its own; a resolve without tables is RTX_ERR_ORDER. */
+ * SearchTex.h have exactly this form). OPTIONAL: without this call the library uses its own tables, computed from their published
+ * construction (include/rtx/smaa_tables.h) and byte-identical to the reference's two arrays -- enable_SMAA then works like the
+ * reference's without any table on the caller's include path. */
 RTX_API int rtx_smaa_set_tables(rtx_context* ctx, const uint8_t* area_rg8, int area_w, int area_h,
                                 const uint8_t* search_r8, int search_w, int search_h);
+/* Those own tables as bytes (either pointer may be NULL; 160*560*2 and 64*16 bytes). Host-only: needs no context and no device. */
+RTX_API int rtx_smaa_default_tables(uint8_t* area_rg8, size_t area_bytes, uint8_t* search_r8, size_t search_bytes);
 /* The post-process alone, on whatever the RGBA8 colour target holds (GLWrapper.cpp:173-204 without :155-165). */
 RTX_API int rtx_smaa_resolve(rtx_context* ctx);
 /* glTexSubImage2D on fboTexColor: replace the RGBA8 colour target by W*H*4 caller bytes, row 0 = bottom row (tests and

@@ -8,9 +8,10 @@
 // (GLWrapper.cpp:224-227,371-375; utils.h:57-63). What is different, by construction:
 //   * the "window" is a device colour target; `window` is a null GLFWwindow* (windowing, input and
 //     presentation are outside the replaced path -- SURVEY.md section 8(b),(f));
-//   * enable_SMAA(preset) switches on the SMAA post-process (the three passes of GLWrapper.cpp:173-204 as HIP kernels); its two
-//     look-up tables are third-party data this repository does not carry: built inside the reference tree (AreaTex.h / SearchTex.h
-//     on the include path) the shim hands those arrays over in init_shaders like SMAA_Builder does; otherwise call set_SMAA_tables;
+//   * enable_SMAA(preset) switches on the SMAA post-process (the three passes of GLWrapper.cpp:173-204 as HIP kernels). Its two
+//     look-up tables need nothing from the caller: the library computes them (rtx/smaa_tables.h; byte-identical to the reference's
+//     AreaTex.h / SearchTex.h arrays). Built inside the reference tree the shim still hands the tree's own arrays over in init_shaders,
+//     like SMAA_Builder does; set_SMAA_tables replaces them with any others;
 //   * image files: the tracer boundary takes decoded 8-bit texels. load_texture/load_cubemap
 //     decode through a pluggable function (set_image_decoder); the built-in decoder reads PNG (png_decode.h), JPEG
 //     (jpeg_decode.h; stb_image's arithmetic, so the texels equal the reference's) and binary PPM/PGM (P6/P5) and
@@ -173,7 +174,7 @@ public:
     {
         // Which GPUs draw() uses is the environment's choice, so that a main.cpp-style program needs no new code for a multi-GPU node:
         //   RTX_DEVICES = "0,1,2,3" (device ids) or "4" (the first four) -> rtx_create_multi: interleaved row bands, assembled on the first;
-        //   RTX_GATHER  = "rccl" (default) | "peer" (hipMemcpyPeerAsync);   RTX_DEVICE = id of the single device otherwise (default 0).
+        //   RTX_GATHER  = "rccl" (default) | "peer" (hipMemcpyPeerAsync) | "loopback" (rccl incl. the root's own bands: one-GPU diagnostic);   RTX_DEVICE = id of the single device otherwise (default 0).
         std::vector<int> ids;
         if (const char* list = std::getenv("RTX_DEVICES")) {
             const std::string t = list;
@@ -192,7 +193,7 @@ public:
         int st;
         if (ids.size() > 1) {
             const char* g = std::getenv("RTX_GATHER");
-            st = rtx_create_multi(width, height, static_cast<int>(ids.size()), ids.data(), (g && g[0] == 'p') ? RTX_GATHER_PEER_COPY : RTX_GATHER_RCCL, &ctx);
+            st = rtx_create_multi(width, height, static_cast<int>(ids.size()), ids.data(), (g && g[0] == 'p') ? RTX_GATHER_PEER_COPY : (g && g[0] == 'l') ? RTX_GATHER_RCCL_LOOPBACK : RTX_GATHER_RCCL, &ctx);
         } else {
             const char* dev = std::getenv("RTX_DEVICE");
             st = rtx_create(width, height, ids.size() == 1 ? ids[0] : (dev ? std::atoi(dev) : 0), &ctx);

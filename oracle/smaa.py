@@ -72,6 +72,20 @@ def blend_pass_jitter(edges_rg8: np.ndarray, preset, area, search, jx: float, jy
     return out
 
 
+def blend_pass_forced(edges_rg8: np.ndarray, preset, area, search, force: int, slack_lo: float = 0.0, slack_hi: float = 0.0) -> np.ndarray:
+    """Diagnostic: pass 2 at exact positions with "phantom" north (force & 1) / west (force & 2) edges taken (see smaa_oracle.c)."""
+    edges = np.ascontiguousarray(edges_rg8, np.uint8)
+    h, w = edges.shape[:2]
+    area, search = _luts(area, search)
+    out = np.empty((h, w, 4), np.uint8)
+    l = _lib()
+    l.smaa_oracle_blend_pass_forced.restype = ctypes.c_int
+    l.smaa_oracle_blend_pass_forced.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    if l.smaa_oracle_blend_pass_forced(edges.ctypes.data, w, h, _preset(preset), area.ctypes.data, search.ctypes.data, int(force), slack_lo, slack_hi, out.ctypes.data) != 0:
+        raise RuntimeError("smaa_oracle_blend_pass_forced failed")
+    return out
+
+
 def neighborhood_pass(color_rgba8: np.ndarray, blend_rgba8: np.ndarray) -> np.ndarray:
     color, blend = np.ascontiguousarray(color_rgba8, np.uint8), np.ascontiguousarray(blend_rgba8, np.uint8)
     h, w = color.shape[:2]

@@ -347,7 +347,7 @@ static void corner_v(const blend_ctx* C, v2* weights, float ax, float ay, float 
 }
 
 /* SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) with the varyings of ...VS (SMAA.h:656-668) */
-static void blend_pixel_at(const blend_ctx* C, float X, float Y, float slack_lo, float slack_hi, uint8_t out[4])
+static void blend_pixel_at(const blend_ctx* C, float X, float Y, float slack_lo, float slack_hi, int force, uint8_t out[4])
 {
     const float S = (float)C->P->max_steps;
     /* offset[0] = (X - 0.25, Y - 0.125, X + 1.25, Y - 0.125); offset[1] = (X - 0.125, Y - 0.25, X - 0.125, Y + 1.25);
@@ -362,6 +362,10 @@ static void blend_pixel_at(const blend_ctx* C, float X, float Y, float slack_lo,
     v4 weights = {0.0f, 0.0f, 0.0f, 0.0f};
     const v4 es = sample(C->edges, X, Y);
     v2 e = {es.x, es.y};
+    /* force (diagnostic, normally 0): bit 0 / bit 1 make a pixel WITHOUT a north / west edge take the branch as a GL implementation's
+     * noisy centre fetch does when it picks up 1e-5 of a neighbour's edge ("phantom edge", smaa_oracle_blend_pass_forced below) */
+    if ((force & 1) && !(e.y > 0.0f)) e.y = 1e-6f;
+    if ((force & 2) && !(e.x > 0.0f)) e.x = 1e-6f;
     if (e.y > 0.0f) {   /* edge at north */
         int do_hv = 1;
         if (C->P->max_steps_diag > 0) {
@@ -410,7 +414,7 @@ static void blend_pixel_at(const blend_ctx* C, float X, float Y, float slack_lo,
     out[0] = to_unorm8(weights.x); out[1] = to_unorm8(weights.y); out[2] = to_unorm8(weights.z); out[3] = to_unorm8(weights.w);
 }
 
-static void blend_pixel(const blend_ctx* C, int x, int y, uint8_t out[4]) { blend_pixel_at(C, (float)x, (float)y, 0.0f, 0.0f, out); }
+static void blend_pixel(const blend_ctx* C, int x, int y, uint8_t out[4]) { blend_pixel_at(C, (float)x, (float)y, 0.0f, 0.0f, 0, out); }
 
 /* ---- pass 3: SMAANeighborhoodBlendingPS (SMAA.h:1252-1300) -------------------------------------------------- */
 static void neighborhood_pixel(const tex_t* color, const tex_t* blend, int x, int y, uint8_t out[4])
@@ -509,6 +513,32 @@ int smaa_oracle_blend_pass_jitter(const uint8_t* edges, int w, int h, int preset
     const blend_ctx C = {&te, &ta, &ts, &k_presets[preset]};
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) blend_pixel_at(&C, (float)x + jx, (float)y + jy, slack_lo, slack_hi, blend_out + ((size_t)y * w + x) * 4);
+        for (int x = 0; x < w; x++) blend_pixel_at(&C, (float)x + jx, (float)y + jy, slack_lo, slack_hi, 0, blend_out + ((size_t)y * w + x) * 4);
+    return 0;
+}
+
+/* Diagnostic for the same pin: pass 2 at EXACT positions, but a pixel that has no north (force bit 0) / west (bit 1) edge of its own while
+ * one of its eight neighbours has one takes the `e.g > 0.0` / `e.r > 0.0` branch anyway (SMAA.h:1155,1205) -- what llvmpipe's centre fetch
+ * does when its bilinear weights are 1e-5 off. The value such a "phantom" pixel gets is then fully determined (searches, area look-up and
+ * corner rounding run on the real edge texture), so the classifier can demand it instead of excusing the pixel. */
+int smaa_oracle_blend_pass_forced(const uint8_t* edges, int w, int h, int preset, const uint8_t* area_tex, const uint8_t* search_tex, int force,
+                                  float slack_lo, float slack_hi, uint8_t* blend_out)
+{
+    if (!edges || !area_tex || !search_tex || !blend_out || w <= 0 || h <= 0 || preset < 0 || preset > 3) return -1;
+    const tex_t te = {w, h, 2, edges}, ta = {160, 560, 2, area_tex}, ts = {64, 16, 1, search_tex};
+    const blend_ctx C = {&te, &ta, &ts, &k_presets[preset]};
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int nb_n = 0, nb_w = 0;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int xx = clampi(x + dx, 0, w - 1), yy = clampi(y + dy, 0, h - 1);
+                    nb_w |= edges[((size_t)yy * w + xx) * 2 + 0] != 0;
+                    nb_n |= edges[((size_t)yy * w + xx) * 2 + 1] != 0;
+                }
+            const int f = ((force & 1) && nb_n ? 1 : 0) | ((force & 2) && nb_w ? 2 : 0);
+            blend_pixel_at(&C, (float)x, (float)y, slack_lo, slack_hi, f, blend_out + ((size_t)y * w + x) * 4);
+        }
     return 0;
 }

@@ -16,7 +16,8 @@ RTX_RGBA32F, RTX_RGBA8, RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_WEIGHTS_R
 RTX_SMAA_OFF, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_HIGH, RTX_SMAA_ULTRA = -1, 0, 1, 2, 3
 RTX_WRAP_REPEAT, RTX_WRAP_CLAMP_TO_EDGE = 0, 1
 RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_GATHER_TARGETS, RTX_OPT_RAY_PENCILS = 0, 1, 2, 3, 4, 5, 6, 7, 8
-RTX_GATHER_RCCL, RTX_GATHER_PEER_COPY = 0, 1
+RTX_GATHER_RCCL, RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL_LOOPBACK = 0, 1, 2
+RTX_RCCL_ID_BYTES = 128
 
 # every symbol include/rtx.h declares (tests/test_capi_symbols.py checks the .so against this list)
 SYMBOLS = (
@@ -25,8 +26,8 @@ SYMBOLS = (
     "rtx_sampler_unit", "rtx_bind_texture", "rtx_texture_destroy", "rtx_set_option", "rtx_get_option", "rtx_draw",
     "rtx_draw_bands", "rtx_finish", "rtx_read_pixels", "rtx_framebuffer_device", "rtx_get_stats",
     "rtx_sum_recent_draw_ms", "rtx_selftest",
-    "rtx_enable_smaa", "rtx_smaa_set_tables", "rtx_smaa_resolve", "rtx_write_pixels",
-    "rtx_create_multi", "rtx_device_count",
+    "rtx_enable_smaa", "rtx_smaa_set_tables", "rtx_smaa_default_tables", "rtx_smaa_resolve", "rtx_write_pixels",
+    "rtx_create_multi", "rtx_device_count", "rtx_rank", "rtx_rccl_unique_id", "rtx_create_rank",
 )
 
 
@@ -94,9 +95,13 @@ def load():
     lib.rtx_selftest.argtypes = [vp, P(i)]
     lib.rtx_create_multi.argtypes = [i, i, i, P(i), i, P(vp)]
     lib.rtx_device_count.argtypes = [vp, P(i)]
+    lib.rtx_rank.argtypes = [vp, P(i)]
+    lib.rtx_rccl_unique_id.argtypes = [vp]
+    lib.rtx_create_rank.argtypes = [i, i, i, i, i, vp, i, P(vp)]
     lib.rtx_enable_smaa.argtypes = [vp, i]
     lib.rtx_smaa_set_tables.argtypes = [vp, vp, i, i, vp, i, i]
     lib.rtx_smaa_resolve.argtypes = [vp]
+    lib.rtx_smaa_default_tables.argtypes = [vp, c.c_size_t, vp, c.c_size_t]
     lib.rtx_write_pixels.argtypes = [vp, i, vp, c.c_size_t]
     for name in SYMBOLS:
         fn = getattr(lib, name)

@@ -6,7 +6,27 @@
 // launch on the context's stream, bracketed by HIP events for the per-draw time.
 // There is no CPU fallback: without a usable HIP device rtx_create fails.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen-ed when a multi-device context asks for it
+// RCCL: types and prototypes only -- the library is dlopen-ed when a multi-device context asks for it, so a box without the RCCL
+// development headers still builds the single-device library from the few declarations below (same ABI as rccl.h / nccl.h).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommInitAll(ncclComm_t*, int, const int*);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 #include <dlfcn.h>
 
@@ -23,6 +43,7 @@
 #include "rt_pack.h"
 #include "smaa_kernel.h"
 #include "bands_kernel.h"
+#include "rtx/smaa_tables.h"
 
 using namespace rtdev;
 
@@ -86,9 +107,10 @@ struct rtx_context {
     int scene_bytes = 0;
     // cross-stream ordering of the single device scene (rtx_draw_bands may bring its own stream): the stream of the last
     // upload / launch and an event after the last launch; a draw on another stream waits for both (upload_scene, draw_impl)
-    hipStream_t upload_stream = nullptr, launch_stream = nullptr;
+    hipStream_t upload_stream = nullptr;
     int last_stage = -1;
-    hipEvent_t launch_done = nullptr;
+    // one "last launch done" event per distinct stream the scene was ever read on: an upload on stream S waits for every other one
+    std::vector<std::pair<hipStream_t, hipEvent_t>> launch_done;
     // textures
     std::map<uint32_t, Texture> textures;
     uint32_t next_handle = 1;
@@ -123,11 +145,17 @@ struct rtx_context {
     uint8_t* d_search = nullptr;
     hipEvent_t smaa_start = nullptr, smaa_stop = nullptr;
     bool smaa_timed = false;
+    bool screen_valid = false;       // d_screen holds a resolve of the current colour target's size (set by smaa_resolve)
     // multi-device (rtx_create_multi): the context the caller holds is rank 0 (the root, which owns the assembled frame); `peers` are
     // the contexts of ranks 1..N-1, ordinary single-device contexts that every scene / texture / option call is forwarded to.
+    // A per-process rank (rtx_create_rank) is the same thing with the other ranks living in other processes: no peers, its own communicator.
     std::vector<rtx_context*> peers;
     rtx_context* owner = nullptr;      // set on a peer: its root
     int rank = 0;
+    bool banded = false;               // the frame is split into interleaved bands over n_total ranks and assembled on rank 0
+    int n_total = 1;                   // ranks the frame is split over
+    bool per_process = false;          // rtx_create_rank: one rank per process
+    bool loopback = false;             // RTX_GATHER_RCCL_LOOPBACK: rank 0's own bands travel through the transport too
     int gather_kind = RTX_GATHER_RCCL;
     int gather_targets = 3;            // bit 0: RGBA32F, bit 1: RGBA8 travel to the root (RTX_OPT_GATHER_TARGETS)
     int band_rows = 8;                 // rows per band of the interleaved split: the kernel's tile height, the finest interleave
@@ -192,7 +220,8 @@ int upload_scene(rtx_context* ctx, hipStream_t stream)
         ctx->d_scene_cap = cap;
     }
     // the device scene is about to be overwritten: a kernel still reading it on ANOTHER stream has to finish first
-    if (ctx->launch_stream && ctx->launch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->launch_done, 0));
+    for (auto& ld : ctx->launch_done)
+        if (ld.first != stream) HIP_TRY(hipStreamWaitEvent(stream, ld.second, 0));
     const int k = ctx->stage_next;
     ctx->stage_next ^= 1;
     HIP_TRY(hipEventSynchronize(ctx->stage_done[k]));  // staging buffer k is free again
@@ -361,11 +390,53 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     const bool high_occ = ctx->opt_occ < 0 ? n_prims >= 32 : ctx->opt_occ != 0;
     HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream));
     HIP_TRY(hipEventRecord(ctx->ev_stop[e], stream));
-    HIP_TRY(hipEventRecord(ctx->launch_done, stream));
-    ctx->launch_stream = stream;
+    {
+        hipEvent_t done = nullptr;
+        for (auto& ld : ctx->launch_done)
+            if (ld.first == stream) done = ld.second;
+        if (!done) {
+            if (ctx->launch_done.size() >= 16) {   // a caller cycling through many streams: fold the oldest into a device-wide wait
+                HIP_TRY(hipEventSynchronize(ctx->launch_done.front().second));
+                done = ctx->launch_done.front().second;
+                ctx->launch_done.erase(ctx->launch_done.begin());
+            } else {
+                HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            }
+            ctx->launch_done.emplace_back(stream, done);
+        }
+        HIP_TRY(hipEventRecord(done, stream));
+    }
     ctx->ev_head = (ctx->ev_head + 1) % EVENT_RING;
     ctx->ev_pending++;
     ctx->launches++;
+    return RTX_OK;
+}
+
+// The two SMAA look-up tables, generated once per process from their published construction (include/rtx/smaa_tables.h).
+void default_smaa_tables(const uint8_t** area, const uint8_t** search)
+{
+    static std::vector<uint8_t> a, s;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        a.resize(rtx_smaa::AREA_BYTES);
+        s.resize(rtx_smaa::SEARCH_BYTES);
+        rtx_smaa::generate_area_table(a.data());
+        rtx_smaa::generate_search_table(s.data());
+    });
+    *area = a.data();
+    *search = s.data();
+}
+
+int upload_smaa_tables(rtx_context* ctx, const uint8_t* area_rg8, const uint8_t* search_r8)
+{
+    int st = use_device(ctx);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_area) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_area), rtx_smaa::AREA_BYTES));
+    if (!ctx->d_search) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_search), rtx_smaa::SEARCH_BYTES));
+    HIP_TRY(hipMemcpy(ctx->d_area, area_rg8, rtx_smaa::AREA_BYTES, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_search, search_r8, rtx_smaa::SEARCH_BYTES, hipMemcpyHostToDevice));
+    ctx->smaa_tables = true;
     return RTX_OK;
 }
 
@@ -390,9 +461,14 @@ int smaa_alloc(rtx_context* ctx)
 // The three passes after the tracer (GLWrapper.cpp:173-204) on the context's RGBA8 colour target, into the screen buffer.
 int smaa_resolve(rtx_context* ctx, hipStream_t stream)
 {
-    if (!ctx->smaa_tables) return fail(RTX_ERR_ORDER, "SMAA is enabled but rtx_smaa_set_tables has not supplied the area / search tables");
     int st = smaa_alloc(ctx);
     if (st) return st;
+    if (!ctx->smaa_tables) {   // the caller supplied none: the library's own (== the arrays the reference uploads, rtx/smaa_tables.h)
+        const uint8_t *area = nullptr, *search = nullptr;
+        default_smaa_tables(&area, &search);
+        st = upload_smaa_tables(ctx, area, search);
+        if (st) return st;
+    }
     if (stream != ctx->stream) return fail(RTX_ERR_INVALID, "the SMAA resolve runs on the context's own stream");
     SmaaBuffers b;
     b.w = ctx->width;
@@ -411,6 +487,7 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
     HIP_TRY(hipEventRecord(ctx->smaa_stop, stream));
     ctx->smaa_frame++;
     ctx->smaa_timed = true;
+    ctx->screen_valid = true;
     return RTX_OK;
 }
 
@@ -419,6 +496,8 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
 struct Rccl {
     void* lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
@@ -434,26 +513,44 @@ struct Rccl {
         }
         if (!lib) { const char* e = dlerror(); err = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return false; }
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) { err = "librccl.so lacks an expected symbol"; return false; }
+        if (!CommInitAll || !CommInitRank || !GetUniqueId || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
+            err = "librccl.so lacks an expected symbol";
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
         return true;
     }
 };
 Rccl g_rccl;
+static_assert(sizeof(ncclUniqueId) == RTX_RCCL_ID_BYTES, "rtx.h documents the size of an RCCL unique id");
 #define NCCL_TRY(expr)                                                                                          \
     do {                                                                                                        \
         ncclResult_t _r = (expr);                                                                               \
         if (_r != ncclSuccess) return fail(RTX_ERR_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
     } while (0)
+// inside an open ncclGroupStart: close the group before reporting (a group left open would swallow every later RCCL call of the thread)
+#define NCCL_TRY_IN_GROUP(expr)                                                                                 \
+    do {                                                                                                        \
+        ncclResult_t _r = (expr);                                                                               \
+        if (_r != ncclSuccess) {                                                                                \
+            (void)g_rccl.GroupEnd();                                                                            \
+            return fail(RTX_ERR_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));                    \
+        }                                                                                                       \
+    } while (0)
 
-inline int n_ranks(const rtx_context* ctx) { return 1 + static_cast<int>(ctx->peers.size()); }
+inline int n_ranks(const rtx_context* ctx) { return ctx->n_total; }
 inline rtx_context* rank_ctx(rtx_context* ctx, int r) { return r == 0 ? ctx : ctx->peers[r - 1]; }
 inline size_t target_bytes(int t) { return t == 0 ? 16 : 4; }   // target 0 = RGBA32F, 1 = RGBA8
+inline bool uses_rccl(const rtx_context* ctx) { return ctx->gather_kind != RTX_GATHER_PEER_COPY; }
 
 int rows_of_rank(const rtx_context* root, int rank)
 {
@@ -467,101 +564,120 @@ int rows_of_rank(const rtx_context* root, int rank)
 }
 
 // GLWrapper::draw on N devices (BASELINE north_star: "GLWrapper dispatch -> HIP launch + RCCL tile gather"). Every rank traces its
-// interleaved row bands into packed buffers on its own device and stream (one launch writes both colour targets); the peers' packed bands
-// travel to the root -- one ncclSend / ncclRecv pair per peer and target inside ONE group, i.e. every peer straight over its own xGMI link,
-// no ring -- and a copy kernel puts every rank's rows in their place in the root's colour targets. Sends, receives and placement run on
-// each device's transfer stream and the packed / landing buffers alternate between two sets, so the gather of frame k overlaps the trace of
-// frame k+1 on all devices. RTX_GATHER_PEER_COPY replaces the RCCL pair by hipMemcpyPeerAsync on the root's transfer stream (same data path
-// over xGMI, no library; also the only mode in which two ranks may share a device, which the tests use on single-GPU boxes).
-int multi_draw(rtx_context* root)
+// interleaved row bands into packed buffers on its own device and stream (one launch writes the colour targets that travel); the peers'
+// packed bands travel to the root -- one ncclSend / ncclRecv pair per peer and target inside ONE group, i.e. every peer straight over its
+// own xGMI link, no ring -- and a copy kernel puts every rank's rows in their place in the root's colour targets. Sends, receives and
+// placement run on each device's transfer stream and the packed / landing buffers alternate between two sets, so the gather of frame k
+// overlaps the trace of frame k+1 on all devices. RTX_GATHER_PEER_COPY replaces the RCCL pair by hipMemcpyPeerAsync on the root's transfer
+// stream (same data path over xGMI, no library; also the only mode in which two ranks may share a device, which the tests use on
+// single-GPU boxes). `me` is the root of a single-process group (the loops then run over all ranks) or the one rank this process owns
+// (rtx_create_rank: the same calls, every process issuing its own share -- sends on a peer, the receives and the placement on rank 0).
+int multi_draw(rtx_context* me)
 {
-    const int N = n_ranks(root), par = static_cast<int>(root->frame_no & 1u);
+    const int N = n_ranks(me), par = static_cast<int>(me->frame_no & 1u);
+    const bool root_here = me->rank == 0;
+    const int first_moved = me->loopback ? 0 : 1;   // first rank whose bands go through the transport
+    std::vector<rtx_context*> local;                 // the ranks this process drives
+    if (me->per_process) local.push_back(me);
+    else for (int r = 0; r < N; r++) local.push_back(rank_ctx(me, r));
     int st;
-    for (int r = 0; r < N; r++) {
-        rtx_context* c = rank_ctx(root, r);
+    for (rtx_context* c : local) {
         if ((st = use_device(c)) != RTX_OK) return st;
-        if (root->frame_no >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->moved[par], 0));   // this buffer set: its previous transfer is done
-        st = draw_impl(c, root->band_rows, r, N, static_cast<float*>(c->d_packed[0][par]), static_cast<uint32_t*>(c->d_packed[1][par]), c->stream);
+        if (me->frame_no >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->moved[par], 0));   // this buffer set: its previous transfer is done
+        st = draw_impl(c, me->band_rows, c->rank, N, (me->gather_targets & 1) ? static_cast<float*>(c->d_packed[0][par]) : nullptr,
+                       (me->gather_targets & 2) ? static_cast<uint32_t*>(c->d_packed[1][par]) : nullptr, c->stream);
         if (st) return st;
         HIP_TRY(hipEventRecord(c->traced[par], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->xfer_stream, c->traced[par], 0));
     }
-    if ((st = use_device(root)) != RTX_OK) return st;
-    HIP_TRY(hipEventRecord(root->gather_start, root->xfer_stream));
-    if (root->gather_kind == RTX_GATHER_RCCL && N > 1) {
-        NCCL_TRY(g_rccl.GroupStart());
-        for (int r = 1; r < N; r++) {
-            rtx_context* c = rank_ctx(root, r);
-            const size_t rows = static_cast<size_t>(rows_of_rank(root, r));
-            for (int t = 0; t < 2; t++) {
-                if (!((root->gather_targets >> t) & 1)) continue;
-                const size_t bytes = rows * root->width * target_bytes(t);
-                NCCL_TRY(g_rccl.Send(c->d_packed[t][par], bytes, ncclUint8, 0, c->comm, c->xfer_stream));
-                NCCL_TRY(g_rccl.Recv(root->d_stage[t][par][r], bytes, ncclUint8, r, root->comm, root->xfer_stream));
+    if (root_here) {
+        if ((st = use_device(me)) != RTX_OK) return st;
+        HIP_TRY(hipEventRecord(me->gather_start, me->xfer_stream));
+    }
+    if (uses_rccl(me)) {
+        if (N > first_moved) {
+            NCCL_TRY(g_rccl.GroupStart());
+            for (rtx_context* c : local) {
+                if (c->rank < first_moved) continue;
+                const size_t rows = static_cast<size_t>(rows_of_rank(me, c->rank));
+                for (int t = 0; t < 2; t++)
+                    if ((me->gather_targets >> t) & 1)
+                        NCCL_TRY_IN_GROUP(g_rccl.Send(c->d_packed[t][par], rows * me->width * target_bytes(t), ncclUint8, 0, c->comm, c->xfer_stream));
             }
+            if (root_here)
+                for (int r = first_moved; r < N; r++) {
+                    const size_t rows = static_cast<size_t>(rows_of_rank(me, r));
+                    for (int t = 0; t < 2; t++)
+                        if ((me->gather_targets >> t) & 1)
+                            NCCL_TRY_IN_GROUP(g_rccl.Recv(me->d_stage[t][par][r], rows * me->width * target_bytes(t), ncclUint8, r, me->comm, me->xfer_stream));
+                }
+            NCCL_TRY(g_rccl.GroupEnd());
         }
-        NCCL_TRY(g_rccl.GroupEnd());
     } else {
         for (int r = 1; r < N; r++) {
-            rtx_context* c = rank_ctx(root, r);
-            HIP_TRY(hipStreamWaitEvent(root->xfer_stream, c->traced[par], 0));
-            const size_t rows = static_cast<size_t>(rows_of_rank(root, r));
+            rtx_context* c = rank_ctx(me, r);
+            HIP_TRY(hipStreamWaitEvent(me->xfer_stream, c->traced[par], 0));
+            const size_t rows = static_cast<size_t>(rows_of_rank(me, r));
             for (int t = 0; t < 2; t++) {
-                if (!((root->gather_targets >> t) & 1)) continue;
-                HIP_TRY(hipMemcpyPeerAsync(root->d_stage[t][par][r], root->device, c->d_packed[t][par], c->device, rows * root->width * target_bytes(t), root->xfer_stream));
+                if (!((me->gather_targets >> t) & 1)) continue;
+                HIP_TRY(hipMemcpyPeerAsync(me->d_stage[t][par][r], me->device, c->d_packed[t][par], c->device, rows * me->width * target_bytes(t), me->xfer_stream));
             }
         }
     }
-    for (int r = 0; r < N; r++)
-        for (int t = 0; t < 2; t++) {
-            if (!((root->gather_targets >> t) & 1)) continue;
-            const void* src = r == 0 ? root->d_packed[t][par] : root->d_stage[t][par][r];
-            void* dst = t == 0 ? static_cast<void*>(root->d_fb_f32) : static_cast<void*>(root->d_fb_u8);
-            HIP_TRY(bands_unpack(src, dst, root->width, root->height, static_cast<int>(target_bytes(t)), root->band_rows, r, N, rows_of_rank(root, r), root->xfer_stream));
-        }
-    HIP_TRY(hipEventRecord(root->gather_stop, root->xfer_stream));
-    HIP_TRY(hipEventRecord(root->moved[par], root->xfer_stream));
-    for (int r = 1; r < N; r++) {   // a peer's buffers are free once its send (RCCL) or the root's copy (peer copy) has completed
-        rtx_context* c = rank_ctx(root, r);
-        if (root->gather_kind == RTX_GATHER_RCCL) {
+    if (root_here) {
+        for (int r = 0; r < N; r++)
+            for (int t = 0; t < 2; t++) {
+                if (!((me->gather_targets >> t) & 1)) continue;
+                const void* src = r < first_moved ? me->d_packed[t][par] : me->d_stage[t][par][r];
+                void* dst = t == 0 ? static_cast<void*>(me->d_fb_f32) : static_cast<void*>(me->d_fb_u8);
+                HIP_TRY(bands_unpack(src, dst, me->width, me->height, static_cast<int>(target_bytes(t)), me->band_rows, r, N, rows_of_rank(me, r), me->xfer_stream));
+            }
+        HIP_TRY(hipEventRecord(me->gather_stop, me->xfer_stream));
+        me->gather_timed = true;
+    }
+    for (rtx_context* c : local) {   // a rank's packed buffers are free once its send (RCCL) / the root's copy and placement have completed
+        if (c->rank == 0 || uses_rccl(me)) {
             if ((st = use_device(c)) != RTX_OK) return st;
             HIP_TRY(hipEventRecord(c->moved[par], c->xfer_stream));
         } else {
-            c->moved[par] = root->moved[par];   // (shared handle: recorded on the root's transfer stream above; owned by the root)
+            c->moved[par] = me->moved[par];   // (shared handle: recorded on the root's transfer stream above; owned by the root)
         }
     }
-    root->gather_timed = true;
-    root->frame_no++;
+    me->frame_no++;
     return RTX_OK;
 }
 
 // the assembled frame is written on the root's transfer stream: whoever reads the colour targets waits for it
 int multi_sync(rtx_context* root)
 {
-    if (root->peers.empty()) return RTX_OK;
+    if (!root->banded) return RTX_OK;
     int st = use_device(root);
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(root->xfer_stream));
     return RTX_OK;
 }
 
-int multi_alloc(rtx_context* root)
+// the packed band buffers, transfer stream and events of one rank (on its own device); `frame` supplies size, rank count and transport
+int rank_alloc(rtx_context* c, const rtx_context* frame, int rank)
+{
+    int st = use_device(c);
+    if (st) return st;
+    c->rank = rank;
+    HIP_TRY(hipStreamCreateWithFlags(&c->xfer_stream, hipStreamNonBlocking));
+    const size_t rows = static_cast<size_t>(rows_of_rank(frame, rank)) + 8;
+    for (int t = 0; t < 2; t++)
+        for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&c->d_packed[t][p], rows * frame->width * target_bytes(t)));
+    for (int p = 0; p < 2; p++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->traced[p], hipEventDisableTiming));
+        if (rank == 0 || uses_rccl(frame)) HIP_TRY(hipEventCreateWithFlags(&c->moved[p], hipEventDisableTiming));
+    }
+    return RTX_OK;
+}
+
+// rank 0 only: landing buffers for every rank whose bands travel, and the gather's timing events
+int root_alloc(rtx_context* root)
 {
     const int N = n_ranks(root);
-    for (int r = 0; r < N; r++) {
-        rtx_context* c = rank_ctx(root, r);
-        int st = use_device(c);
-        if (st) return st;
-        c->rank = r;
-        HIP_TRY(hipStreamCreateWithFlags(&c->xfer_stream, hipStreamNonBlocking));
-        const size_t rows = static_cast<size_t>(rows_of_rank(root, r)) + 8;
-        for (int t = 0; t < 2; t++)
-            for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&c->d_packed[t][p], rows * root->width * target_bytes(t)));
-        for (int p = 0; p < 2; p++) {
-            HIP_TRY(hipEventCreateWithFlags(&c->traced[p], hipEventDisableTiming));
-            if (r == 0 || root->gather_kind == RTX_GATHER_RCCL) HIP_TRY(hipEventCreateWithFlags(&c->moved[p], hipEventDisableTiming));
-        }
-    }
     int st = use_device(root);
     if (st) return st;
     HIP_TRY(hipEventCreate(&root->gather_start));
@@ -569,9 +685,20 @@ int multi_alloc(rtx_context* root)
     for (int t = 0; t < 2; t++)
         for (int p = 0; p < 2; p++) {
             root->d_stage[t][p].assign(N, nullptr);
-            for (int r = 1; r < N; r++) HIP_TRY(hipMalloc(&root->d_stage[t][p][r], (static_cast<size_t>(rows_of_rank(root, r)) + 8) * root->width * target_bytes(t)));
+            for (int r = root->loopback ? 0 : 1; r < N; r++)
+                HIP_TRY(hipMalloc(&root->d_stage[t][p][r], (static_cast<size_t>(rows_of_rank(root, r)) + 8) * root->width * target_bytes(t)));
         }
     return RTX_OK;
+}
+
+int multi_alloc(rtx_context* root)
+{
+    const int N = n_ranks(root);
+    for (int r = 0; r < N; r++) {
+        int st = rank_alloc(rank_ctx(root, r), root, r);
+        if (st) return st;
+    }
+    return root_alloc(root);
 }
 
 }  // namespace
@@ -586,6 +713,38 @@ extern "C" {
             const int _st = (call);                                   \
             if (_st != RTX_OK) return _st;                            \
         }                                                             \
+    } while (0)
+
+// Texture creation on a multi-device context must leave every rank with the SAME handle for the same texture, also when one rank fails
+// (out of memory on one device): the texture is then removed from every rank that created it and the handle counters are brought back in
+// step, so that the next creation numbers alike everywhere. (Blocks need nothing of the kind: their handles are fixed, binding slot + 1.)
+static void forget_texture(rtx_context* c, uint32_t h)
+{
+    auto it = c->textures.find(h);
+    if (it == c->textures.end()) return;
+    (void)hipSetDevice(c->device);
+    if (it->second.d_texels) (void)hipFree(it->second.d_texels);
+    c->textures.erase(it);
+}
+#define RTX_FORWARD_TEXTURE(call)                                                                       \
+    do {                                                                                                \
+        const uint32_t _h = *handle;                                                                    \
+        for (rtx_context * _p : ctx->peers) {                                                           \
+            rtx_context* ctx = _p;                                                                      \
+            uint32_t _hp = 0;                                                                           \
+            uint32_t* handle = &_hp;                                                                    \
+            int _st = (call);                                                                           \
+            if (_st == RTX_OK && _hp != _h) _st = fail(RTX_ERR_DEVICE, "texture handles out of step across the devices (%u on the root, %u on device %d)", _h, _hp, _p->device); \
+            if (_st != RTX_OK) {                                                                        \
+                const std::string _msg = g_error;                                                       \
+                rtx_context* _root = _p->owner;                                                         \
+                forget_texture(_root, _h);                                                              \
+                for (rtx_context * _q : _root->peers) { forget_texture(_q, _h); forget_texture(_q, _hp); _q->next_handle = _root->next_handle; } \
+                (void)hipSetDevice(_root->device);                                                      \
+                g_error = _msg;                                                                         \
+                return _st;                                                                             \
+            }                                                                                           \
+        }                                                                                               \
     } while (0)
 
 const char* rtx_last_error(void) { return g_error.c_str(); }
@@ -620,7 +779,6 @@ int rtx_create(int width, int height, int device, rtx_context** out)
     if ((e = hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
     for (int k = 0; k < 2; k++)
         if ((e = hipEventCreateWithFlags(&ctx->stage_done[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipEventCreateWithFlags(&ctx->launch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     for (int k = 0; k < EVENT_RING; k++) {
         if ((e = hipEventCreate(&ctx->ev_start[k])) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&ctx->ev_stop[k])) != hipSuccess) return bail(e, "hipEventCreate");
@@ -636,30 +794,39 @@ int rtx_create(int width, int height, int device, rtx_context** out)
 int rtx_create_multi(int width, int height, int n_devices, const int* device_ids, int gather, rtx_context** out)
 {
     if (!out || !device_ids || n_devices < 1 || n_devices > 64) return fail(RTX_ERR_INVALID, "rtx_create_multi: bad arguments");
-    if (gather != RTX_GATHER_RCCL && gather != RTX_GATHER_PEER_COPY) return fail(RTX_ERR_INVALID, "unknown gather kind %d", gather);
+    if (gather != RTX_GATHER_RCCL && gather != RTX_GATHER_PEER_COPY && gather != RTX_GATHER_RCCL_LOOPBACK) return fail(RTX_ERR_INVALID, "unknown gather kind %d", gather);
     *out = nullptr;
-    if (gather == RTX_GATHER_RCCL)
+    if (gather != RTX_GATHER_PEER_COPY)
         for (int a = 0; a < n_devices; a++)
             for (int b = a + 1; b < n_devices; b++)
                 if (device_ids[a] == device_ids[b]) return fail(RTX_ERR_INVALID, "device %d listed twice: RCCL needs one device per rank (RTX_GATHER_PEER_COPY allows it)", device_ids[a]);
+    int have = 0;
+    if (hipGetDeviceCount(&have) == hipSuccess)
+        for (int a = 0; a < n_devices; a++)
+            if (device_ids[a] < 0 || device_ids[a] >= have)
+                return fail(RTX_ERR_INVALID, "device %d out of range: %d device%s requested, this node has %d", device_ids[a], n_devices, n_devices == 1 ? "" : "s", have);
     rtx_context* root = nullptr;
     int st = rtx_create(width, height, device_ids[0], &root);
     if (st) return st;
     root->gather_kind = gather;
+    root->loopback = gather == RTX_GATHER_RCCL_LOOPBACK;
+    root->n_total = n_devices;
+    root->banded = n_devices > 1 || root->loopback;
     for (int r = 1; r < n_devices; r++) {
         rtx_context* peer = nullptr;
         st = rtx_create(width, height, device_ids[r], &peer);
         if (st) { rtx_destroy(root); return st; }
         peer->owner = root;
+        peer->gather_kind = gather;
         root->peers.push_back(peer);
     }
     {
         std::lock_guard<std::mutex> lk(g_mutex);
         g_current = root;   // rtx_create made the last peer current
     }
-    if (n_devices > 1) {
+    if (root->banded) {
         st = multi_alloc(root);
-        if (st == RTX_OK && gather == RTX_GATHER_RCCL) {
+        if (st == RTX_OK && uses_rccl(root)) {
             std::string err;
             if (!g_rccl.load(err)) st = fail(RTX_ERR_DEVICE, "%s", err.c_str());
             if (st == RTX_OK) {
@@ -675,10 +842,64 @@ int rtx_create_multi(int width, int height, int n_devices, const int* device_ids
     return RTX_OK;
 }
 
+int rtx_rccl_unique_id(uint8_t id[RTX_RCCL_ID_BYTES])
+{
+    if (!id) return fail(RTX_ERR_INVALID, "rtx_rccl_unique_id: null argument");
+    std::string err;
+    if (!g_rccl.load(err)) return fail(RTX_ERR_DEVICE, "%s", err.c_str());
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, &u, RTX_RCCL_ID_BYTES);
+    return RTX_OK;
+}
+
+int rtx_create_rank(int width, int height, int device, int rank, int n_ranks_, const uint8_t id[RTX_RCCL_ID_BYTES], int gather, rtx_context** out)
+{
+    if (!out || !id || n_ranks_ < 1 || n_ranks_ > 4096 || rank < 0 || rank >= n_ranks_) return fail(RTX_ERR_INVALID, "rtx_create_rank: bad arguments (rank %d of %d)", rank, n_ranks_);
+    if (gather != RTX_GATHER_RCCL && gather != RTX_GATHER_RCCL_LOOPBACK) return fail(RTX_ERR_INVALID, "rtx_create_rank: ranks in separate processes exchange their bands over RCCL (gather %d)", gather);
+    *out = nullptr;
+    rtx_context* ctx = nullptr;
+    int st = rtx_create(width, height, device, &ctx);
+    if (st) return st;
+    ctx->gather_kind = gather;
+    ctx->loopback = gather == RTX_GATHER_RCCL_LOOPBACK;
+    ctx->n_total = n_ranks_;
+    ctx->rank = rank;
+    ctx->per_process = true;
+    ctx->banded = n_ranks_ > 1 || ctx->loopback;
+    if (ctx->banded) {
+        st = rank_alloc(ctx, ctx, rank);
+        if (st == RTX_OK && rank == 0) st = root_alloc(ctx);
+        if (st == RTX_OK) {
+            std::string err;
+            if (!g_rccl.load(err)) st = fail(RTX_ERR_DEVICE, "%s", err.c_str());
+        }
+        if (st == RTX_OK) {
+            ncclUniqueId u;
+            std::memcpy(&u, id, RTX_RCCL_ID_BYTES);
+            st = use_device(ctx);
+            if (st == RTX_OK) {
+                ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, n_ranks_, u, rank);   // collective: returns once every rank has joined
+                if (r != ncclSuccess) st = fail(RTX_ERR_DEVICE, "ncclCommInitRank(rank %d of %d) failed: %s", rank, n_ranks_, g_rccl.GetErrorString(r));
+            }
+        }
+        if (st) { rtx_destroy(ctx); return st; }
+    }
+    *out = ctx;
+    return RTX_OK;
+}
+
 int rtx_device_count(rtx_context* ctx, int* n)
 {
     if (!ctx || !n) return fail(RTX_ERR_INVALID, "null argument");
     *n = n_ranks(ctx);
+    return RTX_OK;
+}
+
+int rtx_rank(rtx_context* ctx, int* rank)
+{
+    if (!ctx || !rank) return fail(RTX_ERR_INVALID, "null argument");
+    *rank = ctx->rank;
     return RTX_OK;
 }
 
@@ -693,7 +914,7 @@ void rtx_destroy(rtx_context* ctx)
     if (ctx->xfer_stream) (void)hipStreamSynchronize(ctx->xfer_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (rtx_context* p : ctx->peers) {
-        if (ctx->gather_kind != RTX_GATHER_RCCL) p->moved[0] = p->moved[1] = nullptr;   // shared with the root's events in peer-copy mode
+        if (!uses_rccl(ctx)) p->moved[0] = p->moved[1] = nullptr;   // shared with the root's events in peer-copy mode
         rtx_destroy(p);
     }
     ctx->peers.clear();
@@ -722,7 +943,7 @@ void rtx_destroy(rtx_context* ctx)
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
     }
-    if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
+    for (auto& ld : ctx->launch_done) (void)hipEventDestroy(ld.second);
     if (ctx->d_fb_f32) (void)hipFree(ctx->d_fb_f32);
     if (ctx->d_fb_u8) (void)hipFree(ctx->d_fb_u8);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -828,7 +1049,7 @@ int rtx_texture2d_create(rtx_context* ctx, int width, int height, int channels, 
     const uint32_t h = ctx->next_handle++;
     ctx->textures[h] = t;
     *handle = h;
-    RTX_FORWARD(rtx_texture2d_create(ctx, width, height, channels, texels, wrap, handle));
+    RTX_FORWARD_TEXTURE(rtx_texture2d_create(ctx, width, height, channels, texels, wrap, handle));
     return RTX_OK;
 }
 
@@ -856,7 +1077,7 @@ int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint
     const uint32_t h = ctx->next_handle++;
     ctx->textures[h] = t;
     *handle = h;
-    RTX_FORWARD(rtx_cubemap_create(ctx, face_size, channels, faces, 0, handle));
+    RTX_FORWARD_TEXTURE(rtx_cubemap_create(ctx, face_size, channels, faces, 0, handle));
     return RTX_OK;
 }
 
@@ -944,10 +1165,10 @@ int rtx_draw(rtx_context* ctx)
     if (!ctx) return fail(RTX_ERR_INVALID, "null context");
     if (ctx->owner) return fail(RTX_ERR_INVALID, "rtx_draw on a peer of a multi-device context: draw through the root");
     int st;
-    if (!ctx->peers.empty()) {
+    if (ctx->banded) {
         if (ctx->smaa_preset >= 0 && !(ctx->gather_targets & 2)) return fail(RTX_ERR_ORDER, "SMAA needs the RGBA8 target on the root: RTX_OPT_GATHER_TARGETS must include 2");
         st = multi_draw(ctx);
-        if (st == RTX_OK && ctx->smaa_preset >= 0) {   // the post-process runs on the root once the frame is assembled
+        if (st == RTX_OK && ctx->smaa_preset >= 0 && ctx->rank == 0) {   // the post-process runs on the root once the frame is assembled
             st = use_device(ctx);
             if (st == RTX_OK) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->moved[(ctx->frame_no - 1u) & 1u], 0));
             if (st == RTX_OK) st = smaa_resolve(ctx, ctx->stream);
@@ -967,14 +1188,17 @@ int rtx_smaa_set_tables(rtx_context* ctx, const uint8_t* area_rg8, int area_w, i
     if (area_w != 160 || area_h != 560 || search_w != 64 || search_h != 16)
         return fail(RTX_ERR_INVALID, "SMAA tables must be 160x560 (RG8) and 64x16 (R8), the sizes SMAA.h addresses (SMAA.h:519-522); got %dx%d and %dx%d",
                     area_w, area_h, search_w, search_h);
-    int st = use_device(ctx);
-    if (st) return st;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (!ctx->d_area) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_area), 160 * 560 * 2));
-    if (!ctx->d_search) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_search), 64 * 16));
-    HIP_TRY(hipMemcpy(ctx->d_area, area_rg8, 160 * 560 * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_search, search_r8, 64 * 16, hipMemcpyHostToDevice));
-    ctx->smaa_tables = true;
+    return upload_smaa_tables(ctx, area_rg8, search_r8);
+}
+
+int rtx_smaa_default_tables(uint8_t* area_rg8, size_t area_bytes, uint8_t* search_r8, size_t search_bytes)
+{
+    if ((area_rg8 && area_bytes < static_cast<size_t>(rtx_smaa::AREA_BYTES)) || (search_r8 && search_bytes < static_cast<size_t>(rtx_smaa::SEARCH_BYTES)))
+        return fail(RTX_ERR_INVALID, "rtx_smaa_default_tables: the area table is %d bytes (160 x 560 RG8), the search table %d (64 x 16 R8)", rtx_smaa::AREA_BYTES, rtx_smaa::SEARCH_BYTES);
+    const uint8_t *a = nullptr, *s = nullptr;
+    default_smaa_tables(&a, &s);
+    if (area_rg8) std::memcpy(area_rg8, a, rtx_smaa::AREA_BYTES);
+    if (search_r8) std::memcpy(search_r8, s, rtx_smaa::SEARCH_BYTES);
     return RTX_OK;
 }
 
@@ -982,6 +1206,7 @@ int rtx_enable_smaa(rtx_context* ctx, int preset)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "null context");
     if (preset < -1 || preset > RTX_SMAA_ULTRA) return fail(RTX_ERR_INVALID, "unknown SMAA preset %d", preset);
+    if (preset < 0 || ctx->smaa_preset < 0) ctx->screen_valid = false;   // (re-)enabled: the screen is the colour target until a resolve has run
     ctx->smaa_preset = preset;
     if (preset >= 0) {
         int st = use_device(ctx);
@@ -1007,8 +1232,10 @@ int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host, size_t 
     if (format != RTX_RGBA8) return fail(RTX_ERR_INVALID, "rtx_write_pixels: only the RGBA8 colour target can be written");
     const size_t need = static_cast<size_t>(ctx->width) * ctx->height * 4;
     if (src_bytes < need) return fail(RTX_ERR_INVALID, "source holds %zu bytes, %zu needed", src_bytes, need);
+    if (ctx->banded && ctx->rank != 0) return fail(RTX_ERR_ORDER, "the colour target lives on rank 0");
     int st = use_device(ctx);
     if (st) return st;
+    if ((st = multi_sync(ctx)) != RTX_OK) return st;   // a multi-device root: the transfer stream may still be placing bands in this target
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(ctx->d_fb_u8, src_host, need, hipMemcpyHostToDevice));
     return RTX_OK;
@@ -1017,7 +1244,7 @@ int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host, size_t 
 int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride, void* dst_device, int format, void* stream)
 {
     if (!ctx || !dst_device) return fail(RTX_ERR_INVALID, "rtx_draw_bands: null argument");
-    if (!ctx->peers.empty()) return fail(RTX_ERR_INVALID, "rtx_draw_bands on a multi-device context: it splits the frame itself (rtx_draw)");
+    if (ctx->banded) return fail(RTX_ERR_INVALID, "rtx_draw_bands on a multi-device context: it splits the frame itself (rtx_draw)");
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     if (format == RTX_RGBA32F) return draw_impl(ctx, band_rows, band_first, band_stride, static_cast<float*>(dst_device), nullptr, s);
     if (format == RTX_RGBA8) return draw_impl(ctx, band_rows, band_first, band_stride, nullptr, static_cast<uint32_t*>(dst_device), s);
@@ -1035,7 +1262,31 @@ int rtx_finish(rtx_context* ctx)
         HIP_TRY(hipStreamSynchronize(p->stream));
         HIP_TRY(hipStreamSynchronize(p->xfer_stream));
     }
-    return multi_sync(ctx);
+    return multi_sync(ctx);   // the root's (or this process' rank's) transfer stream
+}
+
+// which buffer a colour-target format names right now (nullptr + message on failure); shared by rtx_read_pixels / rtx_framebuffer_device
+static int resolve_format(rtx_context* ctx, int format, const void** src, size_t* bytes)
+{
+    const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
+    if (ctx->banded && ctx->rank != 0) return fail(RTX_ERR_ORDER, "the frame is assembled on rank 0: rank %d holds only its own bands", ctx->rank);
+    // the screen is the SMAA output once a resolve has run, else what the colour target holds (GLWrapper.cpp:195-204 vs :159-165)
+    const bool screen_is_smaa = ctx->smaa_preset >= 0 && ctx->d_screen && ctx->screen_valid;
+    switch (format) {
+        case RTX_RGBA32F: *src = ctx->d_fb_f32; *bytes = px * 16; break;
+        case RTX_RGBA8: *src = ctx->d_fb_u8; *bytes = px * 4; break;
+        case RTX_SCREEN_RGBA8: *src = screen_is_smaa ? ctx->d_screen : ctx->d_fb_u8; *bytes = px * 4; break;
+        case RTX_SMAA_EDGES_RG8: *src = ctx->d_edges; *bytes = px * 2; break;
+        case RTX_SMAA_WEIGHTS_RGBA8: *src = ctx->d_blend; *bytes = px * 4; break;
+        default: return fail(RTX_ERR_INVALID, "unknown format %d", format);
+    }
+    if (!*src) return fail(RTX_ERR_ORDER, "format %d needs SMAA to be enabled (rtx_enable_smaa)", format);
+    if (ctx->banded) {
+        const bool needs_f32 = format == RTX_RGBA32F, needs_u8 = format == RTX_RGBA8 || (format == RTX_SCREEN_RGBA8 && !screen_is_smaa);
+        if ((needs_f32 && !(ctx->gather_targets & 1)) || (needs_u8 && !(ctx->gather_targets & 2)))
+            return fail(RTX_ERR_ORDER, "this colour target is not gathered (RTX_OPT_GATHER_TARGETS)");
+    }
+    return RTX_OK;
 }
 
 int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_bytes)
@@ -1043,21 +1294,10 @@ int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_byt
     if (!ctx || !dst_host) return fail(RTX_ERR_INVALID, "rtx_read_pixels: null argument");
     int st = use_device(ctx);
     if (st) return st;
-    const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
     const void* src = nullptr;
     size_t need = 0;
-    switch (format) {
-        case RTX_RGBA32F: src = ctx->d_fb_f32; need = px * 16; break;
-        case RTX_RGBA8: src = ctx->d_fb_u8; need = px * 4; break;
-        case RTX_SCREEN_RGBA8: src = (ctx->smaa_preset >= 0 && ctx->d_screen) ? ctx->d_screen : ctx->d_fb_u8; need = px * 4; break;
-        case RTX_SMAA_EDGES_RG8: src = ctx->d_edges; need = px * 2; break;
-        case RTX_SMAA_WEIGHTS_RGBA8: src = ctx->d_blend; need = px * 4; break;
-        default: return fail(RTX_ERR_INVALID, "unknown format %d", format);
-    }
-    if (!src) return fail(RTX_ERR_ORDER, "format %d needs SMAA to be enabled (rtx_enable_smaa)", format);
+    if ((st = resolve_format(ctx, format, &src, &need)) != RTX_OK) return st;
     if (dst_bytes < need) return fail(RTX_ERR_INVALID, "destination holds %zu bytes, %zu needed", dst_bytes, need);
-    if ((format == RTX_RGBA32F && !(ctx->gather_targets & 1)) || (format == RTX_RGBA8 && !(ctx->gather_targets & 2)))
-        if (!ctx->peers.empty()) return fail(RTX_ERR_ORDER, "this colour target is not gathered (RTX_OPT_GATHER_TARGETS)");
     if ((st = multi_sync(ctx)) != RTX_OK) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(dst_host, src, need, hipMemcpyDeviceToHost));
@@ -1067,10 +1307,12 @@ int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_byt
 int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr)
 {
     if (!ctx || !device_ptr) return fail(RTX_ERR_INVALID, "null argument");
-    if (format == RTX_RGBA32F) *device_ptr = ctx->d_fb_f32;
-    else if (format == RTX_RGBA8) *device_ptr = ctx->d_fb_u8;
-    else if (format == RTX_SCREEN_RGBA8) *device_ptr = (ctx->smaa_preset >= 0 && ctx->d_screen) ? ctx->d_screen : ctx->d_fb_u8;
-    else return fail(RTX_ERR_INVALID, "unknown format %d", format);
+    if (format != RTX_RGBA32F && format != RTX_RGBA8 && format != RTX_SCREEN_RGBA8) return fail(RTX_ERR_INVALID, "unknown format %d", format);
+    const void* src = nullptr;
+    size_t bytes = 0;
+    const int st = resolve_format(ctx, format, &src, &bytes);
+    if (st) return st;
+    *device_ptr = const_cast<void*>(src);
     return RTX_OK;
 }
 
@@ -1129,9 +1371,9 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
 // Extra diagnostics (not part of the reference surface) ---------------------------------------
 // Sum of the HIP-event durations of the `n` most recent draws (n <= 128), for benches that time
 // K draws back to back. Returns RTX_ERR_INVALID if fewer than n draws are pending.
-RTX_API int rtx_sum_recent_draw_ms(rtx_context* ctx, int n, float* sum_ms)
+static int sum_recent_one(rtx_context* ctx, int n, float* sum_ms)
 {
-    if (!ctx || !sum_ms || n <= 0 || n > ctx->ev_pending) return fail(RTX_ERR_INVALID, "rtx_sum_recent_draw_ms: %d draws requested, %d pending", n, ctx ? ctx->ev_pending : 0);
+    if (n > ctx->ev_pending) return fail(RTX_ERR_INVALID, "rtx_sum_recent_draw_ms: %d draws requested, %d pending", n, ctx->ev_pending);
     int st = use_device(ctx);
     if (st) return st;
     float total = 0.0f;
@@ -1146,6 +1388,20 @@ RTX_API int rtx_sum_recent_draw_ms(rtx_context* ctx, int n, float* sum_ms)
     ctx->ev_pending = 0;
     *sum_ms = total;
     return RTX_OK;
+}
+
+// A multi-device context reports the slowest rank's sum (the ranks trace concurrently: that is the frame's trace time).
+RTX_API int rtx_sum_recent_draw_ms(rtx_context* ctx, int n, float* sum_ms)
+{
+    if (!ctx || !sum_ms || n <= 0) return fail(RTX_ERR_INVALID, "rtx_sum_recent_draw_ms: bad arguments");
+    int st = sum_recent_one(ctx, n, sum_ms);
+    if (st) return st;
+    for (rtx_context* p : ctx->peers) {
+        float v = 0.0f;
+        if ((st = sum_recent_one(p, n, &v)) != RTX_OK) return st;
+        if (v > *sum_ms) *sum_ms = v;
+    }
+    return use_device(ctx);
 }
 
 // Runs the device-side exhaustive check of the divide-free byte->float conversion.

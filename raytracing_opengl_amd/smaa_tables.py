@@ -1,16 +1,16 @@
-"""Look-up tables for SMAA tests and benches that do not need the reference checkout (the counterpart of textures.py for SMAA).
+"""The two SMAA look-up tables for tests, smoke and bench (the counterpart of textures.py for SMAA).
 
-The reference uploads two third-party byte tables (src/AreaTex.h 160x560 RG8, src/SearchTex.h 64x16 R8; SMAA_Builder.h:52-83).
-They are inputs of the boundary (rtx_smaa_set_tables), not part of this repository. The three passes are right or wrong
-independently of what the tables hold, so parity tests use the tables built here:
+The reference uploads two third-party byte tables (src/AreaTex.h 160x560 RG8, src/SearchTex.h 64x16 R8; SMAA_Builder.h:52-83). This
+repository stores neither; both are computed from their published construction by include/rtx/smaa_tables.h inside librtx_hip.so
+(rtx_smaa_default_tables -- host code, needs no GPU), and tests/test_smaa_tables.py pins the result: byte-identical to the reference's
+arrays where /root/reference exists, sha256 everywhere.
 
-  search_table()  -- the SMAA search table computed from its published definition (Jimenez et al. 2012, section 3.2 + the
-                     pseudo-gather trick): for a bilinear fetch of four edges at offset (-0.25, -0.125) it says how many of the
-                     last two pixels (0, 1, 2 -> bytes 0, 127, 254) still belong to the line. In the build container
-                     the build-container test of the SMAA pin checks that this equals the reference's searchTexBytes byte for byte.
-  area_table()    -- a SYNTHETIC area table of the right shape: unsmoothed analytic trapezoid areas for the orthogonal
-                     patterns and a smooth made-up function for the diagonal ones. Not the reference's values (those include
-                     smoothing and sampled diagonal coverage) -- good enough to drive every code path with plausible weights.
+  area_table()            -- (560, 160, 2) uint8, == areaTexBytes. What rtx_enable_smaa uses when the caller supplies nothing.
+  search_table()          -- (16, 64) uint8, == searchTexBytes; computed HERE in Python from the same definition, independently of the
+                             C++ generator (the two are compared in the test).
+  synthetic_area_table()  -- an area table of the right shape with made-up contents (unsmoothed trapezoids, a smooth invented function for
+                             the diagonals): the three passes are right or wrong independently of what the tables hold, and parity tests
+                             also run with this one so that they do not depend on the real table's many zero entries.
 """
 from __future__ import annotations
 
@@ -58,7 +58,27 @@ def search_table() -> np.ndarray:
     return np.ascontiguousarray(img[::-1])   # ... and flip vertically
 
 
-def area_table(seed: int = 7) -> np.ndarray:
+def area_table() -> np.ndarray:
+    """(560, 160, 2) uint8: the library's generated table (== the reference's areaTexBytes)."""
+    from . import _capi
+    out = np.zeros((560, 160, 2), np.uint8)
+    st = _capi.load().rtx_smaa_default_tables(out.ctypes.data, out.nbytes, None, 0)
+    if st != _capi.RTX_OK:
+        raise RuntimeError("rtx_smaa_default_tables failed")
+    return out
+
+
+def library_search_table() -> np.ndarray:
+    """(16, 64) uint8: the C++ generator's search table (compared with search_table() in tests/test_smaa_tables.py)."""
+    from . import _capi
+    out = np.zeros((16, 64), np.uint8)
+    st = _capi.load().rtx_smaa_default_tables(None, 0, out.ctypes.data, out.nbytes)
+    if st != _capi.RTX_OK:
+        raise RuntimeError("rtx_smaa_default_tables failed")
+    return out
+
+
+def synthetic_area_table(seed: int = 7) -> np.ndarray:
     """(560, 160, 2) uint8, synthetic (see the module docstring)."""
     t = np.zeros((560, 160, 2), np.float64)
     # orthogonal half: 5 x 5 blocks of 16 x 16 (block index = round(4 e), values 0,1,3,4; 2 never occurs); texel i <-> distance i^2

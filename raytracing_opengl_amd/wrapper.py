@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from ._capi import (RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL, RTX_OPT_GATHER_TARGETS, RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_RAY_PENCILS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
+from ._capi import (RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL, RTX_GATHER_RCCL_LOOPBACK, RTX_OPT_GATHER_TARGETS, RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_RAY_PENCILS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
                     RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_HIGH, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_OFF, RTX_SMAA_ULTRA, RTX_SMAA_WEIGHTS_RGBA8,
                     RTX_WRAP_CLAMP_TO_EDGE, RTX_WRAP_REPEAT)
 
@@ -31,13 +31,17 @@ def _check(status: int, what: str):
 class GLWrapper:
     """GLWrapper(width, height, fullScreen) -- reference src/GLWrapper.cpp:12-18."""
 
-    def __init__(self, width: int, height: int, fullScreen: bool = False, device: int = 0, devices=None, gather: int = _capi.RTX_GATHER_RCCL):
+    def __init__(self, width: int, height: int, fullScreen: bool = False, device: int = 0, devices=None, gather: int = _capi.RTX_GATHER_RCCL,
+                 rank=None):
         """devices: list of HIP device ids -> a multi-device context (rtx_create_multi): the frame is split into interleaved row bands over
-        them and assembled on devices[0]; gather: RTX_GATHER_RCCL or RTX_GATHER_PEER_COPY. Default: the single device `device`."""
+        them and assembled on devices[0]; gather: RTX_GATHER_RCCL, RTX_GATHER_PEER_COPY or RTX_GATHER_RCCL_LOOPBACK.
+        rank: (rank, n_ranks, unique_id bytes) -> ONE rank of a frame split over n_ranks processes, on `device` (rtx_create_rank; the id
+        comes from rccl_unique_id() on rank 0, handed round by the launcher). Default: the single device `device`."""
         self.width, self.height = int(width), int(height)
         self.device = int(device)
         self.devices = None if devices is None else [int(d) for d in devices]
         self.gather = int(gather)
+        self.rank_spec = rank
         self._ctx = None
         self._lib = _capi.load()
         self.window = None  # no GLFW window: presentation is outside the replaced path
@@ -46,7 +50,12 @@ class GLWrapper:
     def init_window(self) -> bool:
         """Creates the device context + colour target; False on failure (GLWrapper.cpp:61-133)."""
         ctx = ctypes.c_void_p()
-        if self.devices is not None:
+        if self.rank_spec is not None:
+            rank, n_ranks, uid = self.rank_spec
+            assert len(uid) == _capi.RTX_RCCL_ID_BYTES
+            buf = ctypes.create_string_buffer(bytes(uid), _capi.RTX_RCCL_ID_BYTES)
+            status = self._lib.rtx_create_rank(self.width, self.height, self.device, int(rank), int(n_ranks), buf, self.gather, ctypes.byref(ctx))
+        elif self.devices is not None:
             ids = (ctypes.c_int * len(self.devices))(*self.devices)
             status = self._lib.rtx_create_multi(self.width, self.height, len(self.devices), ids, self.gather, ctypes.byref(ctx))
         else:
@@ -223,11 +232,18 @@ class SceneUploader:
             self.wrapper.update_buffer(ubo, data)
 
 
+def rccl_unique_id() -> bytes:
+    """rtx_rccl_unique_id: the 128 bytes rank 0 creates and every process of a per-process frame split passes to GLWrapper(rank=...)."""
+    buf = ctypes.create_string_buffer(_capi.RTX_RCCL_ID_BYTES)
+    _check(_capi.load().rtx_rccl_unique_id(buf), "rccl_unique_id")
+    return buf.raw
+
+
 def make_renderer(scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, device: int = 0, texture_lod: int = 1, devices=None,
-                  gather: int = _capi.RTX_GATHER_RCCL) -> GLWrapper:
+                  gather: int = _capi.RTX_GATHER_RCCL, rank=None) -> GLWrapper:
     """The start-up sequence of reference main.cpp:25-157 for a prepared scene: context, specialise,
     skybox, textures, blocks."""
-    gl = GLWrapper(fb_width, fb_height, False, device=device, devices=devices, gather=gather)
+    gl = GLWrapper(fb_width, fb_height, False, device=device, devices=devices, gather=gather, rank=rank)
     if not gl.init_window():
         raise RtxError(f"init_window failed: {getattr(gl, 'last_error', '')}")
     gl.init_shaders(scene_blocks.defines)

@@ -12,6 +12,8 @@ different bytes, and each is recognisable per pixel:
          (b) after SMAA_MAX_SEARCH_STEPS steps `texcoord > end` (SMAA.h:1029,1057...) compares two numbers that are equal in
              exact arithmetic: one more search step or not;
      both are reproduced by oracle.smaa.blend_pass_jitter (positions displaced by +-1e-5 / +-1e-3 texels, each search end by +-1e-3);
+     a phantom pixel that no uniform displacement reproduces must EQUAL what oracle.smaa.blend_pass_forced computes for it -- exact
+     positions, the branch taken although the pixel has no edge of its own -- it is not excused unseen;
  pass 3  `max(a.x, a.z) > max(a.y, a.w)` (SMAA.h:1279) on EQUAL bytes -- common for diagonals -- is decided by the noise.
 Everything else must agree to 1 LSB (bilinear weight rounding)."""
 from __future__ import annotations
@@ -46,8 +48,18 @@ def classify_blend(ref_edges, ref_blend, preset, area, search):
     phantom_n = own_g0 & (ref[..., 0:2] != 0).any(-1)
     phantom_w = own_r0 & (ref[..., 2:4] != 0).any(-1)
     left = [(bad[0] & ~expl[0]), (bad[1] & ~expl[1])]
-    phantom = (left[0] | left[1]) & (phantom_n | phantom_w)
-    unexplained = (left[0] | left[1]) & ~(phantom_n | phantom_w)
+    # a phantom pixel is not excused, its VALUE is demanded: what the weight computation yields at exact positions when the branch is
+    # taken although the pixel has no edge of its own (the searches, area look-ups and corner rounding see the real edge texture)
+    forced = [np.zeros_like(bad[0]), np.zeros_like(bad[0])]
+    if ((left[0] | left[1]) & (phantom_n | phantom_w)).any():
+        for force in (1, 2, 3):
+            for lo, hi in itertools.product(SLACKS, repeat=2):
+                bf = smaa.blend_pass_forced(ref_edges, preset, area, search, force, lo, hi).astype(np.int16)
+                for k, p in enumerate(pairs):
+                    forced[k] |= (np.abs(ref[..., p] - bf[..., p]) <= 1).all(-1)
+    left = [left[0] & ~forced[0], left[1] & ~forced[1]]
+    phantom = ((bad[0] & ~expl[0] & forced[0]) | (bad[1] & ~expl[1] & forced[1])) & (phantom_n | phantom_w)
+    unexplained = left[0] | left[1]
     return dict(differing=int((bad[0] | bad[1]).sum()), explained_by_noise=int(((bad[0] & expl[0]) | (bad[1] & expl[1])).sum()),
                 phantom=int(phantom.sum()), unexplained=int(unexplained.sum()), where=np.argwhere(unexplained)[:8].tolist())
 

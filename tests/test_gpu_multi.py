@@ -103,3 +103,94 @@ def test_rccl_group_reproduces_the_single_device_frame(small_textures, ranks):
     group.stop()
     for (f32, u8, _), (g32, g8, _g) in zip(want, got):
         assert np.array_equal(f32.view(np.uint32), g32.view(np.uint32)) and np.array_equal(u8, g8)
+
+
+# ---- the RCCL transport on a single-GPU box: loopback (rank 0 sends its own bands to itself) -------------------------------------------
+def test_rccl_loopback_runs_the_transport_on_one_device(small_textures):
+    """RTX_GATHER_RCCL_LOOPBACK with one device: librccl is loaded, a communicator created, and every frame's bands go through a grouped
+    ncclSend/ncclRecv pair and the placement kernel on the transfer stream -- the code of the N-device gather, executed."""
+    w, h, depth = 640, 360, 4
+    seq = [None, scenes.build_scene("default", w, h, depth, time=2.0, delta=0.1, yaw=10.0), None, None]
+    sc0 = scenes.build_scene("default", w, h, depth)
+    single = wrapper.make_renderer(sc0, w, h, small_textures["textures"], small_textures["cubemap"])
+    single.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    want = _frames(single, seq)
+    single.stop()
+    group = wrapper.make_renderer(sc0, w, h, small_textures["textures"], small_textures["cubemap"], devices=[0], gather=wrapper.RTX_GATHER_RCCL_LOOPBACK)
+    group.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    got = _frames(group, seq)
+    for k, ((f32, u8, st), (g32, g8, gst)) in enumerate(zip(want, got)):
+        assert np.array_equal(f32.view(np.uint32), g32.view(np.uint32)), k
+        assert np.array_equal(u8, g8), k
+        assert (st["rays_closest"], st["rays_shadow"]) == (gst["rays_closest"], gst["rays_shadow"]), k
+        assert gst["last_gather_ms"] > 0.0
+    # only one target travels when asked so, and the other is then refused
+    group.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 2)
+    group.draw()
+    assert np.array_equal(group.read_pixels(wrapper.RTX_RGBA8), want[-1][1])
+    with pytest.raises(wrapper.RtxError, match="not gathered"):
+        group.read_pixels(wrapper.RTX_RGBA32F)
+    group.stop()
+
+
+def test_rank_context_of_a_one_process_per_gpu_split(small_textures):
+    """rtx_create_rank (what bench.py uses under torch.distributed.run): rank 0 of 1 with the loopback transport -- unique id,
+    ncclCommInitRank, send/recv, placement, SMAA on the assembled frame -- against the plain context."""
+    w, h, depth = 480, 272, 4
+    sc = scenes.build_scene("default", w, h, depth)
+    tables = smaa_tables.area_table(), smaa_tables.search_table()
+    single = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    single.enable_SMAA("ULTRA")
+    single.set_smaa_tables(*tables)
+    single.draw()
+    want32, want8, want_screen = single.read_pixels(wrapper.RTX_RGBA32F), single.read_pixels(wrapper.RTX_RGBA8), single.read_pixels(wrapper.RTX_SCREEN_RGBA8)
+    single.stop()
+    uid = wrapper.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    r0 = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"], gather=wrapper.RTX_GATHER_RCCL_LOOPBACK, rank=(0, 1, uid))
+    r0.enable_SMAA("ULTRA")
+    r0.set_smaa_tables(*tables)
+    for _ in range(3):
+        r0.draw()
+    assert np.array_equal(r0.read_pixels(wrapper.RTX_RGBA32F).view(np.uint32), want32.view(np.uint32))
+    assert np.array_equal(r0.read_pixels(wrapper.RTX_RGBA8), want8)
+    assert np.array_equal(r0.read_pixels(wrapper.RTX_SCREEN_RGBA8), want_screen)
+    r0.stop()
+    # a plain rank (1 of 1, no loopback) is a plain context; bad arguments are refused before any communicator is built
+    p = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"], rank=(0, 1, uid))
+    p.draw()
+    assert np.array_equal(p.read_pixels(wrapper.RTX_RGBA32F).view(np.uint32), want32.view(np.uint32))
+    p.stop()
+    gl = wrapper.GLWrapper(w, h, rank=(2, 2, uid))
+    assert not gl.init_window() and "bad arguments" in gl.last_error
+    gl = wrapper.GLWrapper(w, h, rank=(0, 1, uid), gather=wrapper.RTX_GATHER_PEER_COPY)
+    assert not gl.init_window() and "RCCL" in gl.last_error
+
+
+def _run_bench(extra, torchrun=False, timeout=600):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533"] if torchrun else [sys.executable]
+    cmd = head + [os.path.join(root, "bench.py"), "--width", "640", "--height", "360", "--steps", "4", "--warmup", "2", "--texture-scale", "16", "--no-cpu-baseline", "--no-smaa"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_multi_gpu_forms_run_through_the_c_boundary():
+    """bench.py's N > 1 code on one GPU: the single-process form (rtx_create_multi) and the torch.distributed.run form (rtx_create_rank),
+    both with the loopback transport; and --gpus 2 on a box without a second GPU is one clear line, exit code 2."""
+    r, line = _run_bench(["--gpus", "1", "--transport", "loopback"])
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    assert line["n_gpus"] == 1 and line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical"
+    assert "rtx_create_multi" in line["config"]["parallelism"] and line["config"]["gather_ms"] > 0 and line["config"]["trace_ms_max_rank"] > 0
+    r, line = _run_bench(["--gpus", "1", "--transport", "loopback"], torchrun=True)
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    assert "rtx_create_rank" in line["config"]["parallelism"] and line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical"
+    if _n_devices() < 2:
+        r, line = _run_bench(["--gpus", "2"])
+        assert r.returncode == 2 and line is None
+        err = [l for l in r.stderr.splitlines() if l.strip() and "amdgpu.ids" not in l]
+        assert len(err) == 1 and "--gpus 2 requested but this box has 1 GPU" in err[0], r.stderr
+    r, line = _run_bench(["--gpus", "1"])
+    assert r.returncode == 0 and line["n_gpus"] == 1 and line["config"]["parallelism"] == "single GPU"

@@ -110,6 +110,18 @@ def test_full_size_frame(built, tables):
     _same(got, smaa.run(img, "ULTRA", *tables))
 
 
+def test_caller_supplied_tables_replace_the_librarys(built, tables):
+    """rtx_smaa_set_tables with other bytes (a synthetic area table): the passes follow whatever table they are given."""
+    synth = smaa_tables.synthetic_area_table()
+    img = smaa_cases.pattern(8, 200, 120)
+    gl = _ctx(200, 120, "ULTRA", (synth, tables[1]))
+    got = _resolve(gl, img)
+    gl.stop()
+    want = smaa.run(img, "ULTRA", synth, tables[1])
+    _same(got, want)
+    assert not np.array_equal(want["blend"], smaa.run(img, "ULTRA", *tables)["blend"])
+
+
 def test_error_behaviour(built, tables):
     gl = wrapper.GLWrapper(64, 48)
     assert gl.init_window()
@@ -118,8 +130,14 @@ def test_error_behaviour(built, tables):
     with pytest.raises(wrapper.RtxError, match="needs SMAA"):
         gl.read_pixels(wrapper.RTX_SMAA_EDGES_RG8)
     gl.enable_SMAA("HIGH")
-    with pytest.raises(wrapper.RtxError, match="tables"):
-        gl.smaa_resolve()
+    # a screen read before any resolve is the colour target (never the uninitialised SMAA buffer) ...
+    img0 = smaa_cases.pattern(6, 64, 48)
+    gl.write_pixels(img0)
+    assert np.array_equal(gl.read_pixels(wrapper.RTX_SCREEN_RGBA8), img0)
+    # ... and a resolve without caller-supplied tables uses the library's own (== the reference's arrays): enable_SMAA alone is enough,
+    # as in the reference's main.cpp:32
+    gl.smaa_resolve()
+    assert np.array_equal(gl.read_pixels(wrapper.RTX_SCREEN_RGBA8), smaa.run(img0, "HIGH", *tables)["screen"])
     with pytest.raises(wrapper.RtxError, match="160x560"):
         gl.set_smaa_tables(np.zeros((80, 160, 2), np.uint8), tables[1])
     with pytest.raises(wrapper.RtxError, match="preset"):

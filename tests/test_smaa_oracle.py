@@ -41,14 +41,14 @@ def test_every_difference_from_the_reference_shaders_is_accounted_for(built, tab
     b = smaa_classify.classify_blend(fx["edges"], fx["blend"], preset, area, search)
     assert b["unexplained"] == 0, b
     n_edge = int((fx["edges"] != 0).any(-1).sum())
-    assert b["differing"] <= 0.5 * n_edge, b             # the noise-decided pixels are a minority even among edge pixels
+    assert b["differing"] <= 0.3 * n_edge, b             # the noise-decided pixels are a minority even among edge pixels (measured: <= 28 %)
     n = smaa_classify.classify_neighborhood(color, fx["blend"], fx["screen"])
     assert n["unexplained"] == 0, n
     # end to end (oracle's own intermediates): the final screens agree except around those pixels
     ours = smaa.run(color, preset, area, search)
     d = np.abs(ours["screen"].astype(np.int16) - fx["screen"].astype(np.int16)).max(-1)
     assert (d > 1).sum() <= 3 * (b["differing"] + n["differing"] + e["differing"]) + 8, int((d > 1).sum())
-    assert (d > 1).mean() < 0.02
+    assert (d > 1).sum() <= 0.3 * n_edge                 # ... and so are the screen pixels they reach (<= 24 % of the edge pixels)
 
 
 def test_search_table_equals_the_reference_table_and_live_run_with_the_real_tables(built):
@@ -61,7 +61,7 @@ def test_search_table_equals_the_reference_table_and_live_run_with_the_real_tabl
     os.environ.setdefault("GALLIVM_PERF", "no_aos_sampling,no_quad_lod")
     area, search = ref_smaa.reference_luts()
     assert np.array_equal(smaa_tables.search_table(), search)
-    assert area.shape == smaa.AREA_SHAPE
+    assert np.array_equal(smaa_tables.area_table(), area)     # the library's generated area table IS the reference's (tests/test_smaa_tables.py)
     color = smaa_cases.pattern(11, 240, 150)
     for preset in ("ULTRA", "MEDIUM"):
         r = ref_smaa.run(color, preset, area, search)
