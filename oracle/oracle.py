@@ -131,10 +131,59 @@ class OracleScene:
         self.frame = fr
         self.width, self.height = fb_width, fb_height
 
-    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0, jitter=(0.0, 0.0), tags=None):
+    def mip_levels(self, uniform: str) -> list:
+        """The RGBA8 mip levels >= 1 of the texture bound to sampler `uniform` as the oracle builds them ((h, w, 4) uint8 each)."""
+        t = self.frame.tex[TEX_SLOTS.index(uniform)]
+        l = lib()
+        l.orc_kat_mip_level.restype = ctypes.c_int
+        l.orc_kat_mip_level.argtypes = [ctypes.POINTER(Texture), ctypes.c_int, ctypes.c_void_p]
+        out, L = [], 1
+        while True:
+            buf = np.empty(t.width * t.height * 4, np.uint8)
+            r = l.orc_kat_mip_level(ctypes.byref(t), L, buf.ctypes.data)
+            if r == 0:
+                return out
+            w, h = r >> 16, r & 0xffff
+            out.append(np.ascontiguousarray(buf[: w * h * 4].reshape(h, w, 4)))
+            L += 1
+
+    def set_mip_levels(self, uniform: str, levels):
+        """Diagnostic: replace the mip levels >= 1 of that texture by the caller's (orc_kat_set_mip_level); None / empty = leave.
+        Call drop_mips() to return to the oracle's own."""
+        t = self.frame.tex[TEX_SLOTS.index(uniform)]
+        l = lib()
+        l.orc_kat_set_mip_level.restype = ctypes.c_int
+        l.orc_kat_set_mip_level.argtypes = [ctypes.POINTER(Texture), ctypes.c_int, ctypes.c_void_p]
+        for L, lv in enumerate(levels or (), start=1):
+            a = np.ascontiguousarray(lv, np.uint8)
+            if l.orc_kat_set_mip_level(ctypes.byref(t), L, a.ctypes.data) != 0:
+                raise RuntimeError(f"mip level {L} of {uniform} does not exist")
+
+    @staticmethod
+    def drop_mips():
+        lib().orc_kat_drop_mips()
+
+    def primary_hits(self, threads: int = 0, torus_t=None):
+        """Diagnostic (orc_set_primary_buffers): -> (frame, hits) where hits[y, x] = (t, type, num, 0) of the pixel's FIRST calcInter
+        (type = num = -1 on a miss). torus_t: optional (H, W) float32 -- where the camera ray hits a torus and the entry is > 0, that
+        distance replaces the solver's own root (the reference's root substituted)."""
+        l = lib()
+        l.orc_set_primary_buffers.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        hits = np.zeros((self.height, self.width, 4), np.float32)
+        tin = None if torus_t is None else np.ascontiguousarray(torus_t, np.float32)
+        assert tin is None or tin.shape == (self.height, self.width)
+        l.orc_set_primary_buffers(hits.ctypes.data, None if tin is None else tin.ctypes.data)
+        try:
+            frame, _ = self.render(threads=threads)
+        finally:
+            l.orc_set_primary_buffers(None, None)
+        return frame, hits
+
+    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0, jitter=(0.0, 0.0), tags=None, lod_force: float = -1.0):
         """Returns (float32 array (rows, W, 4), counters dict). Row 0 = bottom (gl_FragCoord).
         jitter: diagnostic displacement of every primary ray (orc_set_ray_jitter), in units of the un-normalised view vector.
-        tags: optional (rows, W) uint32 array that receives the per-pixel ORC_TAG_* event bits (TAG_* below)."""
+        tags: optional (rows, W) uint32 array that receives the per-pixel ORC_TAG_* event bits (TAG_* below).
+        lod_force: diagnostic, >= 0: every mip-mapped fetch is sampled at this level of detail (orc_set_lod_force)."""
         y1 = self.height if y1 is None else y1
         out = np.empty((y1 - y0, self.width, 4), dtype=np.float32)
         cnt = Counters()
@@ -142,6 +191,8 @@ class OracleScene:
         l.orc_set_ray_jitter.argtypes = [ctypes.c_float, ctypes.c_float]
         l.orc_set_tag_buffer.argtypes = [ctypes.c_void_p]
         l.orc_set_ray_jitter(float(jitter[0]), float(jitter[1]))
+        l.orc_set_lod_force.argtypes = [ctypes.c_float]
+        l.orc_set_lod_force(float(lod_force))
         if tags is not None:
             assert tags.shape == (y1 - y0, self.width) and tags.dtype == np.uint32 and tags.flags.c_contiguous
             l.orc_set_tag_buffer(tags.ctypes.data)
@@ -149,6 +200,7 @@ class OracleScene:
             rc = l.orc_render(ctypes.byref(self.frame), y0, y1, out.ctypes.data, ctypes.byref(cnt), threads)
         finally:
             l.orc_set_ray_jitter(0.0, 0.0)
+            l.orc_set_lod_force(-1.0)
             l.orc_set_tag_buffer(None)
         if rc != 0:
             raise RuntimeError("orc_render failed")

@@ -93,6 +93,7 @@ GLFN(void, glDrawArrays, GLenum, GLint, GLsizei);
 GLFN(void, glReadPixels, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void*);
 GLFN(void, glFinish, void);
 GLFN(void, glDisable, GLenum);
+GLFN(void, glGetTexImage, GLenum, GLint, GLenum, GLenum, void*);
 
 static int load_gl(void)
 {
@@ -104,7 +105,7 @@ static int load_gl(void)
     L(glEnableVertexAttribArray); L(glVertexAttribPointer); L(glGenTextures); L(glDeleteTextures); L(glBindTexture); L(glActiveTexture);
     L(glTexImage2D); L(glTexParameteri); L(glGenerateMipmap); L(glPixelStorei); L(glGenFramebuffers); L(glDeleteFramebuffers);
     L(glBindFramebuffer); L(glFramebufferTexture2D); L(glCheckFramebufferStatus); L(glViewport); L(glClearColor); L(glClear);
-    L(glDrawArrays); L(glReadPixels); L(glFinish); L(glDisable);
+    L(glDrawArrays); L(glReadPixels); L(glFinish); L(glDisable); L(glGetTexImage);
 #undef L
     return 0;
 }
@@ -322,6 +323,34 @@ int glref_render(const char* vert_src, const char* frag_src, int w, int h, int n
     p_glDeleteShader(fs);
     if (e != GL_NO_ERROR) FAIL("GL error 0x%x", e);
     return 0;
+}
+
+/* The mip level `level` that THIS GL implementation's glGenerateMipmap builds for a texture uploaded like the reference uploads it
+ * (GLWrapper.cpp:331-337), as RGBA8 into out. Returns width << 16 | height of the level, 0 if it does not exist, -1 on error.
+ * (glGenerateMipmap's filter is the implementation's choice; the fixtures store llvmpipe's levels so that the plain reference frames can
+ * be compared with the same mip texels on both sides.) */
+int glref_generated_mip(int width, int height, int channels, const unsigned char* texels, int level, unsigned char* out)
+{
+    if (!g_ctx) FAIL("glref_init first");
+    int lw = width, lh = height;
+    for (int L = 0; L < level; L++) {
+        if (lw == 1 && lh == 1) return 0;
+        lw = lw > 1 ? lw / 2 : 1; lh = lh > 1 ? lh / 2 : 1;
+    }
+    GLuint id = 0;
+    const GLenum fmt = channels == 1 ? GL_RED : (channels == 3 ? GL_RGB : GL_RGBA);
+    p_glActiveTexture(GL_TEXTURE0 + 14);
+    p_glGenTextures(1, &id);
+    p_glBindTexture(GL_TEXTURE_2D, id);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, (GLint)fmt, width, height, 0, fmt, GL_UNSIGNED_BYTE, texels);
+    p_glGenerateMipmap(GL_TEXTURE_2D);
+    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glGetTexImage(GL_TEXTURE_2D, level, GL_RGBA, GL_UNSIGNED_BYTE, out);
+    const GLenum e = p_glGetError();
+    p_glBindTexture(GL_TEXTURE_2D, 0);
+    p_glDeleteTextures(1, &id);
+    if (e != GL_NO_ERROR) FAIL("GL error 0x%x", e);
+    return (lw << 16) | lh;
 }
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -97,7 +97,42 @@ def _oracle_mip_chain(arr):
         L += 1
 
 
-def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube_mipmap: bool = False, oracle_mips: bool = False, level0_only: bool = False):
+def generated_mips(img) -> list:
+    """The mip levels >= 1 that llvmpipe's glGenerateMipmap builds for this image (each (h, w, 4) uint8), level 1 first."""
+    l = lib()
+    arr = np.ascontiguousarray(img, dtype=np.uint8)
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    l.glref_generated_mip.restype = ctypes.c_int
+    l.glref_generated_mip.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    out, L = [], 1
+    while True:
+        buf = np.empty(arr.shape[0] * arr.shape[1] * 4, np.uint8)
+        r = l.glref_generated_mip(arr.shape[1], arr.shape[0], ch, arr.ctypes.data, L, buf.ctypes.data)
+        if r < 0:
+            raise RuntimeError("glref_generated_mip: " + l.glref_error().decode())
+        if r == 0:
+            return out
+        w, h = r >> 16, r & 0xffff
+        out.append(np.ascontiguousarray(buf[: w * h * 4].reshape(h, w, 4)))
+        L += 1
+
+
+def instrument_primary_hit(frag: str) -> str:
+    """Run-time instrumentation of the reference's shader text (in memory only, never stored): FragColor becomes what the FIRST calcInter
+    of the pixel returned -- (t, type, num, 1) -- instead of the colour. Two insertions into main() (rt.frag:804-902): globals in front of
+    it, a capture right after `tm = calcInter(ro, rd, num, type);`, and the output line. Everything else -- the intersectors, the scan,
+    Durand-Kerner -- is the reference's own code, which is the point: the accepted ROOT is compared, not a colour derived from it."""
+    a = "void main()"
+    b = "tm = calcInter(ro, rd, num, type);"
+    c = "FragColor = vec4(color,1);"
+    assert frag.count(a) == 1 and frag.count(b) == 1 and frag.count(c) >= 1
+    frag = frag.replace(a, "float dbg_t = 0.0; int dbg_type = -1; int dbg_num = -1; bool dbg_first = true;\n" + a, 1)
+    frag = frag.replace(b, b + "\n\t\tif (dbg_first) { dbg_first = false; dbg_t = tm; if (tm < maxDist) { dbg_type = type; dbg_num = num; } }", 1)
+    return frag.replace(c, "FragColor = vec4(dbg_t, float(dbg_type), float(dbg_num), 1);", 1)
+
+
+def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube_mipmap: bool = False, oracle_mips: bool = False, level0_only: bool = False,
+           patch=None):
     """One frame of the reference's program. Returns (H, W, 4) float32, row 0 = bottom row, and the set of block
     names the linked program does not contain (the reference would exit on those).
     Diagnostics: oracle_mips uploads the oracle's mip levels instead of calling glGenerateMipmap (same texels on both sides, only the
@@ -105,6 +140,8 @@ def render(scene_blocks, fb_w: int, fb_h: int, textures=None, cubemap=None, cube
     shader -- texture() and textureLod() alike -- is a level-0 bilinear fetch (no implementation-defined mip machinery at all)."""
     l = lib()
     vert, frag = shader_sources(scene_blocks.defines)
+    if patch is not None:      # diagnostic instrumentation of the shader text, e.g. instrument_primary_hit
+        frag = patch(frag)
     keep = []
     names = (ctypes.c_char_p * 9)(*[n.encode() for n in BLOCKS])
     data = (ctypes.c_void_p * 9)()

@@ -211,6 +211,13 @@ enum { ORC_TAG_BOX_INSIDE = 1,   /* intersectBox returned a negative distance (t
                                           takes that derivative as 0, llvmpipe differences whatever its masked-off lanes hold */
 static uint32_t* g_tag_buffer = NULL;   /* fb_width * rows uint32, or NULL */
 void orc_set_tag_buffer(uint32_t* p) { g_tag_buffer = p; }
+/* Diagnostics for pinning Durand-Kerner's accepted root against the reference (tests/test_reference_frames.py): what the FIRST calcInter
+ * of every pixel returned -- (t, type, num, 0) per pixel of the WHOLE frame, row 0 = bottom -- and the reverse: a per-pixel distance that
+ * replaces the camera ray's own root when it hit a torus (the reference's root substituted), so that the rest of the path can be
+ * compared without the solver's 1e-3 between the two. */
+static float* g_primary_out = NULL;
+static const float* g_primary_t_in = NULL;
+void orc_set_primary_buffers(float* out_t_type_num, const float* torus_t_in) { g_primary_out = out_t_type_num; g_primary_t_in = torus_t_in; }
 
 /* ---------------------------------------------------------------------------------------------
  * GLSL built-ins, restated
@@ -238,6 +245,12 @@ static inline vec3 normalize3(vec3 a) { return div3s(a, length3(a)); }
  * oracle's pixels for lambda - b and lambda + b is reproduced by a level of detail within b of the oracle's. Normally 0. */
 static float g_lod_bias = 0.0f;
 void orc_set_lod_bias(float b) { g_lod_bias = b; }
+/* Diagnostic: every mip-mapped fetch takes THIS level of detail (>= 0; < 0 = off). A fetch in a divergent 2x2 quad has no defined
+ * derivative (GLSL 4.50 section 8.13.1), so a GL implementation may sample it at ANY level; a trilinear sample is piecewise linear in
+ * the level with knots at the integers, so the pixel's values for level 0, 1, ..., top bracket whatever level was taken
+ * (tests/reference_classify.py: the `divergent` and `quad_neighbour` classes demand the reference's pixel inside that bracket). */
+static float g_lod_force = -1.0f;
+void orc_set_lod_force(float level) { g_lod_force = level; }
 static int g_nan_minmax = 0;
 void orc_set_nan_minmax(int mode) { g_nan_minmax = mode; }
 static inline float gl_min(float a, float b) { return g_nan_minmax ? (a < b ? a : b) : (b < a ? b : a); }
@@ -616,6 +629,7 @@ static void quad_resolve(quad_t* q, const orc_frame* fr)
             }
         }
         if (g_lod_bias != 0.0f) lambda += g_lod_bias;   /* diagnostic, see orc_set_lod_bias */
+        if (g_lod_force >= 0.0f) lambda = g_lod_force;  /* diagnostic, see orc_set_lod_force */
         res[k] = sample2d_lod(t, q->lane[k].uv, lambda);
     }
     for (int k = 0; k < 4; k++)
@@ -1141,6 +1155,13 @@ static vec4 shade_pixel(inv_t* iv) /* main(), :804-902 */
         if (segments >= ORC_SEGMENT_CAP) { iv->cnt->segment_cap_hits++; break; }
         segments++;
         tm = calcInter(iv, ro, rd, &num, &type);
+        if (segments == 1 && (g_primary_out || g_primary_t_in)) {   /* diagnostic, see orc_set_primary_buffers */
+            const size_t px = (size_t)(iv->frag_y - 0.5f) * (size_t)iv->fr->fb_width + (size_t)(iv->frag_x - 0.5f);
+            if (iv->frag_x < (float)iv->fr->fb_width && iv->frag_y < (float)iv->fr->fb_height) {
+                if (g_primary_t_in && tm < maxDist && type == TYPE_TORUS && g_primary_t_in[px] > 0.0f) tm = g_primary_t_in[px];
+                if (g_primary_out) { float* o = g_primary_out + px * 4; o[0] = tm; o[1] = (float)(tm < maxDist ? type : -1); o[2] = (float)(tm < maxDist ? num : -1); o[3] = 0.0f; }
+            }
+        }
         if (tm < maxDist) {
             pt = add3(ro, scale3(rd, tm));
             hr = get_hit_info(iv, ro, rd, pt, tm, num, type);
@@ -1439,6 +1460,25 @@ void orc_kat_sample2d_lod(const orc_texture* t, float u, float v, float lambda, 
     (void)mip_lookup(t, 1);
     vec4 c = sample2d_lod(t, v2(u, v), lambda);
     out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+}
+/* Diagnostic: replace the texels of mip level `level` (>= 1) of this texture's cached chain by the caller's RGBA8 bytes -- the build
+ * container hands over the levels a GL implementation generated (glGenerateMipmap leaves the filter to the implementation; llvmpipe's
+ * differs from the integer mean by one LSB on 6-17 % of the texels), so that the plain reference frames can be compared with "the same
+ * mip texels" on both sides. The override lives as long as the cached chain (same level-0 bytes at the same address); orc_kat_drop_mips
+ * forgets every chain. Returns 0, -1 if the level does not exist. */
+int orc_kat_set_mip_level(const orc_texture* t, int level, const uint8_t* in)
+{
+    (void)mip_lookup(t, 1);
+    const orc_mipchain* m = mip_get(t);
+    if (!m || level < 1 || level >= m->levels) return -1;
+    memcpy(m->data[level], in, (size_t)m->w[level] * m->h[level] * 4);
+    return 0;
+}
+void orc_kat_drop_mips(void)
+{
+    for (int k = 0; k < g_mips_n; k++)
+        for (int l = 0; l < g_mips[k].levels; l++) free(g_mips[k].data[l]);
+    g_mips_n = 0;
 }
 /* copies mip level `level` (RGBA8) into out; returns its width<<16 | height, 0 if the level does not exist */
 int orc_kat_mip_level(const orc_texture* t, int level, uint8_t* out)

@@ -52,7 +52,41 @@ CASES = {
     "trap_degenerate_rings": (lambda: _trap("degenerate_rings"), True, (0.12, 0.03)),
     "trap_glass_tir": (lambda: _trap("glass_tir"), False, (0.06, 0.012)),
     "trap_planes_glass": (lambda: _trap("planes_glass"), False, (0.003, 0.0005)),
+    # ---- round 3: more of the reference's own runs -------------------------------------------------------------------------------------
+    # BASELINE configs[0]: the animated default scene at t = 12.5 with the camera the reference's host code produces for yaw 25 / pitch 10
+    # (the same recipe as tests/golden/default_t12.5_640x480_d1.rtxb, which is the output of the reference's own SceneManager), reflection
+    # depth 1, at half the configuration's 640 x 480; with the textures off and as the reference runs it
+    "config0_untextured": (lambda: _strip_textures(scenes.build_scene("default", 320, 240, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0)), False, (0.004, 0.0006)),
+    "config0": (lambda: scenes.build_scene("default", 320, 240, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0), True, (0.10, 0.012)),
+    # the reference's own default run (main.cpp:7-8: 1280 x 720; SceneManager.cpp:233: reflect_depth 5; main.cpp:197-246: animated) at a
+    # quarter of its size, two animation times
+    "app_default_t3": (lambda: _strip_textures(scenes.build_scene("default", 320, 180, 5, time=3.0, delta=0.016)), False, (0.004, 0.0006)),
+    "app_default_t7_5": (lambda: _strip_textures(scenes.build_scene("default", 320, 180, 5, time=7.5, delta=0.016)), False, (0.004, 0.0006)),
+    # a moved and rotated camera (SceneManager.cpp:43-50: quat(vec3(radians(-pitch), radians(yaw), 0)))
+    "moved_camera": (lambda: _strip_textures(scenes.build_scene("default", W, H, 4, time=1.25, delta=0.016, yaw=-38.0, pitch=-14.0, cam_pos=(2.5, 1.5, -6.0))), False, (0.004, 0.0006)),
 }
+# random content: eight seeds of tests/random_scenes.py (what tools/fuzz_reference.py sweeps, textures off) as committed frames
+FUZZ_SEEDS = (3, 11, 19, 28, 42, 57, 64, 90)
+FUZZ_SIZE = (112, 64)
+
+
+def _fuzz(seed):
+    import random_scenes
+    return _strip_textures(random_scenes.random_scene(seed, *FUZZ_SIZE))
+
+
+for _s in FUZZ_SEEDS:
+    CASES[f"fuzz_{_s}"] = ((lambda s=_s: _fuzz(s)), False, (0.02, 0.004))
+SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180)}
+SIZES.update({f"fuzz_{_s}": FUZZ_SIZE for _s in FUZZ_SEEDS})
+
+
+def size(name):
+    """(width, height) of a case's frame; the *_same_mips / *_level0 variants have their base case's size."""
+    for suffix in ("_same_mips", "_level0"):
+        if name.endswith(suffix):
+            name = name[: -len(suffix)]
+    return SIZES.get(name, (W, H))
 # Diagnostic fixture: the default scene again, but the GL textures were given the ORACLE's mip levels (glTexImage2D per
 # level) instead of glGenerateMipmap, so that only level selection and filtering are compared. Checked with the oracle in
 # its llvmpipe-LOD mode (texture_lod = 2): what is left is llvmpipe's atan/asin approximation on the planets + silhouettes.
@@ -60,7 +94,10 @@ SAME_MIPS = ("default_same_mips", 0.025, 0.008)   # name, max fraction > 1e-4, >
 # Variants of the two textured cases (same scene blocks and textures, different GL texture state; oracle/ref_gl/ref_gl.py):
 #   <case>_same_mips : GL was given the oracle's mip texels -> compared with the oracle in its llvmpipe LOD mode (texture_lod = 2)
 #   <case>_level0    : GL was given level 0 only (GL_TEXTURE_MAX_LEVEL = 0) -> compared with the oracle at texture_lod = 0
-TEXTURED = ("default", "trap_degenerate_rings")
+TEXTURED = ("default", "trap_degenerate_rings")     # pinned three ways (variants below)
+TEXTURED_PLAIN_ONLY = ("config0",)                  # textured, plain run only (with llvmpipe's generated mip levels stored)
+# fixtures that also hold what the FIRST calcInter of every pixel returned in the reference's shader (t, type, num): instrumented run
+PRIMARY_HITS = ("torus", "default_untextured")
 VARIANTS = {f"{c}_{v}": (c, v) for c in TEXTURED for v in ("same_mips", "level0")}
 
 
@@ -100,7 +137,19 @@ def load(name):
     ts = texture_set()
     if input_digest(sc, ts) != str(z["digest"]):
         raise RuntimeError(f"inputs of reference frame '{name}' no longer reproduce (textures.py changed?)")
-    _LOADED[name] = dict(name=name, scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
+    # llvmpipe's own mip levels (plain textured runs only), stored as differences from the oracle's integer-mean levels
+    gl_mips = None
+    if any(k.startswith("glmip_") for k in z.files):
+        from oracle import oracle
+        O = oracle.OracleScene(sc, int(z["width"]), int(z["height"]), ts["textures"], ts["cubemap"])
+        gl_mips = {}
+        for uniform, _unit, _img in ts["textures"]:
+            ours = O.mip_levels(uniform)
+            gl_mips[uniform] = [(a.astype(np.int16) + z[f"glmip_{uniform}_{L}"].astype(np.int16)).astype(np.uint8) for L, a in enumerate(ours, start=1)]
+    primary = None
+    if "primary_t" in z.files:
+        primary = dict(t=z["primary_t"], type=z["primary_type"].astype(np.int32), num=z["primary_num"].astype(np.int32))
+    _LOADED[name] = dict(primary=primary, gl_mips=gl_mips, name=name, scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
                          frame=z["frame"], limits=CASES[name][2] if name in CASES else SAME_MIPS[1:], renderer=str(z["renderer"]))
     return _LOADED[name]
 

@@ -66,6 +66,11 @@ def test_frame_parity_and_ray_counts(mid_textures, kind, w, h, depth, lod):
     # RGBA8 target = clamp + round of the same colours
     exp8 = (np.clip(np.nan_to_num(ref, nan=0.0), 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
     assert np.abs(img8.astype(np.int16) - exp8.astype(np.int16)).max() <= 1
+    # the PRODUCT variant (no ray counters: the kernel bench.py times) against the oracle directly, not only via "== counting variant"
+    prod, _p8, _st = _render_gpu(sc, w, h, mid_textures, {wrapper.RTX_OPT_TEXTURE_LOD: lod, wrapper.RTX_OPT_COUNT_RAYS: 0})
+    mx, nbad, nanbad = _compare(prod, ref)
+    assert nanbad == 0 and mx <= TOL and nbad == 0, f"product variant: max diff {mx}, {nbad} components over {TOL}"
+    assert np.array_equal(prod.view(np.uint32), img.view(np.uint32))
 
 
 @pytest.mark.parametrize("opts", [{wrapper.RTX_OPT_CULL: 0}, {wrapper.RTX_OPT_SCENE_LDS: 1}, {wrapper.RTX_OPT_CULL: 0, wrapper.RTX_OPT_SCENE_LDS: 1}])
@@ -243,6 +248,26 @@ def test_full_size_properties(mid_textures):
         mx, nbad, nanbad = _compare(a[y0:y0 + 8], ref)
         assert nanbad == 0 and mx <= TOL, (y0, mx)
     assert np.all(a[..., 3] == 1.0)
+    gl.stop()
+
+
+def test_config1_at_its_own_size(mid_textures):
+    """BASELINE configs[1] -- default scene, 1920 x 1080, depth 4, one GPU -- at exactly that size: the WHOLE frame of the product
+    variant against the oracle (the oracle renders 1080p in seconds), exact ray counts from the counting variant, and the two variants
+    bit-identical."""
+    w, h, depth = 1920, 1080, 4
+    sc = scenes.build_scene("default", w, h, depth)
+    gl = wrapper.make_renderer(sc, w, h, mid_textures["textures"], mid_textures["cubemap"])
+    gl.draw()
+    a = gl.read_pixels()
+    ref, cnt = oracle.OracleScene(sc, w, h, mid_textures["textures"], mid_textures["cubemap"]).render()
+    mx, nbad, nanbad = _compare(a, ref)
+    assert nanbad == 0 and mx <= TOL, mx
+    gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    gl.draw()
+    st = gl.stats()
+    assert (st["rays_closest"], st["rays_shadow"]) == (cnt["rays_closest"], cnt["rays_shadow"])
+    assert np.array_equal(gl.read_pixels().view(np.uint32), a.view(np.uint32))
     gl.stop()
 
 

@@ -19,17 +19,26 @@ from oracle import oracle
 
 NAMES = list(rf.CASES)
 UNTEXTURED = [n for n in NAMES if not rf.CASES[n][1]]
-# (fixture, oracle texture_lod, bound for the `texture` category)
-TEXTURED_PLAN = [(c + "_level0", 0, 0.01) for c in rf.TEXTURED] + [(c + "_same_mips", 2, 0.1) for c in rf.TEXTURED] + [(c, 1, 1.0) for c in rf.TEXTURED]
+# (fixture, oracle texture_lod, bound for the `texture` category, oracle samples llvmpipe's generated mip levels?, texture_level class?)
+#   *_level0     level 0 only on both sides: everything but the mip machinery, 0.01
+#   *_same_mips  GL was handed the oracle's mip texels, oracle in llvmpipe's level formula: 0.1
+#   plain, "gl"  the reference as it really runs (glGenerateMipmap) against the oracle with llvmpipe's generated levels read back + llvmpipe's
+#                level formula: the same bound, 0.1 (round 2 had 1.0 here, i.e. none)
+#   plain, rule  ... against the oracle's / the product's own texture rule (integer-mean mips, exact log2): 0.1, or a sample of the same
+#                texture at another level (texture_level)
+TEXTURED_PLAN = ([(c + "_level0", 0, 0.01, False, False) for c in rf.TEXTURED] + [(c + "_same_mips", 2, 0.1, False, False) for c in rf.TEXTURED]
+                 + [(c, 2, 0.1, True, True) for c in rf.TEXTURED + rf.TEXTURED_PLAIN_ONLY] + [(c, 1, 0.1, False, True) for c in rf.TEXTURED + rf.TEXTURED_PLAIN_ONLY])
+PLAN_IDS = [p[0] + ("_gl_mips" if p[3] else "") + ("_product_rule" if p[4] else "") for p in TEXTURED_PLAN]
 
 
 def _accept(name, r, textured):
     px = r["pixels"]
     assert r["unexplained"] == 0, f"{name}: {r['unexplained']} pixels differ from the reference shader by more than 1e-4 and no mechanism claims them: {r['where']}"
-    assert r["edge"] <= 3 and r["approx_math"] <= max(3, px // 2000), (name, r)          # the two last-resort categories stay marginal
-    assert r["unstable_pixels_in_frame"] <= 0.12 * px, (name, r)                         # the permissive set is a small part of the frame
+    assert r["edge"] <= 3 and r["approx_math"] <= max(3, px // 2000) and r["unstable_between"] <= 8, (name, r)   # the last-resort categories stay marginal
+    assert r["unstable_pixels_in_frame"] <= 0.12 * px, (name, r)                         # the envelope-bounded set is a small part of the frame
+    assert r["box_nan"] == 0, (name, r)                                                  # the one class without a value bound is not needed by any fixture
     if not textured:
-        assert r["divergent"] == 0 and r["texture"] == 0 and r["quad_neighbour"] == 0, (name, r)
+        assert r["divergent"] == 0 and r["texture"] == 0 and r["quad_neighbour"] == 0 and r["texture_level"] == 0, (name, r)
     return r
 
 
@@ -40,9 +49,15 @@ def test_oracle_matches_reference_shader(built, name):
     _accept(name, rc.classify(ref), False)
 
 
-@pytest.mark.parametrize("name,lod,tex_tol", TEXTURED_PLAN, ids=[p[0] for p in TEXTURED_PLAN])
-def test_oracle_matches_reference_shader_textured(built, name, lod, tex_tol):
-    r = _accept(name, rc.classify(rf.load(name), texture_lod=lod, tex_tol=tex_tol), True)
+@pytest.mark.parametrize("name,lod,tex_tol,gl_mips,level_env", TEXTURED_PLAN, ids=PLAN_IDS)
+def test_oracle_matches_reference_shader_textured(built, name, lod, tex_tol, gl_mips, level_env):
+    r = _accept(name, rc.classify(rf.load(name), texture_lod=lod, tex_tol=tex_tol, gl_mips=gl_mips, tex_level_envelope=level_env), True)
+    if gl_mips:                        # llvmpipe's texels + llvmpipe's level formula: the plain run is as close as the *_same_mips one;
+        # texture_level then only for the odd pixel on a planet's u = 0 / 1 seam, where rt.frag:327's `df.x > 0.5` test is decided by WHICH
+        # row / column of the quad an implementation differences (GLSL 4.50 section 8.13.1 allows either): config0 has one such pixel
+        assert r["over"] <= 0.06 * r["pixels"] and r["texture_level"] <= 3, (name, r)
+    elif level_env:
+        assert r["texture_level"] <= 0.001 * r["pixels"], (name, r)
     if name.endswith("_level0"):       # without mip maps the textured frames are as close as the untextured ones
         assert r["over"] <= 0.012 * r["pixels"] and r["divergent"] == 0, (name, r)
     if name.endswith("_same_mips"):    # same texels + llvmpipe's LOD formula: well under the plain run
@@ -82,6 +97,79 @@ def test_the_classifier_does_not_excuse_a_wrong_frame(built):
         assert r["unexplained"] > 50, (damage, r)
 
 
+def test_defects_inside_the_permissive_sets_are_not_excused(built):
+    """Round 2's classifier excused ANY value on an unstable pixel and any value up to 1.0 on a mip-mapped one. Now: a defect confined to
+    the unstable set of the torus frame (silhouettes, Durand-Kerner's last sweep) -- 3 % too dark there and nowhere else --, a defect
+    confined to the mip-mapped pixels of the textured frame (an offset of 0.15; and of 0.02 in the level-0 variant), and a defect
+    confined to the divergent-quad pixels (a value outside every level's sample) must each leave most of the damaged pixels
+    unexplained."""
+    ref = rf.load("torus")
+    img, _ = oracle.OracleScene(*_scene_args(ref)).render(threads=8)
+    _b, _t, unstable, *_ = rc.probe(ref, 1, False)
+    assert unstable.sum() > 1000
+    bad = img.copy()
+    bad[unstable, :3] *= np.float32(0.97)
+    r = rc.classify(ref, candidate=bad)
+    lit = unstable & (img[..., :3].max(-1) > 0.25)           # 3 % of these is more than every bound (NEAR_TOL 2e-3, TORUS_TOL 5e-3)
+    # (unexplained outright, or only "between" two of the oracle's answers -- a class the acceptance caps at 8 pixels per frame)
+    assert lit.sum() > 1000 and r["unexplained"] + r["unstable_between"] > 0.9 * lit.sum() and r["unexplained"] > 1000, (r, int(lit.sum()))
+    with pytest.raises(AssertionError):
+        _accept("torus, damaged", r, False)
+    for name, lod, off, kw in (("default", 1, 0.15, dict(tex_tol=0.1, tex_level_envelope=True)), ("default", 2, 0.15, dict(tex_tol=0.1, gl_mips=True)),
+                               ("default_level0", 0, 0.02, dict(tex_tol=0.01))):
+        ref = rf.load(name)
+        base, tags, unstable, *_ = rc.probe(ref, lod, kw.get("gl_mips", False))
+        tex = ((tags & oracle.TAG_TEXTURE) != 0) & ((tags & oracle.TAG_QUAD_DIVERGENT) == 0) & ~unstable
+        assert tex.sum() > 1500
+        bad = base.copy()
+        bad[tex, :3] += np.float32(off)
+        r = rc.classify(ref, candidate=bad, texture_lod=lod, **kw)
+        assert r["unexplained"] > 0.8 * tex.sum(), (name, lod, r, int(tex.sum()))
+    ref = rf.load("default")
+    base, tags, unstable, *_ = rc.probe(ref, 1, False)
+    div = ((tags & oracle.TAG_QUAD_DIVERGENT) != 0) & ~unstable
+    assert div.sum() > 200
+    bad = base.copy()
+    bad[div, :3] = np.float32(1.5)                            # brighter than any texel of any level
+    r = rc.classify(ref, candidate=bad, texture_lod=1, tex_tol=0.1, tex_level_envelope=True)
+    assert r["unexplained"] > 0.9 * div.sum(), (r, int(div.sum()))
+
+
+def test_accepted_torus_roots_equal_the_reference_shaders(built):
+    """The `torus` class compares colours (<= 0.05). This compares ROOTS: the fixtures hold what the first calcInter of every pixel
+    returned in the reference's own shader (instrumented at run time, oracle/ref_gl.instrument_primary_hit: t, type, num). (1) both sides
+    hit the same primitive at every pixel that is not within rounding of a flip; (2) Durand-Kerner's accepted root agrees to 2e-3 (its
+    stop criterion is max |delta| < 1e-3 over the four roots, rt.frag:479; near a double root -- a grazing ray -- the iteration converges
+    linearly and stops further out) on 99.8 % of the stable pixels, to 2e-2 on all of them and to 1e-3 relative everywhere; the
+    closed-form intersectors agree to 1e-4 relative; (3) with the reference's root SUBSTITUTED into the oracle, every stable pixel whose camera ray hits a torus is within
+    1e-4 of the reference's colour -- nothing of the `torus` class is left, i.e. its <= 0.05 was all the solver's 1e-3."""
+    for name in rf.PRIMARY_HITS:
+        ref = rf.load(name)
+        P = ref["primary"]
+        O = oracle.OracleScene(*_scene_args(ref))
+        frame, hits = O.primary_hits(threads=8)
+        t, ty, nu = hits[..., 0].astype(np.float64), hits[..., 1].astype(np.int32), hits[..., 2].astype(np.int32)
+        _b, _tags, unstable, *_ = rc.probe(ref, 1, False)
+        same = (ty == P["type"]) & (nu == P["num"])
+        assert not (~same & ~unstable).any(), (name, int((~same & ~unstable).sum()))
+        assert (~same).sum() <= 8, (name, int((~same).sum()))
+        tor = same & (ty == 4)
+        assert tor.sum() > 500
+        dt = np.abs(t - P["t"])
+        stable = dt[tor & ~unstable]
+        assert (stable > 2e-3).sum() <= 0.002 * stable.size and stable.max() <= 2e-2, (name, int((stable > 2e-3).sum()), float(stable.max()))
+        assert (dt[tor] / np.maximum(1.0, np.abs(P["t"][tor]))).max() <= 1e-3
+        other = same & (ty >= 0) & (ty != 4)
+        assert (dt[other] / np.maximum(1.0, np.abs(P["t"][other]))).max() <= 1e-4, name
+        sub, hits2 = O.primary_hits(threads=8, torus_t=np.where(P["type"] == 4, P["t"], 0.0).astype(np.float32))
+        assert np.array_equal(hits2[..., 0][tor], P["t"][tor])
+        m = tor & ~unstable
+        before, after = rc._diff(frame, ref["frame"])[m], rc._diff(sub, ref["frame"])[m]
+        assert after.max() <= 1e-4, (name, float(after.max()))
+        if name == "torus":
+            assert (before > 1e-4).sum() > 20       # (there WAS something to explain)
+
+
 @pytest.mark.parametrize("name", UNTEXTURED)
 def test_product_device_code_on_host_matches_reference_shader(built, name):
     """The product's device header compiled for the host (no quads there: untextured cases only)."""
@@ -102,12 +190,15 @@ def test_reference_run_is_reproducible(built):
     assert np.array_equal(again[..., :3], ref["frame"])
 
 
-GPU_PLAN = [(n, 1, 0.0) for n in UNTEXTURED] + [(c + "_level0", 0, 0.01) for c in rf.TEXTURED] + [(c, 1, 1.0) for c in rf.TEXTURED]
+# the kernel has one texture rule (the product's: lod 1) and its level-0 mode: the level-0 fixtures at 0.01, the *_same_mips fixtures (GL had
+# the very mip texels the kernel builds; only the level formula differs) and the plain runs at 0.1 or a sample of another level
+GPU_PLAN = ([(n, 1, 0.0, False) for n in UNTEXTURED] + [(c + "_level0", 0, 0.01, False) for c in rf.TEXTURED]
+            + [(c + "_same_mips", 1, 0.1, True) for c in rf.TEXTURED] + [(c, 1, 0.1, True) for c in rf.TEXTURED + rf.TEXTURED_PLAIN_ONLY])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,lod,tex_tol", GPU_PLAN, ids=[p[0] for p in GPU_PLAN])
-def test_hip_kernel_matches_reference_shader(built, name, lod, tex_tol):
+@pytest.mark.parametrize("name,lod,tex_tol,level_env", GPU_PLAN, ids=[p[0] for p in GPU_PLAN])
+def test_hip_kernel_matches_reference_shader(built, name, lod, tex_tol, level_env):
     """The HIP kernel's frame through the same pixel-by-pixel accounting (the oracle only supplies the per-pixel event tags and the
     stability probe; the pixels judged are the GPU's)."""
     from raytracing_opengl_amd import wrapper
@@ -116,7 +207,7 @@ def test_hip_kernel_matches_reference_shader(built, name, lod, tex_tol):
     gl.draw()
     img = gl.read_pixels(wrapper.RTX_RGBA32F)
     gl.stop()
-    _accept(name, rc.classify(ref, candidate=img, texture_lod=lod, tex_tol=tex_tol), name not in UNTEXTURED)
+    _accept(name, rc.classify(ref, candidate=img, texture_lod=lod, tex_tol=tex_tol, tex_level_envelope=level_env), name not in UNTEXTURED)
 
 
 def test_default_scene_with_the_reference_asset_files(built):
