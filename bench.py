@@ -390,14 +390,32 @@ def main():
                 peak = None
             if v and peak:
                 rate = v["valu_insts_per_launch"] / (kernel_ms * 1e-3)
-                out["roofline"]["valu"] = {
-                    "insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1), "unit": "G wave-instructions/s",
-                    "peak": peak["simple_op_peak_G_per_s"], "frac": round(rate / 1e9 / peak["simple_op_peak_G_per_s"], 4),
-                    "peak_fma_class": peak["fma_class_peak_G_per_s"], "frac_of_fma_class": round(rate / 1e9 / peak["fma_class_peak_G_per_s"], 4),
-                    "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "valu_pipe_busy": v.get("valu_pipe_busy"),
-                    "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash,
-                    "note": "instruction count and pipe-busy from rocprofv3 PMC on these kernel sources (" + v.get("source", "") + "), duration live; "
-                            "peaks = measured issue rates of v_add/v_mul-class and v_fma/v_cmp/v_max-class instructions (" + peak.get("source", "") + ")"}
+                cyc = peak["cycles_per_wave_inst_per_simd"]
+                clock = (v.get("shader_clock_GHz") or 2.3) * 1e9
+                val = {"insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1), "unit": "G wave-instructions/s",
+                       "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "valu_pipe_busy_measured": v.get("valu_pipe_busy"),
+                       "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash}
+                cls = v.get("classes")
+                if cls:
+                    # Mix-weighted issue ceiling: every instruction class at its MEASURED issue cost (cycles per wave-instruction per SIMD,
+                    # tools/micro/valu_rate.hip); the classes the counters do not name ("other": v_mov / v_cmp / v_cndmask / v_min / v_max /
+                    # lane moves) at the cheapest cost measured (v_mov: 2.38 -- compares and selects cost 4.1-4.4, so this is a lower bound
+                    # on the cycles the mix needs). frac = those cycles / the cycles the kernel took = achieved / peak <= 1 by construction.
+                    cost = {"add_f32": cyc["v_add_f32"], "mul_f32": cyc["v_mul_f32"], "fma_f32": cyc["v_fma_f32"], "trans_f32": cyc["v_rcp_f32"],
+                            "int32": cyc["v_add_u32"], "int64": cyc["v_add_u32"], "cvt": cyc["v_cvt_f32_ubyte0"], "other": cyc["v_mov_b32"]}
+                    need_cycles = sum(cls[k] * cost[k] for k in cost if k in cls) / 1024.0      # per SIMD
+                    mix_peak = v["valu_insts_per_launch"] / (need_cycles / clock)
+                    val.update({"peak": round(mix_peak / 1e9, 1), "frac": round(rate / mix_peak, 4),
+                                "classes_per_launch": cls, "issue_cycles_per_class": {k: cost[k] for k in cost},
+                                "mean_issue_cycles_of_the_mix": round(need_cycles * 1024.0 / v["valu_insts_per_launch"], 3),
+                                "shader_clock_GHz": v.get("shader_clock_GHz")})
+                    val["note"] = ("mix-weighted VALU issue ceiling: per-class instruction counts (rocprofv3 PMC, " + v.get("source", "") + ") x measured issue "
+                                   "cycles per class (" + peak.get("source", "") + "), unnamed classes at the cheapest measured cost, so frac <= 1 by "
+                                   "construction; duration live; valu_pipe_busy_measured is SQ_ACTIVE_INST_VALU against GRBM_GUI_ACTIVE (nominal units)")
+                else:
+                    val.update({"peak": peak["simple_op_peak_G_per_s"], "frac": round(rate / 1e9 / peak["simple_op_peak_G_per_s"], 4),
+                                "note": "no per-class counts in the profile: peak = the issue rate of an all-v_add stream (a loose ceiling)"})
+                out["roofline"]["valu"] = val
             t = prof("traffic")
             if t:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]

@@ -106,6 +106,11 @@ typedef struct rtx_stats {
     uint32_t smaa_edge_pixels; /* pixels with an edge in the last resolve (the sparse passes' work list) */
     float last_pencil_build_ms; /* HIP-event time of the last ray-pencil mask build (runs when the scene changed; 0: scene has none) */
     uint32_t pencils;          /* ray pencils of the current scene (RTX_OPT_RAY_PENCILS) */
+    uint32_t kernel_variant;   /* which build of the trace kernel the last draw ran: 0 = default, 1 = many-primitive (RTX_OPT_HIGH_OCCUPANCY) */
+    uint32_t candidate_tables; /* candidate selection in front of the last draw's long-table scans, bit set = active: 1 = group culls
+                                  (>= 16 quadrics or tori), 2 = ray pencils, 4 = slab + direction tables. 0 with many quadrics / tori
+                                  means the scene fell outside what the tables hold (more than 128 of a kind: the library says so once
+                                  on stderr) or RTX_OPT_RAY_PENCILS / RTX_OPT_CULL is off: plain two-level scans, same results, slower */
 } rtx_stats;
 
 RTX_API const char* rtx_last_error(void);

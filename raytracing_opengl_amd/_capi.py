@@ -41,7 +41,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("last_draw_ms", ctypes.c_float), ("launches", ctypes.c_uint32), ("rays_closest", ctypes.c_uint64),
                 ("rays_shadow", ctypes.c_uint64), ("rays_shadow_cast", ctypes.c_uint64), ("torus_solves", ctypes.c_uint64),
                 ("last_smaa_ms", ctypes.c_float), ("last_gather_ms", ctypes.c_float), ("smaa_edge_pixels", ctypes.c_uint32),
-                ("last_pencil_build_ms", ctypes.c_float), ("pencils", ctypes.c_uint32)]
+                ("last_pencil_build_ms", ctypes.c_float), ("pencils", ctypes.c_uint32),
+                ("kernel_variant", ctypes.c_uint32), ("candidate_tables", ctypes.c_uint32)]
 
 
 _lib = None

@@ -833,17 +833,6 @@ RT_HD bool intersect_torus_c(const DevTorus& T, f3 ro, f3 rd, float tmin, float&
     solved = true;
     return intersect_torus_local(T, o, d, tmin, t);
 }
-// The lane-divergent torus scans (calc_inter / in_shadow, RT_TORUS_SKIP_CULLED): a lane first walks past the candidates its local cull
-// rejects (cheap, divergent) and only then joins the wave at the solver -- so that a solver pass is not shared with lanes that merely
-// found out that their candidate needs no solve. Same tests, same order per lane, same tmin at every test.
-template <bool CULL>
-RT_HD bool torus_prepare(const DevTorus& T, f3 ro, f3 rd, float tmin, f3& o, f3& d)
-{
-    const bool ident = ident_flag(T.pos.w);
-    o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos));
-    d = quat_rotate_id(T.quat, ident, rd);
-    return !(CULL && torus_local_cull(T, o, d, tmin));
-}
 RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
 {
     bool solved;
@@ -1154,12 +1143,6 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
 // primitives at once. The number of solver passes per scan drops from "distinct primitives any lane
 // of the wave needs" to "most candidates of a single lane". Per lane the tests still run in index
 // order with the live tmin, so the closest-hit semantics (strict <, first wins) are unchanged.
-#ifndef RT_SURF_LANE_WALK
-#define RT_SURF_LANE_WALK 0   /* 1: rays of no pencil (slab-table masks) walk their own quadric candidates; 2: pencil rays too */
-#endif
-#ifndef RT_TORUS_SKIP_CULLED
-#define RT_TORUS_SKIP_CULLED 0
-#endif
 #ifndef RT_LANE_DIVERGENT_MIN
 #define RT_LANE_DIVERGENT_MIN 3   /* classes with fewer primitives keep the wave-uniform path */
 #endif
@@ -1301,25 +1284,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
     if (ps.use) {
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
-#if RT_SURF_LANE_WALK
-        // every lane walks ITS OWN candidate bits (its own cull records and surfaces: vector loads): the number of passes is the longest
-        // single lane's list, not the wave's OR -- incoherent mirror rays of one wave need most of the table between them but a handful each
-        if (RT_SURF_LANE_WALK == 2 || !ps.mem)
-        for (int w = 0; w < nws; w++) {
-            uint32_t own = ps.next(S, slabw);
-            while (RT_ANY(own != 0u)) {
-                bool have = false;
-                int i = 0;
-                while (own != 0u && !have) {                      // past the candidates the first-level cull rejects
-                    i = (w << 5) + __builtin_ctz(own);
-                    own &= own - 1u;
-                    have = !surface_cull(cullrec[i], ro, rd);
-                }
-                if (have && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
-            }
-        }
-        else
-#endif
         for (int w = 0; w < nws; w++) {
             uint32_t u = wave_or(ps.next(S, slabw), true);
             while (u != 0u) {
@@ -1390,21 +1354,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd, tmin)) cand |= 1ull << (i + k - base);)
             }
-#if RT_TORUS_SKIP_CULLED
-            while (RT_ANY(cand != 0ull)) {
-                bool have = false;
-                int i = 0;
-                f3 o, d;
-                while (cand != 0ull && !have) {                   // divergent and cheap: past the candidates that need no solve
-                    i = base + lane_pop(cand);
-                    have = torus_prepare<CULL>(S.tori()[i], ro, rd, tmin, o, d);
-                }
-                if (have) {                                       // the lanes that DO solve, together
-                    if (COUNT) cnt.torus_solves++;
-                    if (intersect_torus_local(S.tori()[i], o, d, tmin, t)) { num = i; tmin = t; type = TYPE_TORUS; }
-                }
-            }
-#else
             while (RT_ANY(cand != 0ull)) {
                 if (cand != 0ull) {
                     const int i = base + lane_pop(cand);          // differs from lane to lane
@@ -1414,7 +1363,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                     if (th) { num = i; tmin = t; type = TYPE_TORUS; }
                 }
             }
-#endif
         }
     } else {
         const int n = S.h->n_torus;
@@ -1503,24 +1451,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         // the word counter must advance past the quadric words even when every lane is already in shadow
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
-#if RT_SURF_LANE_WALK
-        if (RT_SURF_LANE_WALK == 2 || !ps.mem)
-        for (int w = 0; w < nws; w++) {
-            const uint32_t word = ps.next(S, slabw);
-            uint32_t own = on ? word : 0u;
-            while (RT_ANY(own != 0u)) {
-                bool have = false;
-                int i = 0;
-                while (own != 0u && !have) {
-                    i = (w << 5) + __builtin_ctz(own);
-                    own &= own - 1u;
-                    have = !surface_cull(cullrec[i], ro, rd);
-                }
-                if (have && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; own = 0u; }
-            }
-        }
-        else
-#endif
         for (int w = 0; w < nws; w++) {
             uint32_t u = wave_or(ps.next(S, slabw), on);
             while (u != 0u) {
@@ -1585,21 +1515,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                     const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                     RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd, dist)) cand |= 1ull << (i + k - base);)
                 }
-#if RT_TORUS_SKIP_CULLED
-                while (RT_ANY(cand != 0ull)) {
-                    bool have = false;
-                    int i = 0;
-                    f3 o, d;
-                    while (cand != 0ull && !have) {
-                        i = base + lane_pop(cand);
-                        have = torus_prepare<CULL>(S.tori()[i], ro, rd, dist, o, d);
-                    }
-                    if (have) {
-                        if (COUNT) cnt.torus_solves++;
-                        if (intersect_torus_local(S.tori()[i], o, d, dist, t)) { shadow = 1.0f; on = false; cand = 0ull; }
-                    }
-                }
-#else
                 while (RT_ANY(cand != 0ull)) {
                     if (cand != 0ull) {
                         const int i = base + lane_pop(cand);
@@ -1609,7 +1524,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                         if (th) { shadow = 1.0f; on = false; cand = 0ull; }
                     }
                 }
-#endif
                 if (!RT_ANY(on)) break;
             }
         }

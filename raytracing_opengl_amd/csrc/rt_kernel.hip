@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 //   HEAVY (WPE = RT_WPE_HEAVY) -- the variant for scenes with many primitives: the candidate tables of rt_device.h (group culls, ray
 //         pencils, slab tables) are compiled in. Round 1 ran it at 7 waves (72 VGPRs, 96 B): every ray walked long tables of scalar
 //         loads and latency hiding was worth more than the spills (quadric-heavy 4K 2530 -> 2440 us). With the tables the scans are
-//         short and carry more state: 6 waves (80 VGPRs, 80 B) 1297 / 2271 us (quadric / torus), 7 (128 B) 1327 / 2266, 5 (no
+//         short and carry more state: 6 waves (80 VGPRs, 80 B then, 64 B in the final kernel) 1297 / 2271 us (quadric / torus), 7 (128 B) 1327 / 2266, 5 (no
 //         scratch) 1303 / 2295, 8 (188 B) 1476 / 2298. Chosen at launch from the primitive count (RTX_OPT_HIGH_OCCUPANCY).
 
 constexpr bool ps_wide(int wpe) { return wpe <= 6; }   // 6 workgroups x 24 KB fit the CU's 160 KB of LDS, 7 do not

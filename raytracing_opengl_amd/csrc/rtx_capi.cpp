@@ -140,7 +140,9 @@ struct rtx_context {
     uint16_t* d_edges = nullptr;     // RG8, zero outside the listed pixels
     uint32_t* d_blend = nullptr;     // RGBA8, zero outside the listed pixels
     uint32_t* d_list = nullptr;      // edge pixels of the current frame
-    uint32_t* d_smaa_count = nullptr;  // two alternating counters
+    uint32_t* d_smaa_count = nullptr;  // two alternating counter sets
+    uint64_t* d_bits = nullptr;      // the edge texture as bit planes (smaa_kernel.h): rows ...
+    uint16_t* d_cbits = nullptr;     // ... and columns
     uint16_t* d_area = nullptr;
     uint8_t* d_search = nullptr;
     hipEvent_t smaa_start = nullptr, smaa_stop = nullptr;
@@ -172,6 +174,8 @@ struct rtx_context {
     int ev_head = 0, ev_pending = 0;
     float last_ms = 0.0f;
     uint32_t launches = 0;
+    uint32_t last_variant = 0, last_tables = 0;   // rtx_stats.kernel_variant / candidate_tables of the last draw
+    bool warned_tables = false;
 };
 
 namespace {
@@ -387,7 +391,22 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     // long primitive tables (quadric-/torus-heavy scenes): the 7-waves-per-SIMD build of the kernel hides the table walks
     const rtpack::Defines& df = ctx->defines;
     const int n_prims = df.sphere_size + df.plane_size + df.surface_size + df.box_size + df.torus_size + df.ring_size;
-    const bool high_occ = ctx->opt_occ < 0 ? n_prims >= 32 : ctx->opt_occ != 0;
+    // (a scene whose packer built ray pencils -- 16 .. 128 quadrics or tori -- takes the many-primitive build whatever its total: the
+    // default build has no code that reads the tables)
+    const bool high_occ = ctx->opt_occ < 0 ? (n_prims >= 32 || (ctx->opt_pencils && ctx->n_pencil > 0)) : ctx->opt_occ != 0;
+    ctx->last_variant = high_occ ? 1u : 0u;
+    ctx->last_tables = 0u;
+    if (high_occ && ctx->opt_cull) {
+        const DevSceneHeader* hd = reinterpret_cast<const DevSceneHeader*>(ctx->blob.data());
+        if (df.surface_size >= 16 || df.torus_size >= 16) ctx->last_tables |= 1u;
+        if (p.pencil_masks) ctx->last_tables |= 2u;
+        if (p.pencil_masks && ctx->blob.size() >= sizeof(DevSceneHeader) && hd->off_slabs != 0u) ctx->last_tables |= 4u;
+    }
+    if ((df.surface_size > RT_PENCIL_MAX_PRIMS || df.torus_size > RT_PENCIL_MAX_PRIMS) && !ctx->warned_tables) {
+        ctx->warned_tables = true;   // once per context: the frame is right, but this scene is outside what the candidate tables hold
+        std::fprintf(stderr, "rtx: %d quadrics / %d tori: more than the %d of a kind the ray-pencil and slab tables hold -- two-level scans with group culls only "
+                             "(same pixels, slower; rtx_stats.candidate_tables)\n", df.surface_size, df.torus_size, (int)RT_PENCIL_MAX_PRIMS);
+    }
     HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream));
     HIP_TRY(hipEventRecord(ctx->ev_stop[e], stream));
     {
@@ -449,6 +468,10 @@ int smaa_alloc(rtx_context* ctx)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_blend), px * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_list), smaa_segment_capacity(ctx->width, ctx->height) * SMAA_SEGMENTS * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * SMAA_SEGMENTS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_bits), smaa_plane_bytes(ctx->width, ctx->height)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_cbits), smaa_col_plane_bytes(ctx->width, ctx->height)));
+    HIP_TRY(hipMemsetAsync(ctx->d_bits, 0, smaa_plane_bytes(ctx->width, ctx->height), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_cbits, 0, smaa_col_plane_bytes(ctx->width, ctx->height), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_edges, 0, px * 2, ctx->stream));      // the sparse passes keep both textures zero outside the
     HIP_TRY(hipMemsetAsync(ctx->d_blend, 0, px * 4, ctx->stream));      // current frame's edge pixels (smaa_kernel.hip)
     HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * SMAA_SEGMENTS * sizeof(uint32_t), ctx->stream));
@@ -480,6 +503,8 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
     b.list = ctx->d_list;
     b.segment_capacity = smaa_segment_capacity(ctx->width, ctx->height);
     b.count = ctx->d_smaa_count;
+    b.bits = ctx->d_bits;
+    b.cbits = ctx->d_cbits;
     b.area = ctx->d_area;
     b.search = ctx->d_search;
     HIP_TRY(hipEventRecord(ctx->smaa_start, stream));
@@ -948,7 +973,8 @@ void rtx_destroy(rtx_context* ctx)
     if (ctx->d_fb_u8) (void)hipFree(ctx->d_fb_u8);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (void* p : {static_cast<void*>(ctx->d_screen), static_cast<void*>(ctx->d_edges), static_cast<void*>(ctx->d_blend), static_cast<void*>(ctx->d_list),
-                    static_cast<void*>(ctx->d_smaa_count), static_cast<void*>(ctx->d_area), static_cast<void*>(ctx->d_search)})
+                    static_cast<void*>(ctx->d_smaa_count), static_cast<void*>(ctx->d_area), static_cast<void*>(ctx->d_search), static_cast<void*>(ctx->d_bits),
+                    static_cast<void*>(ctx->d_cbits)})
         if (p) (void)hipFree(p);
     if (ctx->smaa_start) (void)hipEventDestroy(ctx->smaa_start);
     if (ctx->smaa_stop) (void)hipEventDestroy(ctx->smaa_stop);
@@ -1336,6 +1362,8 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
         HIP_TRY(hipEventElapsedTime(&out->last_gather_ms, ctx->gather_start, ctx->gather_stop));
     }
     out->pencils = ctx->n_pencil;
+    out->kernel_variant = ctx->last_variant;
+    out->candidate_tables = ctx->last_tables;
     if (ctx->pencil_timed) {
         HIP_TRY(hipEventSynchronize(ctx->pencil_stop));
         HIP_TRY(hipEventElapsedTime(&out->last_pencil_build_ms, ctx->pencil_start, ctx->pencil_stop));

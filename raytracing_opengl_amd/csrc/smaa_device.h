@@ -163,10 +163,105 @@ SM_HD uint32_t edge_from_lumas(float threshold, float L, float Ll, float Lt, flo
     return ((e & 1u) ? 0x00ffu : 0u) | ((e & 2u) ? 0xff00u : 0u);
 }
 
+// ---- the orthogonal searches on bit planes ---------------------------------------------------------------------------------------
+// SMAASearchXLeft / XRight / YUp / YDown (SMAA.h:1020-1077) walk a line of edges two texels at a time; every step is a 4-tap bilinear fetch
+// and the walk of a long edge is up to max_steps dependent fetches in each of four directions -- most of pass 2's time. The edge texture
+// holds only 0 and 255, so the dense kernel also writes it as two BIT PLANES (2 bits per pixel: bit 2k = red / left edge, bit 2k + 1 = green
+// / top edge of the k-th pixel of a run) --
+//   rows: plane_words(w) 64-bit words per row, 32 consecutive pixels of the ROW per word;
+//   cols: one 16-bit word per column and block of 8 rows, [y >> 3][x]: 8 consecutive pixels of the COLUMN per word --
+// and the NUMBER OF STEPS a search takes is computed from whole words: six loads for a horizontal search, 24 short ones for a vertical one,
+// all independent, then a few dozen integer instructions, whatever the length of the edge. The search's float arithmetic is not touched:
+// the loop's last fetch -- the one whose value goes into SMAASearchLength -- and everything after it run as before on the texture.
+//
+// Why the count is exact. At step k the loop fetches e = bilinear(edges) at (tx0 -/+ 2k, ty) and goes on while e.g > 0.8281 and e.r == 0
+// (horizontal; vertical: r and g swapped). Positions are exact in texel space: the fractions are (0.75 | 0.25, 0.875) resp. (0.875,
+// 0.75 | 0.25), the four weights are the dyadic products of those, the texels are 0 or 1, so the sums are exact. e.g > 0.8281 holds iff
+// BOTH taps of the upper row (horizontal; weight 0.875 together) have their green bit -- any other combination sums to at most 0.78125
+// --, e.r == 0 iff none of the four taps has its red bit. With ok[c] = G[y][c] & ~R[y][c] & ~R[y - 1][c] the step at column c goes on
+// iff ok[c] & ok[c + 1]. The loop consumes n = min(max_steps, f + 1) fetches, f = the first step that fails. (Checked against the
+// per-step loop on every edge pixel of the test patterns: tests/test_smaa_host.py; the host build can run both and compare.)
+// Only for pixels whose whole search window lies inside the frame (no index is clamped); the others take the per-step loop.
+struct SearchPlanes {
+    const uint64_t* rows;    // h x plane_words(w); nullptr = no planes (host reference build): every search takes the per-step loop
+    const uint16_t* cols;    // ((h + 7) / 8) x w
+    int w, h;
+    SM_HDM static int plane_words(int w) { return (w + 31) >> 5; }
+    // first failing step among offsets o0, o0 +/- 2, ... (S of them) of the 96-position string `pair` (bit 2o = step at offset o goes on)
+    SM_HDM static int first_fail(const uint64_t pair[3], int o0, int S, bool down)
+    {
+        const uint64_t M = 0x5555555555555555ull;
+        const uint64_t par = (o0 & 1) ? 0x4444444444444444ull : 0x1111111111111111ull;
+        const int o_lo = down ? o0 - 2 * (S - 1) : o0, o_hi = down ? o0 : o0 + 2 * (S - 1);
+        uint64_t fail[3];
+        for (int k = 0; k < 3; k++) {
+            const int lo = o_lo - 32 * k, hi = o_hi - 32 * k;
+            const uint64_t from = lo <= 0 ? ~0ull : (lo >= 32 ? 0ull : (~0ull << (2 * lo)));
+            const uint64_t to = hi < 0 ? 0ull : (hi >= 31 ? ~0ull : ((1ull << (2 * hi + 2)) - 1ull));
+            fail[k] = ~pair[k] & M & par & from & to;
+        }
+        if (down) {   // steps walk towards smaller offsets: the first failing one is the HIGHEST
+            for (int k = 2; k >= 0; k--)
+                if (fail[k] != 0ull) return (o0 - (32 * k + (63 - __builtin_clzll(fail[k])) / 2)) / 2;
+        } else {
+            for (int k = 0; k < 3; k++)
+                if (fail[k] != 0ull) return ((32 * k + __builtin_ctzll(fail[k]) / 2) - o0) / 2;
+        }
+        return S;
+    }
+    SM_HDM static void pair_of(const uint64_t ok[3], uint64_t pair[3])
+    {
+        pair[0] = ok[0] & ((ok[0] >> 2) | (ok[1] << 62));
+        pair[1] = ok[1] & ((ok[1] >> 2) | (ok[2] << 62));
+        pair[2] = ok[2] & (ok[2] >> 2);
+    }
+    // fetches the loop of search_x consumes for pixel (x, y): dir < 0 left, > 0 right; -1 = window not inside the frame
+    SM_HDM int count_x(int x, int y, int S, bool left) const
+    {
+        if (rows == nullptr || y < 1) return -1;
+        const int c_lo = left ? x - 1 - 2 * (S - 1) : x + 1, c_hi = left ? x : x + 2 + 2 * (S - 1);
+        if (c_lo < 0 || c_hi > w - 1) return -1;
+        const int pw = plane_words(w), w0 = c_lo >> 5;
+        const uint64_t M = 0x5555555555555555ull;
+        uint64_t ok[3], pair[3];
+        for (int k = 0; k < 3; k++) {
+            const int q = w0 + k < pw ? w0 + k : pw - 1;
+            const uint64_t q1 = rows[(size_t)y * pw + q], q0 = rows[(size_t)(y - 1) * pw + q];
+            ok[k] = (q1 >> 1) & ~q1 & ~q0 & M;
+        }
+        pair_of(ok, pair);
+        const int f = first_fail(pair, (left ? x - 1 : x + 1) - 32 * w0, S, left);
+        return f + 1 < S ? f + 1 : S;
+    }
+    // the same for search_y: up = towards smaller y
+    SM_HDM int count_y(int x, int y, int S, bool up) const
+    {
+        if (rows == nullptr || x < 1) return -1;
+        const int r_lo = up ? y - 1 - 2 * (S - 1) : y + 1, r_hi = up ? y : y + 2 + 2 * (S - 1);
+        if (r_lo < 0 || r_hi > h - 1) return -1;
+        const int nb = (h + 7) >> 3, b0 = r_lo >> 3;
+        const uint64_t M = 0x5555555555555555ull;
+        uint64_t ok[3], pair[3];
+        for (int k = 0; k < 3; k++) {
+            uint64_t qa = 0ull, qb = 0ull;
+            for (int m = 0; m < 4; m++) {
+                const int blk = b0 + 4 * k + m < nb ? b0 + 4 * k + m : nb - 1;
+                qa |= (uint64_t)cols[(size_t)blk * w + x - 1] << (16 * m);
+                qb |= (uint64_t)cols[(size_t)blk * w + x] << (16 * m);
+            }
+            ok[k] = qb & ~(qa >> 1) & ~(qb >> 1) & M;     // red of column x, no green in either column
+        }
+        pair_of(ok, pair);
+        const int f = first_fail(pair, (up ? y - 1 : y + 1) - 8 * b0, S, up);
+        return f + 1 < S ? f + 1 : S;
+    }
+};
+
 // ---- pass 2: blending weights (SMAA.h:835-1243) --------------------------------------------------------------
 struct Blend {
     const Views& V;
     const Preset& P;
+    const SearchPlanes& planes;   // bit planes of the edge texture for the orthogonal searches (rows == nullptr: per-step loops only)
 
     SM_HDM F2 edges_at(float tx, float ty, int ox = 0, int oy = 0) const { return sample_rg(V.edges, V.w, V.h, tx, ty, ox, oy); }
 
@@ -287,10 +382,15 @@ struct Blend {
         return sample_r8(V.search, SEARCH_W, SEARCH_H, 32.0f * ex + 66.0f * offset, -32.0f * ey + 32.0f);
     }
     // SMAASearchXLeft / XRight / YUp / YDown (SMAA.h:1020-1077): two texels per step from (tx, ty) towards `end`
-    SM_HDM float search_x(float tx, float ty, float end, float dir) const
+    SM_HDM float search_x(float tx, float ty, float end, float dir, int x, int y) const
     {
         F2 e{0.0f, 1.0f};
         const float stepx = (dir * 2.0f) * 1.0f;
+        const int n = planes.count_x(x, y, P.max_steps, dir < 0.0f);
+        if (n > 0) {      // the loop below would consume n fetches: its last one, and where it leaves tx (stepx * k is exact: small dyadic numbers)
+            e = edges_at(stepx * (float)(n - 1) + tx, ty);
+            tx = stepx * (float)n + tx;
+        } else
         while ((dir < 0.0f ? tx > end : tx < end) && e.y > 0.8281f && e.x == 0.0f) {
             F2 s[SEARCH_BATCH];
             float px = tx;
@@ -306,10 +406,15 @@ struct Blend {
         const float off = -(255.0f / 127.0f) * search_length(e.x, e.y, dir < 0.0f ? 0.0f : 0.5f) + 3.25f;
         return (-dir) * off + tx;
     }
-    SM_HDM float search_y(float tx, float ty, float end, float dir) const
+    SM_HDM float search_y(float tx, float ty, float end, float dir, int x, int y) const
     {
         F2 e{1.0f, 0.0f};
         const float stepy = (dir * 2.0f) * 1.0f;
+        const int n = planes.count_y(x, y, P.max_steps, dir < 0.0f);
+        if (n > 0) {
+            e = edges_at(tx, stepy * (float)(n - 1) + ty);
+            ty = stepy * (float)n + ty;
+        } else
         while ((dir < 0.0f ? ty > end : ty < end) && e.x > 0.8281f && e.y == 0.0f) {
             F2 s[SEARCH_BATCH];
             float py = ty;
@@ -360,10 +465,11 @@ struct Blend {
     SM_HDM float ortho_search(int k, float X, float Y) const
     {
         const float S = (float)P.max_steps;
-        if (k == 0) return search_x(X - 0.25f, Y - 0.125f, (-2.0f * S) * 1.0f + (X - 0.25f), -1.0f);
-        if (k == 1) return search_x(X + 1.25f, Y - 0.125f, (2.0f * S) * 1.0f + (X + 1.25f), 1.0f);
-        if (k == 2) return search_y(X - 0.125f, Y - 0.25f, (-2.0f * S) * 1.0f + (Y - 0.25f), -1.0f);
-        return search_y(X - 0.125f, Y + 1.25f, (2.0f * S) * 1.0f + (Y + 1.25f), 1.0f);
+        const int x = (int)X, y = (int)Y;
+        if (k == 0) return search_x(X - 0.25f, Y - 0.125f, (-2.0f * S) * 1.0f + (X - 0.25f), -1.0f, x, y);
+        if (k == 1) return search_x(X + 1.25f, Y - 0.125f, (2.0f * S) * 1.0f + (X + 1.25f), 1.0f, x, y);
+        if (k == 2) return search_y(X - 0.125f, Y - 0.25f, (-2.0f * S) * 1.0f + (Y - 0.25f), -1.0f, x, y);
+        return search_y(X - 0.125f, Y + 1.25f, (2.0f * S) * 1.0f + (Y + 1.25f), 1.0f, x, y);
     }
     SM_HDM F2 north_from(float X, float Y, float cx, float cz) const   // weights.rg from the ends of the two x searches
     {

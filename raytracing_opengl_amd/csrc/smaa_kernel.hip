@@ -8,7 +8,11 @@
 //                        edges (SMAA.h:689-741) on a four-row window of lumas held in registers and, for edge pixels only, writes the
 //                        RG8 edge texel and appends the pixel to a list -- one atomic per 256 x 8 strip (ballot ranks), none for the
 //                        strips without an edge;
-//   smaa_weights_kernel  over the list: blending weights (SMAA.h:1145-1243) -> RGBA8 weight texel of that pixel;
+//                        It also writes the edge texture a second time as two BIT PLANES (2 bits per pixel: one byte per lane and row,
+//                        32 pixels of a row per 64-bit word; and 16 bits per column and strip, 8 pixels of a column) -- dense, 2 x 2 MB at 4K;
+//   smaa_weights_kernel  over the list, one thread per listed pixel: blending weights (SMAA.h:1145-1243) -> RGBA8 weight texel. The step
+//                        counts of the four orthogonal searches come from the bit planes (smaa_device.h SearchPlanes), the rest from the
+//                        RG8 texture as before. (Round 2 walked every edge: up to 32 dependent 4-tap fetches per direction.)
 //   smaa_blend_kernel    over the list: neighbourhood blending (SMAA.h:1252-1300) of the listed pixel, its left and its lower
 //                        neighbour -- the only pixels whose four weights can be non-zero -- overwriting their screen texels;
 //   smaa_clear_kernel    over the PREVIOUS frame's list: zeroes the edge and weight texels it wrote.
@@ -177,6 +181,39 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #if SMAA_ABL & 16
     if (threshold > -1.0e30f) { if (ebits[0] == 0x123456789abcdefull) screen[0] = 1; return; }   // keep the arithmetic alive, skip the append
 #endif
+    // the bit planes (dense: edge-free strips write their zeros too, so the planes need no clearing). Rows: this lane's four pixels of a
+    // row are one byte, 64 lanes = 64 consecutive bytes. Columns: per 8-row block and column 16 bits, this lane's four columns = 8 bytes.
+    {
+        const int pw8 = smaa::SearchPlanes::plane_words(w) * 8;                              // bytes per row-plane row
+        uint8_t* const plane = reinterpret_cast<uint8_t*>(b.bits);
+        const int byte_x = px >> 2;
+        if (byte_x < pw8) {
+#pragma unroll
+            for (int r = 0; r < STRIP_H; r++)
+                if (y0 + r < h) plane[(size_t)(y0 + r) * pw8 + byte_x] = (uint8_t)(ebits[r >> 3] >> ((r & 7) * 8));
+        }
+#pragma unroll
+        for (int blk = 0; blk < (STRIP_H + 7) / 8; blk++) {
+            if (y0 + blk * 8 >= h) break;                                      // wave-uniform
+            const unsigned long long eb = ebits[blk];                          // (STRIP_H = 4: the upper half of the block stays zero here,
+            uint16_t col[4];                                                   //  see smaa_launch: the column plane needs strips of 8 or 16 rows)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned v = 0;
+#pragma unroll
+                for (int r = 0; r < 8; r++) v |= (unsigned)((eb >> (r * 8 + 2 * k)) & 3ull) << (2 * r);
+                col[k] = (uint16_t)v;
+            }
+            uint16_t* const dst = b.cbits + (size_t)((y0 >> 3) + blk) * w + px;
+            if (vec_ok) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)col[0] | ((unsigned)col[1] << 16), (unsigned)col[2] | ((unsigned)col[3] << 16));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (px + k < w) dst[k] = col[k];
+            }
+        }
+    }
     if (__ballot((ebits[0] | ebits[1]) != 0) == 0) return;                     // wave-uniform: most strips leave here
     const unsigned long long any[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
     unsigned total = (unsigned)__popcll(any[0]) + (unsigned)__popcll(any[1]);  // bit 2s of any[] set <=> pixel slot s has an edge
@@ -225,13 +262,20 @@ struct SegmentedList {
         __syncthreads();
         return prefix[SMAA_SEGMENTS];
     }
-    __device__ __forceinline__ uint32_t entry(const SmaaBuffers& b, unsigned i) const
+    __device__ __forceinline__ unsigned locate(unsigned i, unsigned& within) const   // flat index -> segment, index within it
     {
         unsigned lo = 0;                                                  // largest seg with prefix[seg] <= i
 #pragma unroll
         for (int bit = 32; bit > 0; bit >>= 1)
             if (prefix[lo + bit] <= i) lo += bit;
-        return b.list[(size_t)lo * b.segment_capacity + (i - prefix[lo])];
+        within = i - prefix[lo];
+        return lo;
+    }
+    __device__ __forceinline__ uint32_t entry(const SmaaBuffers& b, unsigned i) const
+    {
+        unsigned k;
+        const unsigned seg = locate(i, k);
+        return b.list[(size_t)seg * b.segment_capacity + k];
     }
 };
 
@@ -246,10 +290,13 @@ __global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned
     }
 }
 
-// Blending weights, one thread per listed pixel. (A four-lanes-per-pixel form -- the four searches of a round in parallel lanes, results
-// exchanged by cross-lane moves; smaa::Blend keeps the pieces it used: diag_search / ortho_search / north_from / west_from -- was byte-exact
-// and no faster on sparse frames, twice slower on dense ones: the kernel is bound by the cache-line look-ups of its scattered 2-byte taps,
-// not by the length of a pixel's dependent chain. profiles/r02_smaa_ablation.txt)
+// Blending weights, one thread per listed pixel. The four orthogonal searches of a pixel do not walk their edge: the number of steps comes
+// from whole words of the two bit planes (smaa::SearchPlanes -- six / 24 independent loads and a few dozen integer instructions whatever
+// the edge's length), and only the search's LAST fetch, the one SMAASearchLength reads, is made on the texture. Tried and dropped on the way
+// (profiles/r03_smaa.txt): one wave per strip with the plane around the strip staged in LDS -- byte-exact, 5x SLOWER (256 us): a strip's
+// pixels then run one after the other in one wave at two waves per SIMD, and the strips' work differs by three orders of magnitude; every
+// edge fetch from the planes through a register window -- byte-exact, 2.5x slower (116 us): 25 instructions per tap instead of a load, and
+// at one wave per SIMD the kernel is bound by what one wave issues; and, in round 2, four lanes per pixel on the texture path.
 __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int preset, unsigned cur)
 {
     __shared__ SegmentedList L;
@@ -257,7 +304,8 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
     if (blockIdx.x == 0 && threadIdx.x < SMAA_SEGMENTS) b.count[(cur ^ 1u) * SMAA_SEGMENTS + threadIdx.x] = 0;   // free for the next frame's appends
     const smaa::Preset P = smaa::preset_of(preset);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
-    const smaa::Blend B{V, P};
+    const smaa::SearchPlanes planes{b.bits, b.cbits, b.w, b.h};
+    const smaa::Blend B{V, P, planes};
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = L.entry(b, i);
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
@@ -295,7 +343,7 @@ int smaa_strip_count(int w, int h, int strip_h)
 }
 static int strip_rows()
 {
-    static const int v = [] { const char* e = getenv("RTX_SMAA_STRIP_H"); const int x = e ? atoi(e) : STRIP_H_DEFAULT; return (x == 4 || x == 8 || x == 16) ? x : STRIP_H_DEFAULT; }();   // A/B knob
+    static const int v = [] { const char* e = getenv("RTX_SMAA_STRIP_H"); const int x = e ? atoi(e) : STRIP_H_DEFAULT; return (x == 8 || x == 16) ? x : STRIP_H_DEFAULT; }();   // A/B knob (the column bit plane is written per block of 8 rows)
     return v;
 }
 size_t smaa_segment_capacity(int w, int h)
@@ -305,6 +353,9 @@ size_t smaa_segment_capacity(int w, int h)
     return (size_t)((strips + SMAA_SEGMENTS - 1) / SMAA_SEGMENTS) * (size_t)(STRIP_W * strip_h);
 }
 
+size_t smaa_plane_bytes(int w, int h) { return (size_t)smaa::SearchPlanes::plane_words(w) * 8u * (size_t)h; }
+size_t smaa_col_plane_bytes(int w, int h) { return (size_t)((h + 7) / 8) * (size_t)w * 2u + 16u; }
+
 hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream)
 {
     const unsigned cur = frame & 1u, prev = cur ^ 1u;
@@ -313,8 +364,7 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const int strip_h = strip_rows();
     const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
     const float thr = smaa::preset_of(preset).threshold;
-    if (strip_h == 4) hipLaunchKernelGGL(smaa_edges_kernel<4>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
-    else if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
+    if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
     else hipLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
     hipLaunchKernelGGL(smaa_weights_kernel, sparse, dim3(256), 0, stream, b, preset, cur);
     hipLaunchKernelGGL(smaa_blend_kernel, sparse, dim3(256), 0, stream, b, cur);

@@ -7,6 +7,10 @@
 
 #include "smaa_device.h"
 
+#include <vector>
+
+static int use_planes = 1;   // 0: every orthogonal search takes the per-step loop (the form the planes' step count is checked against)
+extern "C" void harness_smaa_use_planes(int on) { use_planes = on; }
 extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, const uint16_t* area, const uint8_t* search, uint16_t* edges,
                             uint32_t* blend, uint32_t* screen)
 {
@@ -23,7 +27,20 @@ extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, con
             edges[(size_t)y * w + x] = (uint16_t)smaa::edge_from_lumas(P.threshold, luma(x, y), luma(x - 1, y), luma(x, y - 1), luma(x + 1, y), luma(x, y + 1),
                                                                        luma(x - 2, y), luma(x, y - 2));
     const smaa::Views V{w, h, color, edges, blend, area, search};
-    const smaa::Blend B{V, P};
+    // the bit planes of the edge texture, as the dense HIP kernel writes them (smaa_kernel.hip): the orthogonal searches count their steps
+    // on these (smaa::SearchPlanes), exactly like the weight kernel
+    const int pw = smaa::SearchPlanes::plane_words(w);
+    std::vector<uint64_t> prow((size_t)pw * h, 0ull);
+    std::vector<uint16_t> pcol((size_t)((h + 7) / 8) * w, 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint16_t e = edges[(size_t)y * w + x];
+            const uint64_t two = ((e & 0x00ffu) ? 1ull : 0ull) | ((e & 0xff00u) ? 2ull : 0ull);
+            prow[(size_t)y * pw + (x >> 5)] |= two << (2 * (x & 31));
+            pcol[(size_t)(y >> 3) * w + x] |= (uint16_t)(two << (2 * (y & 7)));
+        }
+    const smaa::SearchPlanes planes{use_planes ? prow.data() : nullptr, pcol.data(), w, h};
+    const smaa::Blend B{V, P, planes};
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? B.weights(x, y) : 0u;

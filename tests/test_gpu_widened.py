@@ -263,3 +263,30 @@ def test_candidate_tables_follow_scene_updates(built, small_textures):
     assert (a0.view(np.uint32) != a1.view(np.uint32)).any(-1).mean() > 0.2          # the scene did change
     assert np.array_equal(a1.view(np.uint32), b.view(np.uint32))                   # updated context, tables rebuilt == literal scans of a fresh one
     assert np.array_equal(a2.view(np.uint32), b.view(np.uint32))                   # tables off
+
+
+def test_stats_say_which_kernel_and_candidate_tables_a_scene_got(small_textures):
+    """rtx_stats.kernel_variant / candidate_tables: no silent cliffs -- a scene with ray pencils always runs the many-primitive build
+    (also below 32 primitives in total), the default scene the default one without tables, and switching the pencils off shows."""
+    import random_scenes
+    w, h = 160, 96
+    gl = wrapper.make_renderer(scenes.build_scene("default", w, h, 2), w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.draw()
+    st = gl.stats()
+    assert (st["kernel_variant"], st["candidate_tables"], st["pencils"]) == (0, 0, 0)
+    gl.stop()
+    seen = set()
+    for seed in range(12):
+        sc = random_scenes.crowd_scene(seed, w, h)
+        gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+        gl.draw()
+        st = gl.stats()
+        n_long = max(sc.defines[2], sc.defines[4])
+        if st["pencils"] > 0:
+            assert st["kernel_variant"] == 1 and (st["candidate_tables"] & 6) == 6 and 16 <= n_long <= 128, (seed, st, sc.defines[:6])
+            seen.add(sum(sc.defines[:6]) >= 32)
+            gl.set_option(wrapper.RTX_OPT_RAY_PENCILS, 0)
+            gl.draw()
+            assert (gl.stats()["candidate_tables"] & 6) == 0
+        gl.stop()
+    assert seen, "no crowd scene with ray pencils among the seeds"

@@ -45,6 +45,36 @@ def test_random_tables_and_noise_byte_exact(built):
         _same(harness.smaa(img, smaa.PRESETS[k], area, search), smaa.run(img, smaa.PRESETS[k], area, search))
 
 
+@pytest.mark.parametrize("preset", smaa.PRESETS)
+def test_step_counts_from_the_bit_planes_change_nothing(built, tables, preset):
+    """The HIP weight kernel computes how many steps an orthogonal search takes from whole words of two bit planes (smaa_device.h
+    SearchPlanes) instead of walking the edge: with and without them the host build must produce the oracle's textures byte for byte -- on
+    lines much longer than 2 x max_steps in both axes (full-length searches in all four directions), lines that end inside the window at
+    every offset and parity, crossings, frame borders (where the per-step loop takes over), widths that are not multiples of 32 and
+    heights that are not multiples of 8."""
+    rng = np.random.default_rng(3)
+    cases = [smaa_cases.pattern(7, 600, 90), smaa_cases.pattern(8, 97, 300)]
+    long_lines = np.full((150, 700, 4), 255, np.uint8)
+    long_lines[::37, :, :3] = 0
+    long_lines[:, ::53, :3] = 0
+    long_lines[70:, 300:, 1] = 90
+    for k in range(140):
+        long_lines[5 + k, 20 + k:23 + k, :3] = 30
+    cases.append(long_lines)
+    ends = np.full((260, 420, 4), 255, np.uint8)            # horizontal and vertical runs of every length 1..100 at shifting offsets
+    for k in range(100):
+        ends[2 * k + 3, 40 + (k % 7): 40 + (k % 7) + k + 1, :3] = 10
+        ends[20 + (k % 5): 20 + (k % 5) + k + 1, 200 + 2 * k, :3] = 10
+    cases.append(ends)
+    noise = rng.integers(0, 256, (70, 300, 4), dtype=np.uint8)
+    noise[..., :3] = (noise[..., :3] // 128) * 128
+    cases.append(noise)
+    for img in cases:
+        want = smaa.run(img, preset, *tables)
+        _same(harness.smaa(img, preset, *tables, planes=True), want)
+        _same(harness.smaa(img, preset, *tables, planes=False), want)
+
+
 def test_divide_free_unorm8_is_exact(built):
     import ctypes
     lib = harness.lib()

@@ -17,7 +17,8 @@ def child(scene_names, steps):
     ts = textures.default_texture_set()
     out = []
     for name in scene_names:
-        sc = scenes.build_scene(name, 3840, 2160, 4)
+        name, _, depth = name.partition(":")          # "torus:6" = the torus scene at reflection depth 6 (default 4)
+        sc = scenes.build_scene(name, 3840, 2160, int(depth or 4))
         gl = wrapper.make_renderer(sc, 3840, 2160, ts["textures"], ts["cubemap"])
         for _ in range(3):
             gl.draw()

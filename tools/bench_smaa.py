@@ -26,8 +26,11 @@ def main():
     traced = gl.read_pixels(wrapper.RTX_RGBA8)
     gl.set_smaa_tables(area, search)
     frames = {"traced default scene": traced, "synthetic pattern": np.tile(smaa_cases.pattern(41, 960, 540), (4, 4, 1))}
+    only = os.environ.get("ONLY")          # e.g. ONLY=traced:ULTRA for a PMC pass of one configuration
     for name, img in frames.items():
         for preset in ("LOW", "MEDIUM", "HIGH", "ULTRA"):
+            if only and only != f"{name.split()[0]}:{preset}":
+                continue
             gl.enable_SMAA(preset)
             gl.write_pixels(img)
             times = []

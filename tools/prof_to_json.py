@@ -52,6 +52,13 @@ stamp = dict(kernel=KERNEL, kernel_hash=build_info.kernel_source_hash(), scene=s
 valu = dict(stamp, valu_insts_per_launch=int(mean["SQ_INSTS_VALU"]), salu_insts_per_launch=int(mean.get("SQ_INSTS_SALU", 0)),
             active_inst_valu_quad_cycles=int(mean.get("SQ_ACTIVE_INST_VALU", 0)), thread_cycles_valu=int(mean.get("SQ_THREAD_CYCLES_VALU", 0)),
             busy_cu_cycles=int(mean.get("SQ_BUSY_CU_CYCLES", 0)), grbm_gui_active=int(mean.get("GRBM_GUI_ACTIVE", 0)))
+# instruction classes (pass "mix"): what the mix-weighted issue ceiling is computed from. "other" = everything the class counters do not
+# name: v_mov, v_cmp, v_cndmask, v_min / v_max / v_med3, v_readlane / v_writelane, DPP moves, bit operations counted nowhere else.
+classes = {k: int(mean.get("SQ_INSTS_VALU_" + c, 0)) for k, c in (("add_f32", "ADD_F32"), ("mul_f32", "MUL_F32"), ("fma_f32", "FMA_F32"),
+                                                                   ("trans_f32", "TRANS_F32"), ("int32", "INT32"), ("int64", "INT64"), ("cvt", "CVT"))}
+if any(classes.values()):
+    classes["other"] = max(0, valu["valu_insts_per_launch"] - sum(classes.values()))
+    valu["classes"] = classes
 if valu["active_inst_valu_quad_cycles"]:
     valu["lane_utilisation"] = round(valu["thread_cycles_valu"] / (64.0 * valu["active_inst_valu_quad_cycles"]), 4)
     valu["cycles_per_valu_inst"] = round(4.0 * valu["active_inst_valu_quad_cycles"] / valu["valu_insts_per_launch"], 3)

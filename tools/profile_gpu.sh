@@ -26,6 +26,8 @@ pass cache SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DU
 pass level SQ_IFETCH_LEVEL SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_VMEM_RD
 fi
 pass valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE
+# instruction classes, for the mix-weighted issue ceiling (tools/prof_to_json.py -> bench.py roofline.valu)
+pass mix SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 cd "$REPO"
