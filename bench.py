@@ -87,7 +87,16 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
         gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank, texture_lod=args.lod,
                                    gather=gather_kind, rank=(rank, n_ranks, uid[0]))
     else:
-        gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod, devices=list(range(n_ranks)), gather=gather_kind)
+        try:
+            gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod, devices=list(range(n_ranks)), gather=gather_kind)
+        except wrapper.RtxError as e:
+            if args.transport != "rccl" or "rccl" not in str(e).lower():
+                raise
+            # no usable RCCL on this box: the same bands over the same links with hipMemcpyPeerAsync issued by rank 0 -- said loudly, and in the line
+            print(f"bench.py: RCCL transport unavailable ({e}); falling back to --transport peer", file=sys.stderr, flush=True)
+            args.transport = "peer"
+            gather_kind = wrapper.RTX_GATHER_PEER_COPY
+            gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod, devices=list(range(n_ranks)), gather=gather_kind)
     target = args.target
     px_bytes = 16 if target == "rgba32f" else 4
     gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 1 if target == "rgba32f" else 2)
