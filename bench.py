@@ -66,26 +66,20 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     per_process = mode == "ranks"
     multi_proc = per_process and n_ranks > 1
 
-    def barrier():
-        if multi_proc:
-            dist.barrier()
+    from raytracing_opengl_amd import ranks   # rendezvous only: unique id, barrier, max / sum of a few numbers (gloo, CPU tensors)
+
+    barrier = ranks.barrier
 
     def reduce_(values, op):
-        if not multi_proc:
-            return list(values)
-        t = torch.tensor(list(values), dtype=torch.float64)
-        dist.all_reduce(t, op=op)
-        return [float(v) for v in t]
+        return ranks.reduce_values(values, "max" if op == dist.ReduceOp.MAX else "sum")
 
     gather_kind = {"rccl": wrapper.RTX_GATHER_RCCL, "peer": wrapper.RTX_GATHER_PEER_COPY, "loopback": wrapper.RTX_GATHER_RCCL_LOOPBACK}[args.transport]
     sc = scenes.build_scene(args.scene, W, H, args.depth)
     ts = textures.default_texture_set(scale=args.texture_scale)
     if per_process:
-        uid = [wrapper.rccl_unique_id() if rank == 0 else None]
-        if multi_proc:
-            dist.broadcast_object_list(uid, src=0)
+        uid = ranks.exchange_unique_id(rank, wrapper.rccl_unique_id)
         gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], device=local_rank, texture_lod=args.lod,
-                                   gather=gather_kind, rank=(rank, n_ranks, uid[0]))
+                                   gather=gather_kind, rank=(rank, n_ranks, uid))
     else:
         try:
             gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod, devices=list(range(n_ranks)), gather=gather_kind)

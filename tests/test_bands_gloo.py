@@ -101,3 +101,51 @@ def test_unpermute_irregular():
             off += y1 - y0
         parts.append(buf)
     assert torch.equal(bands.unpermute(parts, h, rows, world), full)
+
+
+# ---- the rendezvous of the one-process-per-GPU form (rtx_create_rank under torch.distributed.run; bench.py) -------------------------
+def _rendezvous_worker(rank, world, port, q):
+    from raytracing_opengl_amd import ranks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def make_id():                       # stands for rtx_rccl_unique_id: must run on rank 0 ONLY
+            calls.append(rank)
+            return bytes((7 * k + 3) % 256 for k in range(128))
+
+        uid = ranks.exchange_unique_id(rank, make_id)
+        rays = ranks.reduce_values([1000 + rank, 3], "sum")      # per-rank ray counts -> the frame's
+        worst = ranks.reduce_values([0.5 + 0.25 * rank, 2.0 - rank], "max")   # elapsed / trace time: the slowest rank's
+        ranks.barrier()
+        q.put((rank, uid, calls, rays, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_rendezvous_hands_the_unique_id_round_and_reduces():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = bytes((7 * k + 3) % 256 for k in range(128))
+    assert [r[1] for r in results] == [want, want]
+    assert results[0][2] == [0] and results[1][2] == []          # the id was created on rank 0 only
+    assert all(r[3] == [2001.0, 6.0] and r[4] == [0.75, 2.0] for r in results)
+
+
+def test_rank_rendezvous_on_one_rank_is_the_identity():
+    from raytracing_opengl_amd import ranks
+    assert ranks.exchange_unique_id(0, lambda: bytes(128)) == bytes(128)
+    assert ranks.reduce_values([3, 4.5], "sum") == [3.0, 4.5]
+    ranks.barrier()
+    with pytest.raises(ValueError):
+        ranks.exchange_unique_id(0, lambda: b"short")
