@@ -216,46 +216,45 @@ struct SearchPlanes {
         pair[2] = ok[2] & (ok[2] >> 2);
     }
     // fetches the loop of search_x consumes for pixel (x, y): dir < 0 left, > 0 right; -1 = window not inside the frame
-    // (Straight-line on purpose: the indices are clamped so that the loads are always legal and the verdict is applied at the end -- two
-    //  calls in a row, left + right or up + down, then have all their loads in flight together.)
     SM_HDM int count_x(int x, int y, int S, bool left) const
     {
+        if (rows == nullptr || y < 1) return -1;
         const int c_lo = left ? x - 1 - 2 * (S - 1) : x + 1, c_hi = left ? x : x + 2 + 2 * (S - 1);
-        const bool inside = y >= 1 && c_lo >= 0 && c_hi <= w - 1;
-        const int pw = plane_words(w), w0 = (c_lo < 0 ? 0 : (c_lo > w - 1 ? w - 1 : c_lo)) >> 5, yc = h < 2 ? 1 : (y < 1 ? 1 : (y > h - 1 ? h - 1 : y));
+        if (c_lo < 0 || c_hi > w - 1) return -1;
+        const int pw = plane_words(w), w0 = c_lo >> 5;
         const uint64_t M = 0x5555555555555555ull;
         uint64_t ok[3], pair[3];
         for (int k = 0; k < 3; k++) {
             const int q = w0 + k < pw ? w0 + k : pw - 1;
-            const uint64_t q1 = rows[(size_t)yc * pw + q], q0 = rows[(size_t)(yc - 1) * pw + q];
+            const uint64_t q1 = rows[(size_t)y * pw + q], q0 = rows[(size_t)(y - 1) * pw + q];
             ok[k] = (q1 >> 1) & ~q1 & ~q0 & M;
         }
         pair_of(ok, pair);
         const int f = first_fail(pair, (left ? x - 1 : x + 1) - 32 * w0, S, left);
-        return inside ? (f + 1 < S ? f + 1 : S) : -1;
+        return f + 1 < S ? f + 1 : S;
     }
     // the same for search_y: up = towards smaller y
     SM_HDM int count_y(int x, int y, int S, bool up) const
     {
+        if (rows == nullptr || x < 1) return -1;
         const int r_lo = up ? y - 1 - 2 * (S - 1) : y + 1, r_hi = up ? y : y + 2 + 2 * (S - 1);
-        const bool inside = x >= 1 && r_lo >= 0 && r_hi <= h - 1;
-        const int nb = (h + 7) >> 3, b0 = (r_lo < 0 ? 0 : (r_lo > h - 1 ? h - 1 : r_lo)) >> 3, xc = w < 2 ? 1 : (x < 1 ? 1 : (x > w - 1 ? w - 1 : x));
+        if (r_lo < 0 || r_hi > h - 1) return -1;
+        const int nb = (h + 7) >> 3, b0 = r_lo >> 3;
         const uint64_t M = 0x5555555555555555ull;
         uint64_t ok[3], pair[3];
         for (int k = 0; k < 3; k++) {
             uint64_t qa = 0ull, qb = 0ull;
             for (int m = 0; m < 4; m++) {
                 const int blk = b0 + 4 * k + m < nb ? b0 + 4 * k + m : nb - 1;
-                qa |= (uint64_t)cols[(size_t)blk * w + xc - 1] << (16 * m);
-                qb |= (uint64_t)cols[(size_t)blk * w + xc] << (16 * m);
+                qa |= (uint64_t)cols[(size_t)blk * w + x - 1] << (16 * m);
+                qb |= (uint64_t)cols[(size_t)blk * w + x] << (16 * m);
             }
             ok[k] = qb & ~(qa >> 1) & ~(qb >> 1) & M;     // red of column x, no green in either column
         }
         pair_of(ok, pair);
         const int f = first_fail(pair, (up ? y - 1 : y + 1) - 8 * b0, S, up);
-        return inside ? (f + 1 < S ? f + 1 : S) : -1;
+        return f + 1 < S ? f + 1 : S;
     }
-    SM_HDM bool available() const { return rows != nullptr; }
 };
 
 // ---- pass 2: blending weights (SMAA.h:835-1243) --------------------------------------------------------------
@@ -387,7 +386,7 @@ struct Blend {
     {
         F2 e{0.0f, 1.0f};
         const float stepx = (dir * 2.0f) * 1.0f;
-        const int n = planes.available() ? planes.count_x(x, y, P.max_steps, dir < 0.0f) : -1;
+        const int n = planes.count_x(x, y, P.max_steps, dir < 0.0f);
         if (n > 0) {      // the loop below would consume n fetches: its last one, and where it leaves tx (stepx * k is exact: small dyadic numbers)
             e = edges_at(stepx * (float)(n - 1) + tx, ty);
             tx = stepx * (float)n + tx;
@@ -411,7 +410,7 @@ struct Blend {
     {
         F2 e{1.0f, 0.0f};
         const float stepy = (dir * 2.0f) * 1.0f;
-        const int n = planes.available() ? planes.count_y(x, y, P.max_steps, dir < 0.0f) : -1;
+        const int n = planes.count_y(x, y, P.max_steps, dir < 0.0f);
         if (n > 0) {
             e = edges_at(tx, stepy * (float)(n - 1) + ty);
             ty = stepy * (float)n + ty;
@@ -492,34 +491,6 @@ struct Blend {
         corners(wgt, X, cy, X, cz, d1, d2, false);
         return wgt;
     }
-    // Both searches of an axis at once, for the common pixel whose two windows lie inside the frame: the step counts of both directions
-    // first (all their plane words in flight together), then both last fetches, then both SMAASearchLength look-ups -- the same values as
-    // two ortho_search calls, three dependent round trips instead of six. false: take the two searches one after the other.
-    SM_HDM bool ortho_pair(bool vertical, float X, float Y, float& c_lo, float& c_hi) const
-    {
-        if (!planes.available()) return false;
-        const int x = (int)X, y = (int)Y, S = P.max_steps;
-        const int n0 = vertical ? planes.count_y(x, y, S, true) : planes.count_x(x, y, S, true);
-        const int n1 = vertical ? planes.count_y(x, y, S, false) : planes.count_x(x, y, S, false);
-        if (n0 <= 0 || n1 <= 0) return false;
-        const float step = 2.0f;
-        if (!vertical) {
-            const float ty = Y - 0.125f, t0 = X - 0.25f, t1 = X + 1.25f;
-            const F2 e0 = edges_at(-step * (float)(n0 - 1) + t0, ty), e1 = edges_at(step * (float)(n1 - 1) + t1, ty);
-            const float l0 = search_length(e0.x, e0.y, 0.0f), l1 = search_length(e1.x, e1.y, 0.5f);
-            const float off0 = -(255.0f / 127.0f) * l0 + 3.25f, off1 = -(255.0f / 127.0f) * l1 + 3.25f;
-            c_lo = 1.0f * off0 + (-step * (float)n0 + t0);      // (-dir) * off + tx, dir = -1
-            c_hi = -1.0f * off1 + (step * (float)n1 + t1);      //                    dir = +1
-        } else {
-            const float tx = X - 0.125f, t0 = Y - 0.25f, t1 = Y + 1.25f;
-            const F2 e0 = edges_at(tx, -step * (float)(n0 - 1) + t0), e1 = edges_at(tx, step * (float)(n1 - 1) + t1);
-            const float l0 = search_length(e0.y, e0.x, 0.0f), l1 = search_length(e1.y, e1.x, 0.5f);
-            const float off0 = -(255.0f / 127.0f) * l0 + 3.25f, off1 = -(255.0f / 127.0f) * l1 + 3.25f;
-            c_lo = 1.0f * off0 + (-step * (float)n0 + t0);
-            c_hi = -1.0f * off1 + (step * (float)n1 + t1);
-        }
-        return true;
-    }
     SM_HDM static uint32_t pack_weights(F4 w) { return to_unorm8(w.x) | (to_unorm8(w.y) << 8) | (to_unorm8(w.z) << 16) | (to_unorm8(w.w) << 24); }
 
     // SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) for the pixel at (x, y); returns the RGBA8 texel. One thread does everything in
@@ -538,11 +509,8 @@ struct Blend {
                 hv = (out.x == -out.y);
             }
             if (hv) {
-                float cx, cz;
-                if (!ortho_pair(false, X, Y, cx, cz)) {
-                    cx = ortho_search(0, X, Y);
-                    cz = ortho_search(1, X, Y);
-                }
+                const float cx = ortho_search(0, X, Y);
+                const float cz = ortho_search(1, X, Y);
                 const F2 wgt = north_from(X, Y, cx, cz);
                 out.x = wgt.x;
                 out.y = wgt.y;
@@ -551,11 +519,8 @@ struct Blend {
             }
         }
         if (e.x > 0.0f) {
-            float cy, cz;
-            if (!ortho_pair(true, X, Y, cy, cz)) {
-                cy = ortho_search(2, X, Y);
-                cz = ortho_search(3, X, Y);
-            }
+            const float cy = ortho_search(2, X, Y);
+            const float cz = ortho_search(3, X, Y);
             const F2 wgt = west_from(X, Y, cy, cz);
             out.z = wgt.x;
             out.w = wgt.y;
