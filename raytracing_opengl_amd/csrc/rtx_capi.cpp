@@ -1246,6 +1246,7 @@ int rtx_smaa_resolve(rtx_context* ctx)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "null context");
     if (ctx->smaa_preset < 0) return fail(RTX_ERR_ORDER, "rtx_smaa_resolve: SMAA is not enabled (rtx_enable_smaa)");
+    if (ctx->banded && ctx->rank != 0) return fail(RTX_ERR_ORDER, "the frame is assembled on rank 0: rank %d has nothing to resolve", ctx->rank);
     int st = use_device(ctx);
     if (st) return st;
     if ((st = multi_sync(ctx)) != RTX_OK) return st;   // a multi-device root: the RGBA8 target is assembled on the transfer stream
