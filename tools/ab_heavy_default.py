@@ -1,6 +1,6 @@
 """GPU box: the default scene at 4K on the default and on the many-primitive build of the trace kernel (RTX_OPT_HIGH_OCCUPANCY = -1 / 0 / 1),
-kernel time + frame checksum; with RTX_HIP_LIB pointing at a variant built with -DRT_PENCIL_MIN_PRIMS_V=1 it shows what ray pencils cost a
-scene with three long-table primitives (profiles/r03_experiments.txt)."""
+kernel time + frame checksum; with RTX_HIP_LIB pointing at a variant whose RT_PENCIL_MIN_PRIMS (rt_scene_dev.h) and RT_LANE_DIVERGENT_MIN were
+set to 1 it showed what ray pencils cost a scene with three long-table primitives (profiles/r03_experiments.txt)."""
 import os, sys, hashlib
 sys.path.insert(0, os.getcwd())
 import numpy as np
