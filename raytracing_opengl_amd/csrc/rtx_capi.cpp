@@ -467,14 +467,14 @@ int smaa_alloc(rtx_context* ctx)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_edges), px * 2));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_blend), px * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_list), smaa_segment_capacity(ctx->width, ctx->height) * SMAA_SEGMENTS * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * SMAA_SEGMENTS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * SMAA_COUNT_SET * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_bits), smaa_plane_bytes(ctx->width, ctx->height)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_cbits), smaa_col_plane_bytes(ctx->width, ctx->height)));
     HIP_TRY(hipMemsetAsync(ctx->d_bits, 0, smaa_plane_bytes(ctx->width, ctx->height), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_cbits, 0, smaa_col_plane_bytes(ctx->width, ctx->height), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_edges, 0, px * 2, ctx->stream));      // the sparse passes keep both textures zero outside the
     HIP_TRY(hipMemsetAsync(ctx->d_blend, 0, px * 4, ctx->stream));      // current frame's edge pixels (smaa_kernel.hip)
-    HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * SMAA_SEGMENTS * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * SMAA_COUNT_SET * sizeof(uint32_t), ctx->stream));
     HIP_TRY(hipEventCreate(&ctx->smaa_start));
     HIP_TRY(hipEventCreate(&ctx->smaa_stop));
     ctx->smaa_frame = 0;
@@ -1372,9 +1372,9 @@ int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
     if (ctx->smaa_timed) {
         HIP_TRY(hipEventSynchronize(ctx->smaa_stop));
         HIP_TRY(hipEventElapsedTime(&out->last_smaa_ms, ctx->smaa_start, ctx->smaa_stop));
-        uint32_t n[SMAA_SEGMENTS];
-        HIP_TRY(hipMemcpy(n, ctx->d_smaa_count + ((ctx->smaa_frame - 1u) & 1u) * SMAA_SEGMENTS, sizeof n, hipMemcpyDeviceToHost));
-        for (int k = 0; k < SMAA_SEGMENTS; k++) out->smaa_edge_pixels += n[k];
+        std::vector<uint32_t> n(SMAA_COUNT_SET);
+        HIP_TRY(hipMemcpy(n.data(), ctx->d_smaa_count + ((ctx->smaa_frame - 1u) & 1u) * SMAA_COUNT_SET, n.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < SMAA_SEGMENTS; k++) out->smaa_edge_pixels += n[static_cast<size_t>(k) * SMAA_COUNT_STRIDE];
     }
     if (ctx->opt_count) {
         unsigned long long c[4];

@@ -4,7 +4,10 @@
 
 #include <cstdint>
 
-enum { SMAA_SEGMENTS = 64 };
+#ifndef SMAA_COUNT_STRIDE
+#define SMAA_COUNT_STRIDE 32   /* dwords between two segment counters: every counter in a 128-byte line of its own (smaa_kernel.hip) */
+#endif
+enum { SMAA_SEGMENTS = 64, SMAA_COUNT_SET = SMAA_SEGMENTS * SMAA_COUNT_STRIDE };
 
 struct SmaaBuffers {
     int w, h;
@@ -14,7 +17,8 @@ struct SmaaBuffers {
     uint32_t* blend;         // RGBA8 (fboTexBlend); ZERO outside the listed pixels at all times
     uint32_t* list;          // pixel indices (y * w + x) of the current frame's edge pixels: SMAA_SEGMENTS segments of segment_capacity entries
     size_t segment_capacity;
-    uint32_t* count;         // 2 x SMAA_SEGMENTS counters, the two sets used alternately by consecutive frames (see smaa_kernel.hip)
+    uint32_t* count;         // 2 x SMAA_SEGMENTS counters (counter k of set s at [s * SMAA_COUNT_SET + k * SMAA_COUNT_STRIDE]), the two sets used
+                             // alternately by consecutive frames (see smaa_kernel.hip)
     uint64_t* bits;          // the edge texture again as bit planes, written densely every frame (smaa_device.h PlaneEdges) -- rows: h rows of
                              // plane_words(w) 64-bit words, 32 pixels of a row per word, bit 2k = red, bit 2k + 1 = green of pixel k;
     uint16_t* cbits;         // columns: ((h + 7) / 8) x w 16-bit words, 8 pixels of a COLUMN per word

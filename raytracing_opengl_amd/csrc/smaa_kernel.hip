@@ -25,7 +25,9 @@
 // The list is kept in SMAA_SEGMENTS independent segments, each with its own counter: a strip appends to segment (strip index mod
 // SMAA_SEGMENTS), and the sparse kernels walk all segments (blockIdx.y = segment). One shared counter was measured to cost 16 us per 4K
 // frame by itself -- ~3000 atomics on ONE address serialise in one L2 channel (profiles/r02_smaa_ablation.txt) -- with 64 addresses
-// the append disappears into the dense pass. A segment's capacity is the pixel count of the strips that map to it, so it cannot overflow.
+// the append got 8 us cheaper, and with every counter in a 128-byte line of ITS OWN (SMAA_COUNT_STRIDE; round 3 -- 64 adjacent counters are
+// two L2 lines, i.e. two atomic units) the atomics spread over the L2 channels. A segment's capacity is the pixel count of the strips that
+// map to it, so it cannot overflow.
 //
 // Counters: two sets, used alternately. Frame f appends to set f & 1; smaa_clear of frame f walks the lists with the counts of set
 // (f-1) & 1; smaa_weights of frame f, the first kernel after which nobody needs them any more, zeroes set (f-1) & 1 for frame f+1.
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     const unsigned strip = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
     const unsigned seg = strip % SMAA_SEGMENTS;
     uint32_t* const list = b.list + (size_t)seg * b.segment_capacity;
-    if (lane == 0) base = atomicAdd(b.count + cur * SMAA_SEGMENTS + seg, total);
+    if (lane == 0) base = atomicAdd(b.count + cur * SMAA_COUNT_SET + seg * SMAA_COUNT_STRIDE, total);
     base = __shfl(base, 0, 64);
     unsigned before = 0;
     for (int s = 0; s < STRIP_H * 4; s++) {
@@ -234,11 +236,29 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
             const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
             const int r = s >> 2, k = s & 3;
             const uint32_t p = (uint32_t)((size_t)(y0 + r) * w + px + k);
-            const unsigned two = (unsigned)(ebits[s >> 5] >> sh) & 3u;
             list[base + rank] = p;
-            b.edges[p] = (uint16_t)(((two & 1u) ? 0x00ffu : 0u) | ((two & 2u) ? 0xff00u : 0u));
         }
         before += (unsigned)__popcll(bal);
+    }
+    // the RG8 edge texels: a lane's four pixels of a row as ONE 8-byte store wherever one of them has an edge (the others are written as the
+    // zeros they already are: the texture is zero outside the listed pixels) -- up to eight stores per lane instead of one per pixel slot
+#pragma unroll
+    for (int r = 0; r < STRIP_H; r++) {
+        const unsigned bits8 = (unsigned)(ebits[r >> 3] >> ((r & 7) * 8)) & 0xffu;
+        if (__ballot(bits8 != 0u) == 0) continue;                              // wave-uniform
+        if (bits8 != 0u) {
+            uint16_t tx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tx[k] = (uint16_t)((((bits8 >> (2 * k)) & 1u) ? 0x00ffu : 0u) | (((bits8 >> (2 * k)) & 2u) ? 0xff00u : 0u));
+            uint16_t* const dst = b.edges + (size_t)(y0 + r) * w + px;
+            if (vec_ok) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)tx[0] | ((unsigned)tx[1] << 16), (unsigned)tx[2] | ((unsigned)tx[3] << 16));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (px + k < w && tx[k] != 0) dst[k] = tx[k];
+            }
+        }
     }
 }
 
@@ -251,7 +271,7 @@ struct SegmentedList {
     {
         static_assert(SMAA_SEGMENTS == 64, "one count per lane of the first wave");
         if (threadIdx.x < 64) {
-            unsigned v = counts[threadIdx.x];
+            unsigned v = counts[threadIdx.x * SMAA_COUNT_STRIDE];
             for (int off = 1; off < 64; off <<= 1) {
                 const unsigned u = __shfl_up(v, off, 64);
                 if ((int)threadIdx.x >= off) v += u;
@@ -282,7 +302,7 @@ struct SegmentedList {
 __global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned prev)
 {
     __shared__ SegmentedList L;
-    const unsigned n = L.load(b.count + prev * SMAA_SEGMENTS);
+    const unsigned n = L.load(b.count + prev * SMAA_COUNT_SET);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = L.entry(b, i);
         b.edges[p] = 0;
@@ -300,8 +320,8 @@ __global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned
 __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int preset, unsigned cur)
 {
     __shared__ SegmentedList L;
-    const unsigned n = L.load(b.count + cur * SMAA_SEGMENTS);
-    if (blockIdx.x == 0 && threadIdx.x < SMAA_SEGMENTS) b.count[(cur ^ 1u) * SMAA_SEGMENTS + threadIdx.x] = 0;   // free for the next frame's appends
+    const unsigned n = L.load(b.count + cur * SMAA_COUNT_SET);
+    if (blockIdx.x == 0 && threadIdx.x < SMAA_SEGMENTS) b.count[(cur ^ 1u) * SMAA_COUNT_SET + threadIdx.x * SMAA_COUNT_STRIDE] = 0;   // free for the next frame's appends
     const smaa::Preset P = smaa::preset_of(preset);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
     const smaa::SearchPlanes planes{b.bits, b.cbits, b.w, b.h};
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
 __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned cur)
 {
     __shared__ SegmentedList L;
-    const unsigned n = L.load(b.count + cur * SMAA_SEGMENTS);
+    const unsigned n = L.load(b.count + cur * SMAA_COUNT_SET);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
     // three candidates per listed pixel: itself, its left and its lower neighbour (a pixel's weights come from its own weight texel,
     // its right neighbour's alpha and its upper neighbour's green; only listed pixels have non-zero weight texels). A pixel reached
