@@ -218,30 +218,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     }
     if (__ballot((ebits[0] | ebits[1]) != 0) == 0) return;                     // wave-uniform: most strips leave here
     const unsigned long long any[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
-    unsigned total = (unsigned)__popcll(any[0]) + (unsigned)__popcll(any[1]);  // bit 2s of any[] set <=> pixel slot s has an edge
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    unsigned base = 0;
-    const unsigned strip = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
-    const unsigned seg = strip % SMAA_SEGMENTS;
-    uint32_t* const list = b.list + (size_t)seg * b.segment_capacity;
-    if (lane == 0) base = atomicAdd(b.count + cur * SMAA_COUNT_SET + seg * SMAA_COUNT_STRIDE, total);
-    base = __shfl(base, 0, 64);
-    unsigned before = 0;
-    for (int s = 0; s < STRIP_H * 4; s++) {
-        const int sh = 2 * (s & 31);
-        const bool has = (any[s >> 5] >> sh) & 1ull;
-        const unsigned long long bal = __ballot(has);
-        if (bal == 0) continue;                                                // wave-uniform
-        if (has) {
-            const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-            const int r = s >> 2, k = s & 3;
-            const uint32_t p = (uint32_t)((size_t)(y0 + r) * w + px + k);
-            list[base + rank] = p;
-        }
-        before += (unsigned)__popcll(bal);
-    }
-    // the RG8 edge texels: a lane's four pixels of a row as ONE 8-byte store wherever one of them has an edge (the others are written as the
-    // zeros they already are: the texture is zero outside the listed pixels) -- up to eight stores per lane instead of one per pixel slot
+    // The edge texels first (they need nothing from the list): a lane's four pixels of a row as ONE 8-byte store wherever one of them has an
+    // edge (the others are written as the zeros they already are: the texture is zero outside the listed pixels).
 #pragma unroll
     for (int r = 0; r < STRIP_H; r++) {
         const unsigned bits8 = (unsigned)(ebits[r >> 3] >> ((r & 7) * 8)) & 0xffu;
@@ -258,6 +236,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
                 for (int k = 0; k < 4; k++)
                     if (px + k < w && tx[k] != 0) dst[k] = tx[k];
             }
+        }
+    }
+    // The list: an inclusive scan of the lanes' pixel counts ranks them (six cross-lane steps instead of a ballot per pixel slot), the last
+    // lane reserves the strip's entries with ONE atomic, and every lane writes its own pixels one after the other (the list's order is free).
+    const unsigned mine = (unsigned)__popcll(any[0]) + (unsigned)__popcll(any[1]);   // bit 2s of any[] set <=> pixel slot s has an edge
+    unsigned incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    const unsigned strip = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
+    const unsigned seg = strip % SMAA_SEGMENTS;
+    unsigned base = 0;
+    if (lane == 63) base = atomicAdd(b.count + cur * SMAA_COUNT_SET + seg * SMAA_COUNT_STRIDE, incl);   // lane 63's inclusive sum is the total
+    base = __shfl(base, 63, 64);
+    uint32_t* out = b.list + (size_t)seg * b.segment_capacity + base + (incl - mine);
+    for (int half = 0; half < (STRIP_H * 4 + 31) / 32; half++) {
+        unsigned long long m = any[half];
+        while (m != 0ull) {                                                    // this lane's own slots (divergent, a handful at most)
+            const int s = half * 32 + (__builtin_ctzll(m) >> 1);
+            m &= m - 1ull;
+            *out++ = (uint32_t)((size_t)(y0 + (s >> 2)) * w + px + (s & 3));
         }
     }
 }
