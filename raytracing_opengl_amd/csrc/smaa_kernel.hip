@@ -42,7 +42,7 @@ namespace {
 
 constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels = one 1 KiB row segment per load
 #ifndef SMAA_ABL
-#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded */
+#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
 #endif
 #ifndef SMAA_STRIP_H
 #define SMAA_STRIP_H 8
@@ -63,7 +63,7 @@ struct Row4 { float l[4]; };   // lumas of one lane's four pixels in one row
 // registers (rows y-2, y-1, y, y+1 of SMAA.h:689-741's "top-top", "top", centre, "bottom"); the three horizontal neighbours a lane
 // needs come from the adjacent lanes by cross-lane moves, the strip's outermost columns by two extra loads. Every row is copied to the
 // screen as it passes. Edge bits are kept in two registers per lane for the whole strip; at the end the wave reserves its list slots with
-// ONE atomic (none at all for the strips without an edge -- most of a frame), ranks its pixels with ballots and writes list + edge texels.
+// ONE atomic (none at all for the strips without an edge -- most of a frame), ranks its pixels with a scan of the lanes' counts and writes list + edge texels.
 template <int STRIP_H>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffers b, float threshold, unsigned cur)
 {
@@ -329,7 +329,11 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = L.entry(b, i);
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
+#if SMAA_ABL & 512
+        b.blend[p] = (uint32_t)(x ^ y) | 1u;   // timing ablation: list walk + store only
+#else
         b.blend[p] = B.weights(x, y);
+#endif
     }
 }
 
