@@ -32,6 +32,7 @@ const char* ncclGetErrorString(ncclResult_t);
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -141,7 +142,7 @@ struct rtx_context {
     uint32_t* d_blend = nullptr;     // RGBA8, zero outside the listed pixels
     uint32_t* d_list = nullptr;      // edge pixels of the current frame
     uint32_t* d_smaa_count = nullptr;  // two alternating counter sets
-    uint64_t* d_bits = nullptr;      // the edge texture as bit planes (smaa_kernel.h): rows ...
+    uint64_t* d_bits = nullptr;      // the edge texture as bit planes (smaa_kernel.h): rows (two planes: this resolve's and the previous one's) ...
     uint16_t* d_cbits = nullptr;     // ... and columns
     uint16_t* d_area = nullptr;
     uint8_t* d_search = nullptr;
@@ -468,17 +469,44 @@ int smaa_alloc(rtx_context* ctx)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_blend), px * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_list), smaa_segment_capacity(ctx->width, ctx->height) * SMAA_SEGMENTS * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_smaa_count), 2 * SMAA_COUNT_SET * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_bits), smaa_plane_bytes(ctx->width, ctx->height)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_bits), 2 * smaa_plane_bytes(ctx->width, ctx->height)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_cbits), smaa_col_plane_bytes(ctx->width, ctx->height)));
-    HIP_TRY(hipMemsetAsync(ctx->d_bits, 0, smaa_plane_bytes(ctx->width, ctx->height), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_bits, 0, 2 * smaa_plane_bytes(ctx->width, ctx->height), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_cbits, 0, smaa_col_plane_bytes(ctx->width, ctx->height), ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_edges, 0, px * 2, ctx->stream));      // the sparse passes keep both textures zero outside the
-    HIP_TRY(hipMemsetAsync(ctx->d_blend, 0, px * 4, ctx->stream));      // current frame's edge pixels (smaa_kernel.hip)
+    // Neither texture is ever cleared by the passes: the kernels read edges from the bit planes, and a weight texel only where the plane has
+    // an edge pixel (smaa_kernel.hip). RTX_SMAA_POISON=1 (tests) starts the weight texture full of garbage to prove exactly that.
+    const char* poison = std::getenv("RTX_SMAA_POISON");
+    HIP_TRY(hipMemsetAsync(ctx->d_edges, 0, px * 2, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_blend, (poison && poison[0] == '1') ? 0xa5 : 0, px * 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_smaa_count, 0, 2 * SMAA_COUNT_SET * sizeof(uint32_t), ctx->stream));
     HIP_TRY(hipEventCreate(&ctx->smaa_start));
     HIP_TRY(hipEventCreate(&ctx->smaa_stop));
     ctx->smaa_frame = 0;
     return RTX_OK;
+}
+
+// `frame`: the resolve whose buffers are meant (the row bit plane alternates between two buffers)
+SmaaBuffers smaa_buffers(rtx_context* ctx, unsigned frame)
+{
+    SmaaBuffers b;
+    b.w = ctx->width;
+    b.h = ctx->height;
+    b.color = ctx->d_fb_u8;
+    b.screen = ctx->d_screen;
+    b.edges = ctx->d_edges;
+    b.blend = ctx->d_blend;
+    b.list = ctx->d_list;
+    b.segment_capacity = smaa_segment_capacity(ctx->width, ctx->height);
+    b.count = ctx->d_smaa_count;
+    {   // the row plane alternates between two buffers: resolve f writes plane f & 1 and reads what resolve f - 1 wrote
+        const size_t words = smaa_plane_bytes(ctx->width, ctx->height) / 8;
+        b.bits = ctx->d_bits + (frame & 1u) * words;
+        b.bits_prev = ctx->d_bits + ((frame & 1u) ^ 1u) * words;
+    }
+    b.cbits = ctx->d_cbits;
+    b.area = ctx->d_area;
+    b.search = ctx->d_search;
+    return b;
 }
 
 // The three passes after the tracer (GLWrapper.cpp:173-204) on the context's RGBA8 colour target, into the screen buffer.
@@ -493,20 +521,7 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
         if (st) return st;
     }
     if (stream != ctx->stream) return fail(RTX_ERR_INVALID, "the SMAA resolve runs on the context's own stream");
-    SmaaBuffers b;
-    b.w = ctx->width;
-    b.h = ctx->height;
-    b.color = ctx->d_fb_u8;
-    b.screen = ctx->d_screen;
-    b.edges = ctx->d_edges;
-    b.blend = ctx->d_blend;
-    b.list = ctx->d_list;
-    b.segment_capacity = smaa_segment_capacity(ctx->width, ctx->height);
-    b.count = ctx->d_smaa_count;
-    b.bits = ctx->d_bits;
-    b.cbits = ctx->d_cbits;
-    b.area = ctx->d_area;
-    b.search = ctx->d_search;
+    const SmaaBuffers b = smaa_buffers(ctx, ctx->smaa_frame);
     HIP_TRY(hipEventRecord(ctx->smaa_start, stream));
     HIP_TRY(smaa_launch(b, ctx->smaa_preset, ctx->smaa_frame, stream));
     HIP_TRY(hipEventRecord(ctx->smaa_stop, stream));
@@ -1326,6 +1341,8 @@ int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_byt
     if ((st = resolve_format(ctx, format, &src, &need)) != RTX_OK) return st;
     if (dst_bytes < need) return fail(RTX_ERR_INVALID, "destination holds %zu bytes, %zu needed", dst_bytes, need);
     if ((st = multi_sync(ctx)) != RTX_OK) return st;
+    if (format == RTX_SMAA_EDGES_RG8 || format == RTX_SMAA_WEIGHTS_RGBA8)   // kept as bit planes / never cleared on the device: made on demand
+        HIP_TRY(smaa_expand(smaa_buffers(ctx, ctx->smaa_frame - 1u), ctx->stream));   // the last resolve's planes
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(dst_host, src, need, hipMemcpyDeviceToHost));
     return RTX_OK;

@@ -79,25 +79,56 @@ SM_HD float sat_(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 SM_HD int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
 // ---- samplers -----------------------------------------------------------------------------------------------
-// General LINEAR + CLAMP_TO_EDGE fetch of an RG8 texture at texel-space (tx, ty) plus an integer texel offset.
-SM_HD F2 sample_rg(const uint16_t* t, int w, int h, float tx, float ty, int ox = 0, int oy = 0)
+// Where the RG8 edge texture of pass 1 is read from: raw(i, j) = the RG8 texel of an IN-RANGE texel (the samplers clamp first), R in
+// bits 0..7, G in bits 8..15.
+//   TexEdges   the texture itself (what the reference's fboTexEdge is): 2 bytes per texel. The host reference build, and the form the other
+//              source is checked against.
+//   PlaneTex   the ROW bit plane the dense HIP kernel writes every frame (SearchPlanes below: 32 pixels per 64-bit word, bit 2k = red,
+//              bit 2k + 1 = green of pixel k): the same texel values, 0 or 255. The HIP weight kernel reads the edges from here, so the
+//              RG8 texture need not exist on the device at all -- no scattered 2-byte texel stores in the dense pass, and nothing to
+//              clear before the next frame (the plane is rewritten densely; round 2 kept the texture zero outside the current edge list
+//              with a kernel of its own).
+struct TexEdges {
+    const uint16_t* t;
+    int w;
+    SM_HDM uint32_t raw(int i, int j) const { return t[(size_t)j * w + i]; }
+};
+struct PlaneTex {
+    const uint64_t* rows;
+    int pw;                  // 64-bit words per row
+    // (read as 32-bit halves -- 16 pixels each, little-endian: half h of word q is dword 2q + h -- so that the extraction is a 32-bit shift)
+    SM_HDM uint32_t two(int i, int j) const { return (reinterpret_cast<const uint32_t*>(rows)[((size_t)j * pw << 1) + (i >> 4)] >> (2 * (i & 15))) & 3u; }
+    SM_HDM uint32_t raw(int i, int j) const
+    {
+        const uint32_t t = two(i, j);
+        return ((t & 1u) ? 0x00ffu : 0u) | ((t & 2u) ? 0xff00u : 0u);
+    }
+    SM_HDM bool any(int i, int j) const { return two(i, j) != 0u; }   // the pixel has an edge
+};
+// General LINEAR + CLAMP_TO_EDGE fetch of the RG8 edge texture at texel-space (tx, ty) plus an integer texel offset.
+template <class E>
+SM_HD F2 sample_edges(const E& src, int w, int h, float tx, float ty, int ox = 0, int oy = 0)
 {
     const float fx = floorf(tx), fy = floorf(ty);
     const float a = tx - fx, b = ty - fy;
     const int i0 = clampi((int)fx + ox, w - 1), i1 = clampi((int)fx + ox + 1, w - 1);
     const int j0 = clampi((int)fy + oy, h - 1), j1 = clampi((int)fy + oy + 1, h - 1);
     // A tap whose weight is exactly 0 is not fetched: 0 * texel is +0 for every texel and x + 0 = x, so the sum is the same bits. Most of
-    // SMAA's fetches sit on a texel row, column or centre (a == 0 and / or b == 0); the weight kernel is bound by cache-line look-ups of
-    // scattered 2-byte taps, not by arithmetic, so this is worth up to 4x fewer of them.
-    const uint32_t p00 = t[(size_t)j0 * w + i0];
-    const uint32_t p10 = a != 0.0f ? t[(size_t)j0 * w + i1] : 0u;
-    const uint32_t p01 = b != 0.0f ? t[(size_t)j1 * w + i0] : 0u;
-    const uint32_t p11 = (a != 0.0f && b != 0.0f) ? t[(size_t)j1 * w + i1] : 0u;
+    // SMAA's fetches sit on a texel row, column or centre (a == 0 and / or b == 0).
+    const uint32_t p00 = src.raw(i0, j0);
+    const uint32_t p10 = a != 0.0f ? src.raw(i1, j0) : 0u;
+    const uint32_t p01 = b != 0.0f ? src.raw(i0, j1) : 0u;
+    const uint32_t p11 = (a != 0.0f && b != 0.0f) ? src.raw(i1, j1) : 0u;
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     F2 r;
     r.x = w00 * unorm8(p00 & 255u) + w10 * unorm8(p10 & 255u) + w01 * unorm8(p01 & 255u) + w11 * unorm8(p11 & 255u);
     r.y = w00 * unorm8(p00 >> 8) + w10 * unorm8(p10 >> 8) + w01 * unorm8(p01 >> 8) + w11 * unorm8(p11 >> 8);
     return r;
+}
+// The same for any RG8 texture in memory (the area table).
+SM_HD F2 sample_rg(const uint16_t* t, int w, int h, float tx, float ty, int ox = 0, int oy = 0)
+{
+    return sample_edges(TexEdges{t, w}, w, h, tx, ty, ox, oy);
 }
 // Texel-centre fetch (integer position): one tap.
 SM_HD F2 texel_rg(const uint16_t* t, int w, int h, int i, int j)
@@ -258,12 +289,14 @@ struct SearchPlanes {
 };
 
 // ---- pass 2: blending weights (SMAA.h:835-1243) --------------------------------------------------------------
-struct Blend {
+template <class E>
+struct BlendT {
     const Views& V;
     const Preset& P;
     const SearchPlanes& planes;   // bit planes of the edge texture for the orthogonal searches (rows == nullptr: per-step loops only)
+    const E& src;                 // where single edge texels are fetched from (TexEdges / PlaneTex)
 
-    SM_HDM F2 edges_at(float tx, float ty, int ox = 0, int oy = 0) const { return sample_rg(V.edges, V.w, V.h, tx, ty, ox, oy); }
+    SM_HDM F2 edges_at(float tx, float ty, int ox = 0, int oy = 0) const { return sample_edges(src, V.w, V.h, tx, ty, ox, oy); }
 
     SM_HDM static float decode1(float r) { return rintf(r * fabsf(5.0f * r - 3.75f)); }   // SMAADecodeDiagBilinearAccess, red channel
 
@@ -499,7 +532,8 @@ struct Blend {
     {
         const float X = (float)x, Y = (float)y;
         F4 out{0.0f, 0.0f, 0.0f, 0.0f};
-        F2 e = texel_rg(V.edges, V.w, V.h, x, y);
+        const uint32_t own = src.raw(clampi(x, V.w - 1), clampi(y, V.h - 1));   // texel-centre fetch of the pixel's own edges
+        F2 e{unorm8(own & 255u), unorm8(own >> 8)};
         if (e.y > 0.0f) {
             bool hv = true;
             if (P.max_steps_diag > 0) {
@@ -528,14 +562,24 @@ struct Blend {
         return pack_weights(out);
     }
 };
+using Blend = BlendT<TexEdges>;
 
 // ---- pass 3: neighbourhood blending (SMAA.h:1252-1300) ---------------------------------------------------------
 // Returns true and the new RGBA8 texel when pixel (x, y) is blended; false when its four weights are all zero (the output is then the
 // input texel, which the dense pass has already copied).
-SM_HD bool neighborhood(const Views& V, int x, int y, uint32_t& out)
+// MASKED (the HIP kernels): a weight texel counts only where the CURRENT frame has an edge pixel (`member`, the row bit plane) -- the weight
+// texture is then never cleared: texels of earlier frames' edge pixels stay behind and are not looked at, exactly as if they were the zeros
+// the reference's glClear + discard leave (GLWrapper.cpp:189-190).
+template <bool MASKED = false>
+SM_HD bool neighborhood(const Views& V, int x, int y, uint32_t& out, const PlaneTex* member = nullptr)
 {
     const int xr = clampi(x + 1, V.w - 1), yt = clampi(y + 1, V.h - 1);
-    const uint32_t own = V.blend[(size_t)y * V.w + x], right = V.blend[(size_t)y * V.w + xr], top = V.blend[(size_t)yt * V.w + x];
+    uint32_t own = V.blend[(size_t)y * V.w + x], right = V.blend[(size_t)y * V.w + xr], top = V.blend[(size_t)yt * V.w + x];
+    if (MASKED) {
+        if (!member->any(x, y)) own = 0u;
+        if (!member->any(xr, y)) right = 0u;
+        if (!member->any(x, yt)) top = 0u;
+    }
     const float ax = unorm8(right >> 24), ay = unorm8((top >> 8) & 255u), aw = unorm8(own & 255u), az = unorm8((own >> 16) & 255u);
     if (ax * 1.0f + ay * 1.0f + az * 1.0f + aw * 1.0f < 1e-5f) return false;
     const float X = (float)x, Y = (float)y;

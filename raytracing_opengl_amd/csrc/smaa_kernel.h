@@ -13,13 +13,16 @@ struct SmaaBuffers {
     int w, h;
     const uint32_t* color;   // RGBA8 colour target of the tracer (fboTexColor, GLWrapper.cpp:127)
     uint32_t* screen;        // RGBA8 output (what the reference draws to the default framebuffer, GLWrapper.cpp:195-204)
-    uint16_t* edges;         // RG8 (fboTexEdge); ZERO outside the listed pixels at all times
-    uint32_t* blend;         // RGBA8 (fboTexBlend); ZERO outside the listed pixels at all times
+    uint16_t* edges;         // RG8 (fboTexEdge): the dense kernel writes a lane's four texels of a row wherever this frame OR the previous one has
+                             // an edge among them -- new edges in, stale ones out, no clearing pass
+    uint32_t* blend;         // RGBA8 (fboTexBlend): the weight kernel writes the listed pixels' texels; texels of earlier frames' edge pixels stay
+                             // behind and are never read (pass 3 looks at a texel only where `bits` has an edge pixel); smaa_expand zeroes them
     uint32_t* list;          // pixel indices (y * w + x) of the current frame's edge pixels: SMAA_SEGMENTS segments of segment_capacity entries
     size_t segment_capacity;
     uint32_t* count;         // 2 x SMAA_SEGMENTS counters (counter k of set s at [s * SMAA_COUNT_SET + k * SMAA_COUNT_STRIDE]), the two sets used
                              // alternately by consecutive frames (see smaa_kernel.hip)
-    uint64_t* bits;          // the edge texture again as bit planes, written densely every frame (smaa_device.h PlaneEdges) -- rows: h rows of
+    const uint64_t* bits_prev;   // the row plane the PREVIOUS resolve wrote (all zero before the first): what the RG8 texture still holds
+    uint64_t* bits;          // the edge texture again as bit planes, written densely every frame (smaa_device.h SearchPlanes) -- rows: h rows of
                              // plane_words(w) 64-bit words, 32 pixels of a row per word, bit 2k = red, bit 2k + 1 = green of pixel k;
     uint16_t* cbits;         // columns: ((h + 7) / 8) x w 16-bit words, 8 pixels of a COLUMN per word
     const uint16_t* area;    // 160 x 560 RG8
@@ -33,3 +36,5 @@ size_t smaa_segment_capacity(int w, int h);
 size_t smaa_plane_bytes(int w, int h);        // size of the row bit plane
 size_t smaa_col_plane_bytes(int w, int h);    // size of the column bit plane
 hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream);
+// For read-backs of RTX_SMAA_EDGES_RG8 / RTX_SMAA_WEIGHTS_RGBA8: fills `edges` from the bit plane and zeroes the weight texels of pixels without an edge.
+hipError_t smaa_expand(const SmaaBuffers& b, hipStream_t stream);

@@ -5,22 +5,27 @@
 // of a frame. Here the frame is touched densely ONCE and the rest is sparse:
 //
 //   smaa_edges_kernel    dense: reads the colour target (16 B per lane, 1 KiB per wave and row), copies it to the screen, detects luma
-//                        edges (SMAA.h:689-741) on a four-row window of lumas held in registers and, for edge pixels only, writes the
-//                        RG8 edge texel and appends the pixel to a list -- one atomic per 256 x 8 strip (ballot ranks), none for the
-//                        strips without an edge;
-//                        It also writes the edge texture a second time as two BIT PLANES (2 bits per pixel: one byte per lane and row,
-//                        32 pixels of a row per 64-bit word; and 16 bits per column and strip, 8 pixels of a column) -- dense, 2 x 2 MB at 4K;
+//                        edges (SMAA.h:689-741) on a four-row window of lumas held in registers, writes the edge texture as two BIT
+//                        PLANES (2 bits per pixel -- the texels are 0 or 255: one byte per lane and row, 32 pixels of a row per 64-bit
+//                        word; and 16 bits per column and strip, 8 pixels of a column; dense, 2 x 2 MB at 4K), brings the RG8 edge texture up to
+//                        date (texels where this frame or the previous one has an edge) and appends the strip's edge pixels to a list --
+//                        one atomic per 256 x 8 strip, none for the strips without an edge;
 //   smaa_weights_kernel  over the list, one thread per listed pixel: blending weights (SMAA.h:1145-1243) -> RGBA8 weight texel. The step
-//                        counts of the four orthogonal searches come from the bit planes (smaa_device.h SearchPlanes), the rest from the
-//                        RG8 texture as before. (Round 2 walked every edge: up to 32 dependent 4-tap fetches per direction.)
+//                        counts of the four orthogonal searches come from whole plane words (smaa_device.h SearchPlanes), single edge
+//                        texels from the RG8 texture. (Round 2 walked every edge on the texture: up to 32 dependent 4-tap fetches per
+//                        direction.)
 //   smaa_blend_kernel    over the list: neighbourhood blending (SMAA.h:1252-1300) of the listed pixel, its left and its lower
-//                        neighbour -- the only pixels whose four weights can be non-zero -- overwriting their screen texels;
-//   smaa_clear_kernel    over the PREVIOUS frame's list: zeroes the edge and weight texels it wrote.
+//                        neighbour -- the only pixels whose four weights can be non-zero -- overwriting their screen texels; a weight
+//                        texel is looked at only where the row plane has an edge pixel.
 //
-// Invariant: the edge and weight textures are zero everywhere except at the pixels of the current list (allocated zeroed, cleared
-// through the list before the next frame's pass 1), so the sparse passes see exactly the textures the reference's dense passes
-// would have produced (glClear(0) + discard, GLWrapper.cpp:177-178,189-190). Algorithmic HBM traffic per frame: W*H*4 B read +
-// W*H*4 B written, against 6 x W*H*4 B + 2 x W*H*2 B for three dense passes.
+// Nothing is cleared between frames (round 3; round 2 zeroed the previous frame's edge and weight texels through its list with a kernel
+// of its own -- 5 us, the fixed cost of any sparse kernel here): the planes are rewritten densely every frame; the dense kernel keeps the
+// previous frame's row plane and rewrites the RG8 edge texels wherever either frame has an edge, so that texture is always exact; and a
+// weight texel that an earlier frame left behind at a pixel without an edge is never read -- the same textures, to a reader, as the
+// reference's glClear(0) + discard produce (GLWrapper.cpp:177-178,189-190). smaa_expand_kernel masks the weight texture for
+// rtx_read_pixels. (Reading the single edge texels from the row plane as well, so that the RG8 texture would not be needed at all, was
+// measured: the weight kernel's diagonal searches then pay ~8 instructions more per tap, 26.9 -> 35.5 us at ULTRA. profiles/r03_smaa.txt) Algorithmic HBM traffic per frame: W*H*4 B read + W*H*4 B written, against 6 x W*H*4 B + 2 x W*H*2 B for three
+// dense passes.
 //
 // The list is kept in SMAA_SEGMENTS independent segments, each with its own counter: a strip appends to segment (strip index mod
 // SMAA_SEGMENTS), and the sparse kernels walk all segments (blockIdx.y = segment). One shared counter was measured to cost 16 us per 4K
@@ -29,8 +34,8 @@
 // two L2 lines, i.e. two atomic units) the atomics spread over the L2 channels. A segment's capacity is the pixel count of the strips that
 // map to it, so it cannot overflow.
 //
-// Counters: two sets, used alternately. Frame f appends to set f & 1; smaa_clear of frame f walks the lists with the counts of set
-// (f-1) & 1; smaa_weights of frame f, the first kernel after which nobody needs them any more, zeroes set (f-1) & 1 for frame f+1.
+// Counters: two sets, used alternately. Frame f appends to set f & 1; smaa_weights of frame f zeroes set (f-1) & 1 for frame f+1 (the
+// stats of frame f-1 were read from it until then).
 // The sparse kernels treat the segments as one list again (SegmentedList below), so their work stays balanced.
 #include "smaa_kernel.h"
 
@@ -90,6 +95,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     if (x0 >= w) return;                                                       // wave-uniform (after the barrier)
     const int px = x0 + lane * 4;
     const bool vec_ok = ((w & 3) == 0) && (px + 3 < w);
+    // what the RG8 edge texture still holds for this lane's pixels: the previous resolve's row plane (requested first, needed last)
+    const int pw8 = smaa::SearchPlanes::plane_words(w) * 8;                    // bytes per row-plane row
+    const int byte_x = px >> 2;
+    unsigned long long pbits[2] = {0, 0};
+    if (byte_x < pw8) {
+        const uint8_t* const pplane = reinterpret_cast<const uint8_t*>(b.bits_prev);
+#pragma unroll
+        for (int r = 0; r < STRIP_H; r++)
+            if (y0 + r < h) pbits[r >> 3] |= (unsigned long long)pplane[(size_t)(y0 + r) * pw8 + byte_x] << ((r & 7) * 8);
+    }
 
     auto load_row = [&](int y, uint32_t c[4]) {                               // clamped in y; x clamped per pixel on the scalar path
         const int yc = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
@@ -186,9 +201,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     // the bit planes (dense: edge-free strips write their zeros too, so the planes need no clearing). Rows: this lane's four pixels of a
     // row are one byte, 64 lanes = 64 consecutive bytes. Columns: per 8-row block and column 16 bits, this lane's four columns = 8 bytes.
     {
-        const int pw8 = smaa::SearchPlanes::plane_words(w) * 8;                              // bytes per row-plane row
         uint8_t* const plane = reinterpret_cast<uint8_t*>(b.bits);
-        const int byte_x = px >> 2;
         if (byte_x < pw8) {
 #pragma unroll
             for (int r = 0; r < STRIP_H; r++)
@@ -216,15 +229,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
             }
         }
     }
-    if (__ballot((ebits[0] | ebits[1]) != 0) == 0) return;                     // wave-uniform: most strips leave here
-    const unsigned long long any[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
-    // The edge texels first (they need nothing from the list): a lane's four pixels of a row as ONE 8-byte store wherever one of them has an
-    // edge (the others are written as the zeros they already are: the texture is zero outside the listed pixels).
+    // The RG8 edge texels: a lane's four pixels of a row as ONE 8-byte store wherever this frame or the previous one has an edge among them
+    // -- this frame's edges go in, the previous frame's come out, and the texture is exact without a clearing pass (round 2 zeroed the
+    // previous list's texels with a kernel of its own: 5 us, the fixed cost of any sparse kernel here).
+    if (__ballot((ebits[0] | ebits[1] | pbits[0] | pbits[1]) != 0) == 0) return;   // wave-uniform: most strips leave here
 #pragma unroll
     for (int r = 0; r < STRIP_H; r++) {
-        const unsigned bits8 = (unsigned)(ebits[r >> 3] >> ((r & 7) * 8)) & 0xffu;
-        if (__ballot(bits8 != 0u) == 0) continue;                              // wave-uniform
-        if (bits8 != 0u) {
+        const unsigned bits8 = (unsigned)(ebits[r >> 3] >> ((r & 7) * 8)) & 0xffu, old8 = (unsigned)(pbits[r >> 3] >> ((r & 7) * 8)) & 0xffu;
+        if (__ballot((bits8 | old8) != 0u) == 0) continue;                     // wave-uniform
+        if ((bits8 | old8) != 0u) {
             uint16_t tx[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) tx[k] = (uint16_t)((((bits8 >> (2 * k)) & 1u) ? 0x00ffu : 0u) | (((bits8 >> (2 * k)) & 2u) ? 0xff00u : 0u));
@@ -234,10 +247,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (px + k < w && tx[k] != 0) dst[k] = tx[k];
+                    if (px + k < w) dst[k] = tx[k];
             }
         }
     }
+    if (__ballot((ebits[0] | ebits[1]) != 0) == 0) return;                     // wave-uniform: nothing to append
+    const unsigned long long any[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
     // The list: an inclusive scan of the lanes' pixel counts ranks them (six cross-lane steps instead of a ballot per pixel slot), the last
     // lane reserves the strip's entries with ONE atomic, and every lane writes its own pixels one after the other (the list's order is free).
     const unsigned mine = (unsigned)__popcll(any[0]) + (unsigned)__popcll(any[1]);   // bit 2s of any[] set <=> pixel slot s has an edge
@@ -299,14 +314,17 @@ struct SegmentedList {
     }
 };
 
-__global__ __launch_bounds__(256) void smaa_clear_kernel(SmaaBuffers b, unsigned prev)
+// For rtx_read_pixels only: the RG8 edge texture and the weight texture as the reference's passes would have left them, from the row plane
+// (dense, one thread per pixel): edges = the plane's two bits as 0 / 255 bytes; weights = the stored texel where the plane has an edge
+// pixel, zero elsewhere (which also wipes what earlier frames left behind).
+__global__ __launch_bounds__(256) void smaa_expand_kernel(SmaaBuffers b)
 {
-    __shared__ SegmentedList L;
-    const unsigned n = L.load(b.count + prev * SMAA_COUNT_SET);
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = L.entry(b, i);
-        b.edges[p] = 0;
-        b.blend[p] = 0;
+    const size_t n = (size_t)b.w * b.h;
+    const smaa::PlaneTex plane{b.bits, smaa::SearchPlanes::plane_words(b.w)};
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / (size_t)b.w), x = (int)(p - (size_t)y * b.w);
+        b.edges[p] = (uint16_t)plane.raw(x, y);
+        if (!plane.any(x, y)) b.blend[p] = 0u;
     }
 }
 
@@ -325,7 +343,8 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
     const smaa::Preset P = smaa::preset_of(preset);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
     const smaa::SearchPlanes planes{b.bits, b.cbits, b.w, b.h};
-    const smaa::Blend B{V, P, planes};
+    const smaa::TexEdges src{b.edges, b.w};
+    const smaa::Blend B{V, P, planes, src};
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = L.entry(b, i);
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned
     __shared__ SegmentedList L;
     const unsigned n = L.load(b.count + cur * SMAA_COUNT_SET);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
+    const smaa::PlaneTex member{b.bits, smaa::SearchPlanes::plane_words(b.w)};
     // three candidates per listed pixel: itself, its left and its lower neighbour (a pixel's weights come from its own weight texel,
     // its right neighbour's alpha and its upper neighbour's green; only listed pixels have non-zero weight texels). A pixel reached
     // twice gets the same bytes twice.
@@ -354,7 +374,7 @@ __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned
         if (which == 2) y -= 1;
         if (x < 0 || y < 0) continue;
         uint32_t out;
-        if (smaa::neighborhood(V, x, y, out)) b.screen[(size_t)y * b.w + x] = out;
+        if (smaa::neighborhood<true>(V, x, y, out, &member)) b.screen[(size_t)y * b.w + x] = out;
     }
 }
 
@@ -380,11 +400,16 @@ size_t smaa_segment_capacity(int w, int h)
 size_t smaa_plane_bytes(int w, int h) { return (size_t)smaa::SearchPlanes::plane_words(w) * 8u * (size_t)h; }
 size_t smaa_col_plane_bytes(int w, int h) { return (size_t)((h + 7) / 8) * (size_t)w * 2u + 16u; }
 
+hipError_t smaa_expand(const SmaaBuffers& b, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smaa_expand_kernel, dim3(2048), dim3(256), 0, stream, b);
+    return hipGetLastError();
+}
+
 hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream)
 {
-    const unsigned cur = frame & 1u, prev = cur ^ 1u;
+    const unsigned cur = frame & 1u;
     const dim3 sparse(1024);                                                    // grid-stride over the device-side total of the segment counts
-    hipLaunchKernelGGL(smaa_clear_kernel, sparse, dim3(256), 0, stream, b, prev);
     const int strip_h = strip_rows();
     const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
     const float thr = smaa::preset_of(preset).threshold;

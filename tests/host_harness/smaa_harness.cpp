@@ -40,7 +40,28 @@ extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, con
             pcol[(size_t)(y >> 3) * w + x] |= (uint16_t)(two << (2 * (y & 7)));
         }
     const smaa::SearchPlanes planes{use_planes ? prow.data() : nullptr, pcol.data(), w, h};
-    const smaa::Blend B{V, P, planes};
+    if (use_planes) {
+        // the HIP kernels' form: single edge texels from the row plane too (PlaneTex), a weight texture that is NEVER cleared -- filled
+        // with garbage here wherever the frame has no edge pixel -- and pass 3 looking at weights only where the plane has an edge
+        const smaa::PlaneTex src{prow.data(), pw};
+        const smaa::BlendT<smaa::PlaneTex> B{V, P, planes, src};
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? B.weights(x, y) : (0x9e3779b9u * (uint32_t)(y * w + x + 1)) | 0x01010101u;
+#pragma omp parallel for
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                uint32_t out;
+                screen[(size_t)y * w + x] = smaa::neighborhood<true>(V, x, y, out, &src) ? out : color[(size_t)y * w + x];
+            }
+        for (int y = 0; y < h; y++)                      // what a read-back of the weight texture returns: stale texels masked out
+            for (int x = 0; x < w; x++)
+                if (!edges[(size_t)y * w + x]) blend[(size_t)y * w + x] = 0u;
+        return 0;
+    }
+    const smaa::TexEdges src{edges, w};
+    const smaa::Blend B{V, P, planes, src};
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? B.weights(x, y) : 0u;

@@ -110,6 +110,19 @@ def test_full_size_frame(built, tables):
     _same(got, smaa.run(img, "ULTRA", *tables))
 
 
+def test_weight_texture_is_never_cleared_and_never_misread(built, tables, monkeypatch):
+    """No pass clears anything between frames: pass 3 looks at a weight texel only where the current frame's bit plane has an edge pixel.
+    With the weight texture starting out full of garbage (RTX_SMAA_POISON) and frames that move their edges around, every texture
+    read back -- edges and weights are reconstructed / masked on demand -- is the oracle's."""
+    monkeypatch.setenv("RTX_SMAA_POISON", "1")
+    w, h = 333, 141
+    gl = _ctx(w, h, "ULTRA", tables)
+    frames = [smaa_cases.pattern(31, w, h), smaa_cases.pattern(32, w, h), np.full((h, w, 4), 255, np.uint8), smaa_cases.pattern(31, w, h)[::-1].copy(), smaa_cases.pattern(33, w, h)]
+    for k, img in enumerate(frames):
+        _same(_resolve(gl, img), smaa.run(img, "ULTRA", *tables), f"frame {k}")
+    gl.stop()
+
+
 def test_caller_supplied_tables_replace_the_librarys(built, tables):
     """rtx_smaa_set_tables with other bytes (a synthetic area table): the passes follow whatever table they are given."""
     synth = smaa_tables.synthetic_area_table()
