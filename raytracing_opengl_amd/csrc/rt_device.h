@@ -738,6 +738,15 @@ RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, 
 // (half the instructions, smaller rounding error than the margins were derived for) and everything that depends on the
 // ray direction only (dot(rd,rd), the six products of the quadric form) is loop-invariant and hoisted by the compiler.
 RT_HD float dot3_fma(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+// The earliest possible entry into the sphere, t_in = (-b - sqrt(hp)) / a (b < 0, hp >= 0 the padded discriminant), lies beyond the
+// limit L = 1.001 tlimit + 0.01 + 1e-5 (1 + |oc|^2):  t_in > L  <=>  s = -b - a L > sqrt(hp)  <=>  s > 0 and s^2 > hp -- no square root and
+// no division (round 3: the IEEE expansions of both were a fifth of this predicate's instructions). NaN anywhere -> false -> not culled.
+RT_HD bool sphere_entry_beyond(float a, float b, float hp, float d2, float tlimit)
+{
+    const float L = fmaf(tlimit, 1.001f, fmaf(1e-5f, d2, 0.01001f));
+    const float s = fmaf(-a, L, -b);
+    return s > 0.0f && s * s > hp;
+}
 RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
 {
     const f3 oc = ro - c;
@@ -752,8 +761,7 @@ RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
     const float h = fmaf(b, b, -(a * cc));
     const float err = 1e-5f * a * d2;
     if (h < -err) return true;                // line misses the sphere, beyond rounding doubt
-    const float t_in = (-b - sqrtf(gl_max(h + err, 0.0f))) / a;   // earliest possible entry (a ~ 1)
-    return t_in > tlimit * 1.001f + 0.01f + 1e-5f * sqrtf(d2);
+    return sphere_entry_beyond(a, b, h + err, d2, tlimit);
 }
 // The premise above holds for UNIT directions only. The shader's Durand-Kerner update divides by the product of root
 // differences but not by the quartic's leading coefficient dot(rd,rd)^2, so for a direction of length L its steps are L^4
@@ -881,7 +889,11 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
 //      the two evaluations differ by rounding only, far less than the stored margin;
 //  (2) past that branch a hit needs a point of the ray strictly inside the clip box
 //      (checkSurfaceEdges); if the ray's LINE misses the box's inflated bounding sphere there is none.
-RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
+// Round 3: the test is one of the ray's SEGMENT, not of its line. intersect_surface accepts a root only for epsilon < t < tlimit (closest
+// hit so far / distance to the light) at a point inside the clip box, so a bound that lies behind the origin, or that the ray enters
+// beyond the limit, settles the quadric like a line that misses it (the closest-hit scan passes the tmin of the moment, which is the very
+// value intersect_surface would compare with).
+RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
 {
     if (!(Q.bound.w >= 0.0f)) return false;
     // p2 ~ d^T M d from the six direction products (ray-invariant) and the symmetric M of this quadric
@@ -896,7 +908,11 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd)
     const float d2 = dot3_fma(oc, oc);
     if (!(d2 <= Q.sym1.w)) return false;        // a clip box open along some axis: the bound only holds for origins this near (rt_pack.h)
     const float cc = d2 - Q.bound.w;
-    return fmaf(b, b, -(a * cc)) < -1e-5f * a * d2;  // rounding-safe (see sphere_cull); NaN -> false -> not culled
+    const float h = fmaf(b, b, -(a * cc)), err = 1e-5f * a * d2;
+    if (h < -err) return true;                  // the line misses: rounding-safe (see sphere_cull); NaN -> false -> not culled
+    if (!(cc > 0.0f)) return false;             // origin inside the bound
+    if (b >= 0.0f) return true;                 // the bound lies behind the origin
+    return sphere_entry_beyond(a, b, h + err, d2, tlimit);
 }
 
 // ---- second-level culls for long tables (RT_GROUP consecutive primitives under one sphere, built by the packer) ----
@@ -1002,6 +1018,42 @@ RT_HD uint32_t wave_or(uint32_t own, bool on)
     return uni;
 #else
     return on ? own : 0u;
+#endif
+}
+
+#if defined(RT_SCAN_STATS) && defined(__HIPCC__)
+// diagnostic build only (tools/scan_stats.py): how long are the quadric candidate lists of a WAVE against those of its lanes?
+// g_scan[kind][..]: kind 0 closest-hit/pencil, 1 closest-hit/slab tables, 2 shadow/pencil, 3 shadow/slab tables;
+// [0] wave-level word walks, [1] set bits of the wave's OR, [2] set bits of the lanes' own words, [3] participating lanes,
+// [4] largest lane count per walk, [5] second-level runs (some lane needs the exact test), [6] lanes in those runs, [7] walks with an empty OR
+__device__ unsigned long long g_scan[4][8];
+#endif
+RT_HD void scan_stats_word(int kind, uint32_t own, bool on, uint32_t uni)
+{
+#if defined(RT_SCAN_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long act = __ballot(on);
+    if (act == 0ull) return;
+    const int mine = on ? __builtin_popcount(own) : 0;
+    int mx = 0; unsigned long long m = act, tot = 0ull;
+    while (m) { const int l = __builtin_ctzll(m); const int v = __shfl(mine, l, 64); mx = v > mx ? v : mx; tot += (unsigned long long)v; m &= m - 1ull; }
+    if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) {
+        atomicAdd(&g_scan[kind][0], 1ull);
+        atomicAdd(&g_scan[kind][1], (unsigned long long)__builtin_popcount(uni));
+        atomicAdd(&g_scan[kind][2], tot);
+        atomicAdd(&g_scan[kind][3], (unsigned long long)__builtin_popcountll(act));
+        atomicAdd(&g_scan[kind][4], (unsigned long long)mx);
+        if (uni == 0u) atomicAdd(&g_scan[kind][7], 1ull);
+    }
+#endif
+}
+RT_HD void scan_stats_level2(int kind, bool need)
+{
+#if defined(RT_SCAN_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long nb = __ballot(need);
+    if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) {
+        atomicAdd(&g_scan[kind][5], 1ull);
+        atomicAdd(&g_scan[kind][6], (unsigned long long)__builtin_popcountll(nb));
+    }
 #endif
 }
 
@@ -1285,13 +1337,16 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
         for (int w = 0; w < nws; w++) {
-            uint32_t u = wave_or(ps.next(S, slabw), true);
+            const uint32_t own_w = ps.next(S, slabw);
+            uint32_t u = wave_or(own_w, true);
+            scan_stats_word(ps.mem ? 0 : 1, own_w, true, u);
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
                 const DevSurfaceCull c0 = cullrec[i];
-                const bool need = !surface_cull(c0, ro, rd);
+                const bool need = !surface_cull(c0, ro, rd, tmin);
                 if (RT_ANY(need)) {
+                    scan_stats_level2(ps.mem ? 0 : 1, need);
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
                 }
             }
@@ -1307,8 +1362,10 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             if (CULL) {
                 const DevSurfaceCull c0 = cullrec[i], c1 = cullrec[i + 1];
                 if (group_live) {
-                    need[0] = !surface_cull(c0, ro, rd);
-                    need[1] = need[1] && !surface_cull(c1, ro, rd);
+                    // the second of the pair is judged before the first has run: a lane that runs the first may see its tmin GROW (trap T4:
+                    // the degenerate branch accepts t > tmin), so only a lane that skips the first may hold the second to today's limit
+                    need[0] = !surface_cull(c0, ro, rd, tmin);
+                    need[1] = need[1] && !surface_cull(c1, ro, rd, need[0] ? RT_FLT_MAX : tmin);
                 } else {           // every lane misses the group: only the degenerate branch could still answer
                     need[0] = quadric_may_degenerate(c0, rd);
                     need[1] = need[1] && quadric_may_degenerate(c1, rd);
@@ -1452,13 +1509,16 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         const int nws = (S.h->n_surface + 31) >> 5;
         const DevSurfaceCull* cullrec = S.surf_cull();
         for (int w = 0; w < nws; w++) {
-            uint32_t u = wave_or(ps.next(S, slabw), on);
+            const uint32_t own_w = ps.next(S, slabw);
+            uint32_t u = wave_or(own_w, on);
+            scan_stats_word(ps.mem ? 2 : 3, own_w, on, u);
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
                 const DevSurfaceCull c0 = cullrec[i];
-                const bool need = on && !surface_cull(c0, ro, rd);
+                const bool need = on && !surface_cull(c0, ro, rd, dist);
                 if (RT_ANY(need)) {
+                    scan_stats_level2(ps.mem ? 2 : 3, need);
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; }
                     if (!RT_ANY(on)) u = 0u;
                 }
@@ -1475,8 +1535,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             if (CULL) {
                 const DevSurfaceCull c0 = cullrec[i], c1 = cullrec[i + 1];
                 if (group_live) {
-                    need[0] = need[0] && !surface_cull(c0, ro, rd);
-                    need[1] = need[1] && !surface_cull(c1, ro, rd);
+                    need[0] = need[0] && !surface_cull(c0, ro, rd, dist);
+                    need[1] = need[1] && !surface_cull(c1, ro, rd, dist);
                 } else {
                     need[0] = need[0] && quadric_may_degenerate(c0, rd);
                     need[1] = need[1] && quadric_may_degenerate(c1, rd);

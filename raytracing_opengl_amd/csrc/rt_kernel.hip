@@ -27,6 +27,17 @@ extern "C" __attribute__((visibility("default"))) int rtx_debug_dk_stats(unsigne
     return 0;
 }
 #endif
+#ifdef RT_SCAN_STATS
+extern "C" __attribute__((visibility("default"))) int rtx_debug_scan_stats(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 #ifdef RT_WG_TIMES
 // diagnostic build: per-workgroup start time and duration (s_memtime ticks) of the last launch, to see which tiles are the
 // long pole of a launch (tools/wg_times.py)

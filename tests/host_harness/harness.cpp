@@ -243,7 +243,7 @@ int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float 
         if (u01() < 0.1) rd = -rd;
         const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
         float t = 0.0f;
-        const bool cull = surface_cull(C, ro, rd);
+        const bool cull = surface_cull(C, ro, rd, tmin);
         const bool hit = intersect_surface(Q, ro, rd, tmin, t);
         c_cull += cull; c_hit += hit;
         if (cull && hit) {
@@ -408,7 +408,7 @@ int harness_kat(int type, const void* record, const float ro[3], const float rd[
     bool hit = false, cull = false;
     f3 nor = mk3(0, 0, 0);
     f2 uv = mk2(0, 0);
-    if (type == TYPE_SURFACE) { cull = surface_cull(S.surf_cull()[0], o, dd); hit = intersect_surface(S.surfaces()[0], o, dd, tmin, t); }
+    if (type == TYPE_SURFACE) { cull = surface_cull(S.surf_cull()[0], o, dd, tmin); hit = intersect_surface(S.surfaces()[0], o, dd, tmin, t); }
     if (type == TYPE_BOX) { RayBoxCtx bctx; hit = intersect_box(S.boxes()[0], o, dd, tmin, t, nor, bctx); }
     if (type == TYPE_TORUS) { bool solved; cull = torus_cull(S.torus_bound()[0], o, dd, tmin); if (!cull) { float t2; intersect_torus_c<true>(S.tori()[0], o, dd, tmin, t2, solved); cull = !solved; } hit = intersect_torus(S.tori()[0], o, dd, tmin, t); }
     if (type == TYPE_RING) { cull = ring_cull(S.ring_bound()[0], o, dd, tmin); hit = intersect_ring(S.rings()[0], o, dd, tmin, t, uv); }
