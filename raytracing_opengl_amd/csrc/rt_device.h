@@ -787,10 +787,33 @@ RT_HD bool ring_cull(f4 bound, f3 ro, f3 rd, float tlimit)
 // hole x^2+y^2 < (R-r)^2. true = the part of the ray with 0 < t <= tlimit never meets the
 // (1 %-inflated) puck, or crosses the puck's slab entirely inside the (deflated) hole. Margins as
 // in sphere_cull. Same premise as torus_cull: Durand-Kerner reports no root for a geometric miss.
+RT_HD float rt_sqrt_approx(float x)   // conservative predicates only: 1 ulp is as good as correctly rounded there
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
 {
     const float dd = dot3(d, d);
     if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
+    // Round 3 -- the convex hull of the torus: the points within r of the disc of radius R in the plane z = 0. With q the point of that
+    // disc nearest to the origin o and w = o - q, the disc lies in the half-space (x - q).w <= 0, so a ray with d.w >= 0 only ever moves
+    // away from it: dist(o + t d, disc) >= |w| for every t >= 0. |w| >= r + margin (T.cull.y, squared) then keeps the whole half-line outside
+    // the hull, and the torus inside it. This is the cull for the rays that START on a torus -- its own shadow and mirror rays, half of all
+    // solves that survive the other culls -- wherever the surface is convex (the outer half of the tube, where w is the surface normal
+    // and d.w > 0 for every shadow ray that is cast at all and every mirror ray). Outside the disc's rim (rho > R): q = R (o.x, o.y) / rho,
+    // w = ((rho - R) o.x / rho, (rho - R) o.y / rho, o.z), compared after multiplying by rho > 0; above the disc: w = (0, 0, o.z).
+    {
+        const float q2 = o.x * o.x + o.y * o.y, Ra = T.cull.z;
+        const bool rim = q2 > Ra * Ra;
+        const float rho = rt_sqrt_approx(q2), e = rim ? rho - Ra : 0.0f;
+        const float w2 = e * e + o.z * o.z;
+        const float away = rim ? e * (o.x * d.x + o.y * d.y) + rho * (o.z * d.z) : o.z * d.z;
+        if (w2 >= T.cull.y && away >= 0.0f) return true;   // NaN -> false -> not culled
+    }
     float t0 = 0.0f, t1 = gl_min(tlimit, 100.0f) * 1.001f + 0.01f;
     // slab |z| <= hz
     const float hz = T.cull.x;
@@ -1025,7 +1048,7 @@ RT_HD uint32_t wave_or(uint32_t own, bool on)
 // diagnostic build only (tools/scan_stats.py): how long are the quadric candidate lists of a WAVE against those of its lanes?
 // g_scan[kind][..]: kind 0 closest-hit/pencil, 1 closest-hit/slab tables, 2 shadow/pencil, 3 shadow/slab tables;
 // [0] wave-level word walks, [1] set bits of the wave's OR, [2] set bits of the lanes' own words, [3] participating lanes,
-// [4] largest lane count per walk, [5] second-level runs (some lane needs the exact test), [6] lanes in those runs, [7] walks with an empty OR
+// [4] largest lane count per walk, [5] second-level runs (some lane needs the exact test), [6] lanes in those runs, [7] lanes whose exact test HIT
 __device__ unsigned long long g_scan[4][8];
 #endif
 RT_HD void scan_stats_word(int kind, uint32_t own, bool on, uint32_t uni)
@@ -1042,8 +1065,13 @@ RT_HD void scan_stats_word(int kind, uint32_t own, bool on, uint32_t uni)
         atomicAdd(&g_scan[kind][2], tot);
         atomicAdd(&g_scan[kind][3], (unsigned long long)__builtin_popcountll(act));
         atomicAdd(&g_scan[kind][4], (unsigned long long)mx);
-        if (uni == 0u) atomicAdd(&g_scan[kind][7], 1ull);
     }
+#endif
+}
+RT_HD void scan_stats_hit(int kind)
+{
+#if defined(RT_SCAN_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(&g_scan[kind][7], 1ull);
 #endif
 }
 RT_HD void scan_stats_level2(int kind, bool need)
@@ -1347,7 +1375,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 const bool need = !surface_cull(c0, ro, rd, tmin);
                 if (RT_ANY(need)) {
                     scan_stats_level2(ps.mem ? 0 : 1, need);
-                    if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; }
+                    if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; scan_stats_hit(ps.mem ? 0 : 1); }
                 }
             }
         }
@@ -1519,7 +1547,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 const bool need = on && !surface_cull(c0, ro, rd, dist);
                 if (RT_ANY(need)) {
                     scan_stats_level2(ps.mem ? 2 : 3, need);
-                    if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; }
+                    if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; scan_stats_hit(ps.mem ? 2 : 3); }
                     if (!RT_ANY(on)) u = 0u;
                 }
             }

@@ -376,7 +376,9 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const double hole = (std::fabs(static_cast<double>(R)) - std::fabs(static_cast<double>(r))) * 0.99 - 0.01;
         s.k = mk4(4.0f * R2, static_cast<float>(rb * rb), static_cast<float>(rb * rb), hole > 0.0 ? static_cast<float>(hole * hole) : 0.0f);
         s.qinv = quat_inv(s.quat);
-        s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), 0.0f, 0.0f, 0.0f);
+        // y, z: the convex-hull cull of torus_local_cull -- (|r| + margin)^2 and |R|
+        const double hull = std::fabs(static_cast<double>(r)) + RT_TORUS_HULL_MARGIN;
+        s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), static_cast<float>(hull * hull), std::fabs(R), 0.0f);
         // The culls rest on "a geometric miss makes Durand-Kerner report no root". That holds for tori with a real tube
         // (validated on random rays), but not for degenerate ones: with tube radius 0 the solver, out of sweeps, can stop
         // on an iterate whose imaginary part happens to be below 1e-3 far away from the (zero-thickness) torus -- found by
@@ -394,7 +396,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         if (!real_tube || !unit_quat) {
             const float inf = std::numeric_limits<float>::infinity();
             s.k.y = inf; s.k.z = inf; s.k.w = 0.0f;
-            s.cull.x = inf;
+            s.cull.x = inf; s.cull.y = inf;
         }
         std::memcpy(reinterpret_cast<DevTorus*>(blob.data() + h.off_torus) + i, &s, sizeof s);
         const f4 tb = mk4(s.pos.x, s.pos.y, s.pos.z, s.k.y);

@@ -64,13 +64,16 @@ struct alignas(16) DevBox {
     f4 form_tex;       // half extents xyz, w = textureNum as float bits (int)
     f4 qinv;
 };
+#ifndef RT_TORUS_HULL_MARGIN
+#define RT_TORUS_HULL_MARGIN 2.5e-4   /* how far outside the torus' convex hull an origin must lie for the hull cull (rt_device.h torus_local_cull) */
+#endif
 struct alignas(16) DevTorus {
     f4 quat;
     f4 pos;            // xyz, w = int bits: 1 if quat is the identity
     f4 radii;          // R, r, R*R, r*r
     f4 k;              // x = 4*R*R, y = world cull-sphere radius^2, z = puck radius^2 ((R+r) inflated), w = hole radius^2 ((R-r) deflated, 0 = none)
     f4 qinv;
-    f4 cull;           // x = puck half height (r inflated), yzw unused
+    f4 cull;           // x = puck half height (r inflated), y = (r + RT_TORUS_HULL_MARGIN)^2, z = |R| (convex-hull cull), w unused
 };
 struct alignas(16) DevRing {
     f4 quat;

@@ -184,6 +184,72 @@ int harness_torus_premise(const void* record, int64_t n, uint64_t seed, float di
     return n_bad;
 }
 
+// Rays that START on the torus -- its own shadow and mirror rays, which the convex-hull cull of torus_local_cull is for: a point of the
+// surface, pushed out along the normal by a gap in [gap_lo, gap_hi] (log-uniform; the shader's hit bias is ~1e-3) and, like a hit point
+// that comes from a Durand-Kerner root, displaced ALONG the incoming ray by up to +-jitter; directions over the whole outward
+// hemisphere (with a share of grazing ones) and a tenth over the inward one. counts / bad as above.
+int harness_torus_surface_premise(const void* record, int64_t n, uint64_t seed, float gap_lo, float gap_hi, float jitter, int64_t counts[4], float* bad, int max_bad)
+{
+    rtpack::Defines d;
+    std::memset(&d, 0, sizeof d);
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    blocks[rtpack::BLK_SCENE].assign(64, 0);
+    d.torus_size = 1;
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    blocks[rtpack::BLK_TORUSES].assign(p, p + rtpack::kRecordSize[rtpack::BLK_TORUSES]);
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(d, blocks, blob, err)) return -2;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    const DevTorus T = S.tori()[0];
+    const double R = T.radii.x, r = T.radii.y;
+    int64_t c_cull = 0, c_hit = 0, c_bad = 0;
+    int n_bad = 0;
+#pragma omp parallel for schedule(static, 4096) reduction(+ : c_cull, c_hit, c_bad)
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t x = seed * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(k) * 0xbf58476d1ce4e5b9ull + 1;
+        auto u01 = [&]() { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return (x >> 11) * (1.0 / 9007199254740992.0); };
+        auto gauss = [&]() { double a = 0; for (int i = 0; i < 6; i++) a += u01(); return (a - 3.0) * 1.41421356; };
+        const double phi = 6.283185307179586 * u01(), th = 6.283185307179586 * u01();
+        const double cp = std::cos(phi), sp = std::sin(phi), ct = std::cos(th), st = std::sin(th);
+        const double nx = ct * cp, ny = ct * sp, nz = st;                       // outward normal of the tube (torus frame, axis z)
+        const double gap = gap_lo * std::pow(static_cast<double>(gap_hi) / gap_lo, u01());
+        // outgoing direction: around the normal, a third of them within a few degrees of the tangent plane
+        double dx, dy, dz, dn;
+        do { dx = gauss(); dy = gauss(); dz = gauss(); const double l = std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30; dx /= l; dy /= l; dz /= l; dn = dx * nx + dy * ny + dz * nz; } while (false);
+        if (u01() < 0.33) {   // grazing: squash the normal component
+            const double f = 0.05 * u01();
+            dx -= (1.0 - f) * dn * nx; dy -= (1.0 - f) * dn * ny; dz -= (1.0 - f) * dn * nz;
+            const double l = std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30; dx /= l; dy /= l; dz /= l; dn = dx * nx + dy * ny + dz * nz;
+        }
+        if ((dn < 0.0) != (u01() < 0.1)) { dx = -dx; dy = -dy; dz = -dz; }
+        // the incoming ray the point was "hit" by: the error of its root moves the point along it
+        double ix = gauss(), iy = gauss(), iz = gauss();
+        const double il = std::sqrt(ix * ix + iy * iy + iz * iz) + 1e-30;
+        const double jt = jitter * (2.0 * u01() - 1.0);
+        const double lx = (R + r * ct) * cp + nx * gap + ix / il * jt, ly = (R + r * ct) * sp + ny * gap + iy / il * jt, lz = r * st + nz * gap + iz / il * jt;
+        const f3 ol = mk3((float)lx, (float)ly, (float)lz), dl = mk3((float)dx, (float)dy, (float)dz);
+        const f3 ro = quat_rotate(T.qinv, ol) + xyz(T.pos);
+        const f3 rd = quat_rotate(T.qinv, dl);
+        const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
+        bool solved = false;
+        float t = 0.0f, t2 = 0.0f;
+        bool cull = torus_cull(S.torus_bound()[0], ro, rd, tmin);
+        if (!cull) { intersect_torus_c<true>(T, ro, rd, tmin, t2, solved); cull = !solved; }
+        const bool hit = intersect_torus(T, ro, rd, tmin, t);
+        c_cull += cull; c_hit += hit;
+        if (cull && hit) {
+            c_bad++;
+#pragma omp critical
+            if (n_bad < max_bad) { float* o = bad + 7 * n_bad++; o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = tmin; }
+        }
+    }
+    counts[0] = n; counts[1] = c_cull; counts[2] = c_hit; counts[3] = c_bad;
+    return n_bad;
+}
+
 // The packed first-level cull record of one quadric: out = bound xyz, radius^2 (negative: none), |p2| margin.
 int harness_surface_bound(const void* record, float out[5])
 {

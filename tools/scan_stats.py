@@ -31,9 +31,9 @@ def main():
         for k in range(4):
             r = v[8 * k: 8 * k + 8]
             n = max(r[0], 1)
-            print(f"  {KINDS[k]}: {r[0]} word walks ({r[7]} with an empty OR); per walk: wave OR {r[1]/n:.2f} bits, "
+            print(f"  {KINDS[k]}: {r[0]} word walks; per walk: wave OR {r[1]/n:.2f} bits, "
                   f"busiest lane {r[4]/n:.2f}, mean lane {r[2]/max(r[3],1):.2f} ({r[3]/n:.1f} lanes); "
-                  f"second-level runs {r[5]/n:.2f} with {r[6]/max(r[5],1):.1f} lanes each")
+                  f"second-level runs {r[5]/n:.2f} with {r[6]/max(r[5],1):.1f} lanes each, of which {r[7]/max(r[6],1):.2f} hit")
         gl.stop()
 
 
