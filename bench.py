@@ -53,7 +53,20 @@ def emit(out):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)
+
+
+_JSON_OUT = None
+
+
+def keep_stdout_for_the_json_line():
+    """From here on file descriptor 1 is stderr for everything but emit(): RCCL prints a five-line version banner through C stdio when a
+    communicator is created (N > 1, and the loopback diagnostic), and whoever reads this process' stdout expects ONE line of JSON."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
@@ -234,6 +247,7 @@ def main():
             port = so.getsockname()[1]
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    keep_stdout_for_the_json_line()
     # how the N ranks are driven: "single" = plain context (N = 1); "multi" = one process, rtx_create_multi; "ranks" = one process per GPU,
     # rtx_create_rank; "torch" = one process per GPU, rtx_draw_bands + dist.gather (the Python path)
     if args.gpus == 1 and args.transport != "loopback":

@@ -174,6 +174,8 @@ def _run_bench(extra, torchrun=False, timeout=600):
     cmd = head + [os.path.join(root, "bench.py"), "--width", "640", "--height", "360", "--steps", "4", "--warmup", "2", "--texture-scale", "16", "--no-cpu-baseline", "--no-smaa"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode == 0:   # stdout is the ONE line of JSON and nothing else (RCCL's version banner used to precede it)
+        assert [l for l in r.stdout.splitlines() if l.strip()] == lines[-1:], r.stdout[:2000]
     return r, (json.loads(lines[-1]) if lines else None)
 
 
