@@ -929,8 +929,9 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
     const f3 oc = ro - xyz(Q.bound);
     const float b = dot3_fma(oc, rd);
     const float d2 = dot3_fma(oc, oc);
-    if (!(d2 <= Q.sym1.w)) return false;        // a clip box open along some axis: the bound only holds for origins this near (rt_pack.h)
-    const float cc = d2 - Q.bound.w;
+    // near origins: the tight bound (it may rest on the fattened surface's own extent, which grows with the distance it is looked at from);
+    // far ones: the bound of the closed clip box, if there is one (NaN: none -- the comparisons below then never cull)
+    const float cc = d2 - (d2 <= (float)(RT_QUADRIC_FAR * RT_QUADRIC_FAR) ? Q.bound.w : Q.sym1.w);
     const float h = fmaf(b, b, -(a * cc)), err = 1e-5f * a * d2;
     if (h < -err) return true;                  // the line misses: rounding-safe (see sphere_cull); NaN -> false -> not culled
     if (!(cc > 0.0f)) return false;             // origin inside the bound
@@ -1106,9 +1107,9 @@ RT_HD PencilPrim pencil_prim(const DevPencil& P, f4 bound, const DevSurfaceCull*
         if (P.kind == RT_PENCIL_PARALLEL) r.a.w = fabsf(quadric_p2(*Q, xyz(P.a)));
     }
     if (!(bound.w >= 0.0f)) return r;                                  // no bound (or NaN): every cell
-    if (Q && !(Q->sym1.w > 1.0e30f)) return r;                         // a bound that only holds for origins near the quadric: every cell
+    if (Q && !(Q->sym1.w >= 0.0f)) return r;                           // no bound that holds for origins at any distance: every cell
     const f3 c = xyz(bound);
-    const float rad = sqrtf(bound.w) + 4.0e-3f + 1.0e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
+    const float rad = sqrtf(Q ? Q->sym1.w : bound.w) + 4.0e-3f + 1.0e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
     if (P.kind == RT_PENCIL_APEX) {
         const f3 v = c - xyz(P.a);
         const float D2 = dot3(v, v);

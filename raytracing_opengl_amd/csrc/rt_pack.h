@@ -10,15 +10,15 @@
 #include <limits>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 
 #include "rt_device.h"
 
-#ifndef RT_QUADRIC_FAR
-#define RT_QUADRIC_FAR 64.0   /* quadrics with an open clip box: their bound holds for origins up to this far from its centre (pack_scene) */
-#endif
 
 namespace rtpack {
 using namespace rtdev;
@@ -186,6 +186,121 @@ inline bool quadric_clip_bounds(const double A[3][3], const double w[3], const d
     return true;
 }
 
+// Round 3 -- where inside a (finite) box can the fattened surface { |F(x)| <= tau }, F(x) = (x-p)^T A (x-p) + w^T (x-p) + f, be at all?
+// An octree over the box, three levels deep (8 x 8 x 8 leaves), keeps the cells that cannot be ruled out: for x = c + d in a cell with centre
+// c and half widths h, F(x) = F(c) + grad F(c).d + d^T A d, so |F(c)| > sum |g_k| h_k + sum |A_ij| h_i h_j + tau leaves no point of the
+// fattened surface in the cell (rigorous; evaluated in double). The clip box of a quadric says where a hit may lie, this says where the
+// surface is: a cylinder of radius 0.5 in a 2.4-cube keeps a fifth of the cube's leaves, an ellipsoid of semi-axes 0.8 / 1.1 a tenth, and
+// the bounding sphere of the kept leaves is what the first-level test needs. Collects the leaves' corner boxes in `leaves` (lo xyz, hi xyz).
+struct QuadricCells {
+    double A[3][3], w[3], p[3], f, tau;
+    std::vector<double> leaves;
+    bool may_hold(const double lo[3], const double hi[3]) const
+    {
+        double c[3], hw[3], v[3];
+        for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]); hw[k] = 0.5 * (hi[k] - lo[k]); v[k] = c[k] - p[k]; }
+        double Fc = f, g[3], slack = tau;
+        for (int r = 0; r < 3; r++) {
+            double Av = 0.0;
+            for (int q = 0; q < 3; q++) { Av += A[r][q] * v[q]; slack += std::fabs(A[r][q]) * hw[r] * hw[q]; }
+            Fc += v[r] * Av + w[r] * v[r];
+            g[r] = 2.0 * Av + w[r];
+        }
+        for (int k = 0; k < 3; k++) slack += std::fabs(g[k]) * hw[k];
+        return !(std::fabs(Fc) > slack * (1.0 + 1e-9) + 1e-12);    // NaN: may hold
+    }
+    void descend(const double lo[3], const double hi[3], int depth)
+    {
+        if (!may_hold(lo, hi)) return;
+        if (depth == 0) { leaves.insert(leaves.end(), lo, lo + 3); leaves.insert(leaves.end(), hi, hi + 3); return; }
+        for (int o = 0; o < 8; o++) {
+            double l[3], u[3];
+            for (int k = 0; k < 3; k++) {
+                const double m = 0.5 * (lo[k] + hi[k]);
+                l[k] = (o >> k) & 1 ? m : lo[k];
+                u[k] = (o >> k) & 1 ? hi[k] : m;
+            }
+            descend(l, u, depth - 1);
+        }
+    }
+    // radius of the smallest sphere about c that holds every kept leaf (0 if none is kept)
+    double radius_about(const double c[3]) const
+    {
+        double r2 = 0.0;
+        for (size_t i = 0; i + 6 <= leaves.size(); i += 6) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; k++) { const double d = std::fmax(std::fabs(leaves[i + k] - c[k]), std::fabs(leaves[i + 3 + k] - c[k])); d2 += d * d; }
+            r2 = std::fmax(r2, d2);
+        }
+        return std::sqrt(r2);
+    }
+    // The same to a resolution of `eps`, by branch and bound: always split the cell whose farthest corner is farthest from c, drop the
+    // children that cannot hold the surface; when the farthest cell is smaller than eps its farthest corner bounds everything (a few hundred
+    // cells; the 8 x 8 x 8 leaves alone would add up to their own diagonal to the radius).
+    double radius_about_fine(const double c[3], const double lo[3], const double hi[3], double eps) const
+    {
+        struct Cell { double far2, lo[3], hi[3]; };
+        auto far2_of = [&](const double l[3], const double u[3]) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; k++) { const double d = std::fmax(std::fabs(l[k] - c[k]), std::fabs(u[k] - c[k])); d2 += d * d; }
+            return d2;
+        };
+        auto less = [](const Cell& x, const Cell& y) { return x.far2 < y.far2; };
+        std::vector<Cell> heap;
+        if (!may_hold(lo, hi)) return 0.0;
+        Cell root;
+        for (int k = 0; k < 3; k++) { root.lo[k] = lo[k]; root.hi[k] = hi[k]; }
+        root.far2 = far2_of(lo, hi);
+        heap.push_back(root);
+        for (int guard = 0; guard < 20000 && !heap.empty(); guard++) {
+            std::pop_heap(heap.begin(), heap.end(), less);
+            const Cell top = heap.back();
+            heap.pop_back();
+            const double size = std::fmax(top.hi[0] - top.lo[0], std::fmax(top.hi[1] - top.lo[1], top.hi[2] - top.lo[2]));
+            if (size <= eps) return std::sqrt(top.far2);
+            for (int o = 0; o < 8; o++) {
+                Cell ch;
+                for (int k = 0; k < 3; k++) {
+                    const double m = 0.5 * (top.lo[k] + top.hi[k]);
+                    ch.lo[k] = (o >> k) & 1 ? m : top.lo[k];
+                    ch.hi[k] = (o >> k) & 1 ? top.hi[k] : m;
+                }
+                if (!may_hold(ch.lo, ch.hi)) continue;
+                ch.far2 = far2_of(ch.lo, ch.hi);
+                heap.push_back(ch);
+                std::push_heap(heap.begin(), heap.end(), less);
+            }
+        }
+        if (heap.empty()) return 0.0;     // every cell was ruled out
+        double r2 = 0.0;                  // guard hit: the cells still open bound the rest
+        for (const Cell& x : heap) r2 = std::fmax(r2, x.far2);
+        return std::sqrt(r2);
+    }
+    // a good centre when it can be chosen freely: start at the middle of the leaves' box and walk towards the farthest leaf corner while
+    // that shrinks the radius (Ritter's idea; the radius is always recomputed exactly, so whatever the walk does the sphere holds the leaves)
+    double free_sphere(double c[3]) const
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = 0; i + 6 <= leaves.size(); i += 6)
+            for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], leaves[i + k]); hi[k] = std::fmax(hi[k], leaves[i + 3 + k]); }
+        for (int k = 0; k < 3; k++) c[k] = 0.5 * (lo[k] + hi[k]);
+        double best = radius_about(c);
+        for (int it = 0; it < 24; it++) {
+            double far[3] = {c[0], c[1], c[2]}, fd2 = -1.0;
+            for (size_t i = 0; i + 6 <= leaves.size(); i += 6) {
+                double q[3], d2 = 0.0;
+                for (int k = 0; k < 3; k++) { q[k] = std::fabs(leaves[i + k] - c[k]) > std::fabs(leaves[i + 3 + k] - c[k]) ? leaves[i + k] : leaves[i + 3 + k]; d2 += (q[k] - c[k]) * (q[k] - c[k]); }
+                if (d2 > fd2) { fd2 = d2; far[0] = q[0]; far[1] = q[1]; far[2] = q[2]; }
+            }
+            const double step = 0.5 / (it + 2.0);
+            double t[3] = {c[0] + step * (far[0] - c[0]), c[1] + step * (far[1] - c[1]), c[2] + step * (far[2] - c[2])};
+            const double r = radius_about(t);
+            if (r < best) { best = r; c[0] = t[0]; c[1] = t[1]; c[2] = t[2]; }
+        }
+        return best;
+    }
+};
+
 // blocks[b] may be shorter than count*record (or empty): returns false and sets err.
 inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks[BLK_COUNT], std::vector<unsigned char>& blob, std::string& err)
 {
@@ -312,9 +427,26 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             const double lo[3] = {vmin.x, vmin.y, vmin.z}, hi[3] = {vmax.x, vmax.y, vmax.z};
             double clo[3], chi[3];
             sc.bound = mk4(0.0f, 0.0f, 0.0f, -1.0f);
-            sc.sym1.w = std::numeric_limits<float>::infinity();     // the bound holds for origins at any distance
+            sc.sym1.w = std::numeric_limits<float>::quiet_NaN();    // no bound that holds for origins at any distance (yet)
             bool from_surface = false;
-            if (quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi, 0.0, from_surface)) {
+            // The bounds are a pure function of the 160-byte record and cost ~0.1 ms of branch and bound: a program that re-uploads all
+            // its blocks every frame (the reference's main loop does, main.cpp:246) gets them from a small cache.
+            struct CachedBounds { f4 bound; float far_w; double aabb[6]; };
+            static std::mutex cache_mu;
+            static std::unordered_map<std::string, CachedBounds> cache;
+            const std::string cache_key(reinterpret_cast<const char*>(p), SZ_SURFACE);
+            bool cached = false;
+            {
+                std::lock_guard<std::mutex> g(cache_mu);
+                const auto it = cache.find(cache_key);
+                if (it != cache.end()) {
+                    cached = true;
+                    sc.bound = it->second.bound;
+                    sc.sym1.w = it->second.far_w;
+                    for (int k = 0; k < 6; k++) surf_aabb[i * 6 + k] = it->second.aabb[k];
+                }
+            }
+            if (!cached && quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi, 0.0, from_surface)) {
                 auto sphere = [&](double& cx, double& cy, double& cz) {
                     cx = 0.5 * (clo[0] + chi[0]); cy = 0.5 * (clo[1] + chi[1]); cz = 0.5 * (clo[2] + chi[2]);
                     const double hx = 0.5 * (chi[0] - clo[0]), hy = 0.5 * (chi[1] - clo[1]), hz = 0.5 * (chi[2] - clo[2]);
@@ -344,10 +476,44 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                     far2 = far * far;
                 }
                 if (ok && rad == rad && rad < 1.0e15) {
-                    sc.bound = mk4(static_cast<float>(cx), static_cast<float>(cy), static_cast<float>(cz), static_cast<float>(rad * rad));
-                    sc.sym1.w = static_cast<float>(far2);
+                    // (cx, cy, cz, rad): the sphere of the box [clo, chi] the clipped surface lies in. If the clip box is closed this bound
+                    // holds whatever the reference's arithmetic does and wherever the ray starts (sym1.w); `tight` is the sphere of the
+                    // part of that box the (fattened) surface can be in at all -- for origins within RT_QUADRIC_FAR (bound.w).
+                    double tight = rad, tc[3] = {cx, cy, cz};
+                    if (rad < 1.0e6) {
+                        QuadricCells cells;
+                        for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) cells.A[r][q] = A[r][q]; cells.w[r] = wv[r]; cells.p[r] = pw[r]; }
+                        cells.f = f;
+                        const double coef = std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(dd) + std::fabs(e) + std::fabs(f);
+                        const double reach = 2.0 * (RT_QUADRIC_FAR + rad) + 3.0 * std::sqrt((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2])) + 1.0;
+                        cells.tau = 64.0 / 16777216.0 * coef * reach * reach;     // as above: what the float evaluation can mistake for the surface
+                        if (from_surface) cells.descend(clo, chi, 3);     // the leaves choose the centre; the radius is refined below
+                        if (!cells.may_hold(clo, chi) || (from_surface && cells.leaves.empty())) {
+                            tight = 0.0;                 // the surface does not reach into its clip box at all
+                        } else if (from_surface) {
+                            double c2[3];
+                            cells.free_sphere(c2);
+                            const double r2 = cells.radius_about_fine(c2, clo, chi, 0.02 * rad) * 1.01 + 0.01;
+                            if (r2 < rad) { tight = r2; tc[0] = c2[0]; tc[1] = c2[1]; tc[2] = c2[2]; }
+                        } else {
+                            tight = std::fmin(rad, cells.radius_about_fine(tc, clo, chi, 0.02 * rad) * 1.01 + 0.01);     // same centre: the far bound stays the clip box' own
+                        }
+                    }
+                    if (!(tight == tight)) tight = rad;
+                    sc.bound = mk4(static_cast<float>(tc[0]), static_cast<float>(tc[1]), static_cast<float>(tc[2]), static_cast<float>(tight * tight * (1.0 + 1e-6)));
+                    sc.sym1.w = from_surface ? std::numeric_limits<float>::quiet_NaN() : static_cast<float>(rad * rad);
+                    (void)far2;
                     for (int k = 0; k < 3; k++) { surf_aabb[i * 6 + k] = clo[k]; surf_aabb[i * 6 + 3 + k] = chi[k]; }
                 }
+            }
+            if (!cached) {
+                CachedBounds cb;
+                cb.bound = sc.bound;
+                cb.far_w = sc.sym1.w;
+                for (int k = 0; k < 6; k++) cb.aabb[k] = surf_aabb[i * 6 + k];
+                std::lock_guard<std::mutex> g(cache_mu);
+                if (cache.size() > 4096) cache.clear();
+                cache.emplace(cache_key, cb);
             }
         }
         std::memcpy(reinterpret_cast<DevSurface*>(blob.data() + h.off_surface) + i, &s, sizeof s);
@@ -453,7 +619,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     };
     group_bounds(d.surface_size, h.off_surf_group, [&](int i) {
         const DevSurfaceCull* q = reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + i;
-        return std::isinf(q->sym1.w) ? q->bound : mk4(0.0f, 0.0f, 0.0f, -1.0f);     // a bound that only holds near the quadric: no group cull
+        return q->sym1.w >= 0.0f && q->bound.w >= 0.0f ? mk4(q->bound.x, q->bound.y, q->bound.z, q->sym1.w) : mk4(0.0f, 0.0f, 0.0f, -1.0f);     // the bound that holds at any distance, or no group cull
     });
     group_bounds(d.torus_size, h.off_torus_group, [&](int i) { return reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i]; });
     for (int i = 0; i < d.light_point_size; i++) {
@@ -548,8 +714,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                 bool usable;
                 if (k < d.surface_size) {
                     const DevSurfaceCull* q = reinterpret_cast<const DevSurfaceCull*>(blob.data() + h.off_surf_cull) + k;
-                    b = q->bound;
-                    usable = std::isinf(q->sym1.w);        // a bound that only holds near the quadric is no bound here
+                    b = mk4(q->bound.x, q->bound.y, q->bound.z, q->sym1.w);
+                    usable = q->bound.w >= 0.0f && q->sym1.w >= 0.0f;        // a bound that only holds near the quadric is no bound here
                 } else {
                     b = reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[k - d.surface_size];
                     usable = true;

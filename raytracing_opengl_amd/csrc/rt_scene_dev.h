@@ -53,10 +53,17 @@ struct alignas(16) DevSurface {
     f4 vmax;           // v_max xyz, w = int bits: 1 if quat is the identity (any zero signs)
     f4 qinv;           // quat_inv(quat)
 };
+#ifndef RT_QUADRIC_FAR
+#define RT_QUADRIC_FAR 64.0   /* a quadric bound that rests on the surface's own extent holds for origins up to this far from its centre (rt_pack.h pack_scene) */
+#endif
 struct alignas(16) DevSurfaceCull {  // first-level record of a quadric (surface_cull)
-    f4 bound;          // cull sphere of the CLIPPED surface: centre xyz (world), w = radius^2 (inflated); w < 0: unbounded
+    f4 bound;          // cull sphere of the CLIPPED surface: centre xyz (world), w = radius^2 (inflated); w < 0: unbounded. It may rest on the
+                       // surface's own extent (the FATTENED surface the reference's float arithmetic sees, rt_pack.h) and then holds for origins
+                       // within RT_QUADRIC_FAR of the centre only
     f4 sym0;           // symmetric M = R^T diag(a,b,c) R : m00, m01, m02, m11
-    f4 sym1;           // m12, m22, |p2| margin, w = squared distance from the bound's centre up to which the bound holds (inf: any)
+    f4 sym1;           // m12, m22, |p2| margin, w = radius^2 about the same centre of a bound that holds for origins at ANY distance (the sphere
+                       // of a closed clip box: a hit lies in the box whatever the arithmetic does) -- what far origins and the candidate tables
+                       // (pencils, slab tables, group culls) use; NaN: none (a clip box open along some axis)
 };
 struct alignas(16) DevBox {
     f4 quat;
