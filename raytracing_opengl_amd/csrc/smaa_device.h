@@ -24,6 +24,17 @@
 #define SM_HDM inline
 #endif
 
+#ifndef SMAA_DIAG_IN_STEP
+#define SMAA_DIAG_IN_STEP 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SM_ANY(x) (__any((x)) != 0)     /* some lane of the wave */
+#else
+#define SM_ANY(x) (x)
+#endif
+#ifndef SMAA_PH
+#define SMAA_PH(k)      /* diagnostic build only (smaa_kernel.hip, -DSMAA_PHASE_TIMES): a timestamp per wave at the convergent points of weights() */
+#endif
 namespace smaa {
 
 struct Preset {            // SMAA.h:304-324
@@ -246,41 +257,80 @@ struct SearchPlanes {
         pair[1] = ok[1] & ((ok[1] >> 2) | (ok[2] << 62));
         pair[2] = ok[2] & (ok[2] >> 2);
     }
-    // fetches the loop of search_x consumes for pixel (x, y): dir < 0 left, > 0 right; -1 = window not inside the frame
+    // fetches the loop of search_x consumes for pixel (x, y): dir < 0 left, > 0 right; -1 = no planes.
+    // Round 3: windows that reach beyond the frame are counted too. The samplers clamp every tap's index on its own (CLAMP_TO_EDGE), so
+    // beyond the frame the string of per-position conditions simply repeats its border position -- ok[c] = ok[0] for c < 0, ok[w - 1] for
+    // c > w - 1, and row y - 1 of row 0 is row 0 -- and "the step at c goes on iff ok[c] & ok[c + 1]" holds as before. (Until then such
+    // pixels -- everything within 2 max_steps + 2 of the frame's border -- walked their edges step by step: up to eight dependent round
+    // trips per search, and the few waves that held them were the last to finish: 28 us for the slowest wave of the traced 4K frame
+    // against 18 for the 95th percentile, tools/smaa_phase_times.py.)
+    // (All loads of a count are issued first, from clamped indices, and the repetition is applied with selects afterwards: a branch between
+    // the loads makes the compiler wait for each before the next is issued -- 24 dependent latencies instead of one, measured.)
+    SM_HDM static uint64_t spread(uint64_t bit) { return (0ull - (bit & 1ull)) & 0x5555555555555555ull; }
     SM_HDM int count_x(int x, int y, int S, bool left) const
     {
-        if (rows == nullptr || y < 1) return -1;
-        const int c_lo = left ? x - 1 - 2 * (S - 1) : x + 1, c_hi = left ? x : x + 2 + 2 * (S - 1);
-        if (c_lo < 0 || c_hi > w - 1) return -1;
-        const int pw = plane_words(w), w0 = c_lo >> 5;
+        if (rows == nullptr) return -1;
+        const int c_lo = left ? x - 1 - 2 * (S - 1) : x + 1;
+        const int pw = plane_words(w), w0 = c_lo >> 5, qlast = (w - 1) >> 5, tail = (w - 1) & 31;     // (>> of a negative int: arithmetic)
+        const int ym = y > 0 ? y - 1 : 0;
         const uint64_t M = 0x5555555555555555ull;
-        uint64_t ok[3], pair[3];
+        const uint64_t beyond = tail != 31 ? M & (~0ull << (2 * ((tail + 1) & 31))) : 0ull;
+        uint64_t q1[3], q0[3], ok[3], pair[3];
         for (int k = 0; k < 3; k++) {
-            const int q = w0 + k < pw ? w0 + k : pw - 1;
-            const uint64_t q1 = rows[(size_t)y * pw + q], q0 = rows[(size_t)(y - 1) * pw + q];
-            ok[k] = (q1 >> 1) & ~q1 & ~q0 & M;
+            const int qi = w0 + k, q = qi < 0 ? 0 : (qi > qlast ? qlast : qi);
+            q1[k] = rows[(size_t)y * pw + q];
+            q0[k] = rows[(size_t)ym * pw + q];
+        }
+        const bool over = c_lo < 0 || c_lo + 2 * S + 1 > w - 1;     // the window hangs over the frame: rare, decided per wave after the loads
+        if (SM_ANY(over)) {
+            for (int k = 0; k < 3; k++) {
+                const int qi = w0 + k;
+                const uint64_t o = (q1[k] >> 1) & ~q1[k] & ~q0[k] & M;
+                const uint64_t first = spread(o), last = spread(o >> (2 * tail));
+                ok[k] = qi < 0 ? first : (qi > qlast ? last : (qi == qlast ? (o & ~beyond) | (last & beyond) : o));
+            }
+        } else {
+            for (int k = 0; k < 3; k++) ok[k] = (q1[k] >> 1) & ~q1[k] & ~q0[k] & M;
         }
         pair_of(ok, pair);
         const int f = first_fail(pair, (left ? x - 1 : x + 1) - 32 * w0, S, left);
         return f + 1 < S ? f + 1 : S;
     }
-    // the same for search_y: up = towards smaller y
+    // the same for search_y: up = towards smaller y. A word of the column plane holds 8 rows: the replication is per 16-bit block.
     SM_HDM int count_y(int x, int y, int S, bool up) const
     {
-        if (rows == nullptr || x < 1) return -1;
-        const int r_lo = up ? y - 1 - 2 * (S - 1) : y + 1, r_hi = up ? y : y + 2 + 2 * (S - 1);
-        if (r_lo < 0 || r_hi > h - 1) return -1;
-        const int nb = (h + 7) >> 3, b0 = r_lo >> 3;
-        const uint64_t M = 0x5555555555555555ull;
+        if (rows == nullptr) return -1;
+        const int r_lo = up ? y - 1 - 2 * (S - 1) : y + 1;
+        const int nb = (h + 7) >> 3, b0 = r_lo >> 3, btail = (h - 1) & 7;
+        const int xm = x > 0 ? x - 1 : 0;
+        const uint32_t beyond = btail != 7 ? 0x5555u & (0xffffu << (2 * ((btail + 1) & 7))) : 0u;
+        uint32_t qa[12], qb[12];
         uint64_t ok[3], pair[3];
-        for (int k = 0; k < 3; k++) {
-            uint64_t qa = 0ull, qb = 0ull;
-            for (int m = 0; m < 4; m++) {
-                const int blk = b0 + 4 * k + m < nb ? b0 + 4 * k + m : nb - 1;
-                qa |= (uint64_t)cols[(size_t)blk * w + x - 1] << (16 * m);
-                qb |= (uint64_t)cols[(size_t)blk * w + x] << (16 * m);
+        for (int j = 0; j < 12; j++) {
+            const int bi = b0 + j, blk = bi < 0 ? 0 : (bi > nb - 1 ? nb - 1 : bi);
+            qa[j] = cols[(size_t)blk * w + xm];
+            qb[j] = cols[(size_t)blk * w + x];
+        }
+        const bool over = r_lo < 0 || r_lo + 2 * S + 1 > h - 1;
+        if (SM_ANY(over)) {
+            for (int k = 0; k < 3; k++) {
+                uint64_t o = 0ull;
+                for (int m = 0; m < 4; m++) {
+                    const int j = 4 * k + m, bi = b0 + j;
+                    const uint32_t ob = qb[j] & ~(qa[j] >> 1) & ~(qb[j] >> 1) & 0x5555u;     // red of column x, no green in either column
+                    const uint32_t first = (0u - (ob & 1u)) & 0x5555u, last = (0u - ((ob >> (2 * btail)) & 1u)) & 0x5555u;
+                    const uint32_t r = bi < 0 ? first : (bi > nb - 1 ? last : (bi == nb - 1 ? (ob & ~beyond) | (last & beyond) : ob));
+                    o |= (uint64_t)r << (16 * m);
+                }
+                ok[k] = o;
             }
-            ok[k] = qb & ~(qa >> 1) & ~(qb >> 1) & M;     // red of column x, no green in either column
+        } else {
+            const uint64_t M = 0x5555555555555555ull;
+            for (int k = 0; k < 3; k++) {
+                uint64_t a = 0ull, b = 0ull;
+                for (int m = 0; m < 4; m++) { a |= (uint64_t)qa[4 * k + m] << (16 * m); b |= (uint64_t)qb[4 * k + m] << (16 * m); }
+                ok[k] = b & ~(a >> 1) & ~(b >> 1) & M;
+            }
         }
         pair_of(ok, pair);
         const int f = first_fail(pair, (up ? y - 1 : y + 1) - 8 * b0, S, up);
@@ -374,6 +424,65 @@ struct BlendT {
         if (!(edges_at(X, Y, 1, 0).x > 0.0f)) return F2{0.0f, 0.0f};
         const F2 r = search_diag2(X, Y, 1.0f, 1.0f, end);
         return F2{r.x + ((end.y > 0.9f) ? 1.0f : 0.0f), r.y};
+    }
+    // The four diagonal searches of a pixel IN STEP (round 3): every round issues the next SEARCH_BATCH fetches of all searches that are
+    // still running -- raw texel loads only, one per step for the first pair (their positions are texel centres), two for the second
+    // (x + 0.25: weights 0.75 / 0.25, the row weights 1 / 0) -- and only then consumes them, each search in its own order with its own
+    // stopping test: the same fetches, values and results as diag_search(0..3) one after the other, but the wave waits for ONE memory round
+    // trip per round instead of one per search and round (a wave is as slow as its slowest lane: with four searches of up to four rounds
+    // one after the other, the waves that held a long diagonal were the last of the kernel to finish -- tools/smaa_phase_times.py).
+    // No branch sits between a load and the next load: the compiler waits for a load where its value is first used.
+    SM_HDM void diag_searches(float X, float Y, F2 e, F2 out[4]) const
+    {
+        const float last = (float)(P.max_steps_diag - 1);
+        const float dx[4] = {-1.0f, 1.0f, -1.0f, 1.0f}, dy[4] = {1.0f, -1.0f, -1.0f, 1.0f};
+        float tx[4] = {X, X, X + 0.25f, X + 0.25f}, ty[4] = {Y, Y, Y, Y}, n[4] = {-1.0f, -1.0f, -1.0f, -1.0f}, wgt[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        F2 end[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+        bool on[4];
+        on[0] = e.x > 0.0f;
+        on[1] = true;
+        on[2] = true;
+        on[3] = edges_at(X, Y, 1, 0).x > 0.0f;
+        const bool gate0 = on[0], gate3 = on[3];
+        const int wm = V.w - 1, hm = V.h - 1;
+        while (SM_ANY(on[0] || on[1] || on[2] || on[3])) {
+            uint32_t r0[4][SEARCH_BATCH], r1[2][SEARCH_BATCH];     // r0: the texel at floor(position); r1: its right neighbour (second pair only)
+            for (int s = 0; s < 4; s++) {
+                if (!SM_ANY(on[s])) continue;                      // wave-uniform
+                float px = tx[s], py = ty[s];
+                for (int k = 0; k < SEARCH_BATCH; k++) {
+                    px = 1.0f * dx[s] + px;
+                    py = 1.0f * dy[s] + py;
+                    const int i = (int)floorf(px), j = clampi((int)floorf(py), hm);
+                    r0[s][k] = src.raw(clampi(i, wm), j);
+                    if (s >= 2) r1[s - 2][k] = src.raw(clampi(i + 1, wm), j);
+                }
+            }
+            for (int s = 0; s < 4; s++) {
+                if (!SM_ANY(on[s])) continue;
+                for (int k = 0; k < SEARCH_BATCH && on[s]; k++) {
+                    tx[s] = 1.0f * dx[s] + tx[s];
+                    ty[s] = 1.0f * dy[s] + ty[s];
+                    n[s] = 1.0f * 1.0f + n[s];
+                    F2 v;
+                    if (s < 2) {       // texel centre: the bilinear sum is 1 * texel + three exact zeros
+                        v.x = unorm8(r0[s][k] & 255u);
+                        v.y = unorm8(r0[s][k] >> 8);
+                    } else {           // a = 0.25, b = 0: w00 = 0.75, w10 = 0.25, the lower row's weights are exact zeros
+                        const F2 q{0.75f * unorm8(r0[s][k] & 255u) + 0.25f * unorm8(r1[s - 2][k] & 255u), 0.75f * unorm8(r0[s][k] >> 8) + 0.25f * unorm8(r1[s - 2][k] >> 8)};
+                        v.x = decode1(q.x);
+                        v.y = rintf(q.y);
+                    }
+                    end[s] = v;
+                    wgt[s] = v.x * 0.5f + v.y * 0.5f;
+                    on[s] = n[s] < last && wgt[s] > 0.9f;
+                }
+            }
+        }
+        out[0] = gate0 ? F2{n[0] + ((end[0].y > 0.9f) ? 1.0f : 0.0f), wgt[0]} : F2{0.0f, 0.0f};
+        out[1] = F2{n[1], wgt[1]};
+        out[2] = F2{n[2], wgt[2]};
+        out[3] = gate3 ? F2{n[3] + ((end[3].y > 0.9f) ? 1.0f : 0.0f), wgt[3]} : F2{0.0f, 0.0f};
     }
     SM_HDM F2 diag_weights_from(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r) const
     {
@@ -534,14 +643,25 @@ struct BlendT {
         F4 out{0.0f, 0.0f, 0.0f, 0.0f};
         const uint32_t own = src.raw(clampi(x, V.w - 1), clampi(y, V.h - 1));   // texel-centre fetch of the pixel's own edges
         F2 e{unorm8(own & 255u), unorm8(own >> 8)};
+        SMAA_PH(1);
+        bool hv = e.y > 0.0f;
         if (e.y > 0.0f) {
-            bool hv = true;
             if (P.max_steps_diag > 0) {
-                const F2 dwt = diag_weights_from(X, Y, diag_search(0, X, Y, e), diag_search(1, X, Y, e), diag_search(2, X, Y, e), diag_search(3, X, Y, e));
+#if SMAA_DIAG_IN_STEP
+                F2 ds[4];
+                diag_searches(X, Y, e, ds);
+                const F2 s0 = ds[0], s1 = ds[1], s2 = ds[2], s3 = ds[3];
+#else
+                const F2 s0 = diag_search(0, X, Y, e), s1 = diag_search(1, X, Y, e), s2 = diag_search(2, X, Y, e), s3 = diag_search(3, X, Y, e);
+#endif
+                const F2 dwt = diag_weights_from(X, Y, s0, s1, s2, s3);
                 out.x = dwt.x;
                 out.y = dwt.y;
                 hv = (out.x == -out.y);
             }
+        }
+        SMAA_PH(2);
+        if (e.y > 0.0f) {
             if (hv) {
                 const float cx = ortho_search(0, X, Y);
                 const float cz = ortho_search(1, X, Y);
@@ -552,6 +672,7 @@ struct BlendT {
                 e.x = 0.0f;
             }
         }
+        SMAA_PH(3);
         if (e.x > 0.0f) {
             const float cy = ortho_search(2, X, Y);
             const float cz = ortho_search(3, X, Y);
@@ -559,6 +680,7 @@ struct BlendT {
             out.z = wgt.x;
             out.w = wgt.y;
         }
+        SMAA_PH(4);
         return pack_weights(out);
     }
 };

@@ -41,6 +41,18 @@
 
 #include <cstdlib>
 
+#ifdef SMAA_PHASE_TIMES
+// diagnostic build (tools/smaa_phase_times.py): per wave of the last smaa_weights_kernel launch, s_memrealtime (10 ns ticks) at [0] kernel
+// entry, [5] list prefix done, [6] list entry read, [1..4] the convergent points of smaa::BlendT::weights, [7] exit; [8] = 1 if the wave had a pixel
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_smaa_ph[4096][9];
+#define SMAA_PH(k) do { g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_phase_times(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ph), sizeof(unsigned long long) * 4096 * 9) == hipSuccess ? 0 : 1;
+}
+#endif
+
 #include "smaa_device.h"
 
 namespace {
@@ -338,7 +350,14 @@ __global__ __launch_bounds__(256) void smaa_expand_kernel(SmaaBuffers b)
 __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int preset, unsigned cur)
 {
     __shared__ SegmentedList L;
+#ifdef SMAA_PHASE_TIMES
+    SMAA_PH(0);
+    g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][8] = 0ull;
+#endif
     const unsigned n = L.load(b.count + cur * SMAA_COUNT_SET);
+#ifdef SMAA_PHASE_TIMES
+    SMAA_PH(5);
+#endif
     if (blockIdx.x == 0 && threadIdx.x < SMAA_SEGMENTS) b.count[(cur ^ 1u) * SMAA_COUNT_SET + threadIdx.x * SMAA_COUNT_STRIDE] = 0;   // free for the next frame's appends
     const smaa::Preset P = smaa::preset_of(preset);
     const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
@@ -348,12 +367,20 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = L.entry(b, i);
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
+#ifdef SMAA_PHASE_TIMES
+        g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][8] = 1ull;
+        if (p == 0xffffffffu) return;    // (keeps p live up to here)
+        SMAA_PH(6);
+#endif
 #if SMAA_ABL & 512
         b.blend[p] = (uint32_t)(x ^ y) | 1u;   // timing ablation: list walk + store only
 #else
         b.blend[p] = B.weights(x, y);
 #endif
     }
+#ifdef SMAA_PHASE_TIMES
+    SMAA_PH(7);
+#endif
 }
 
 __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned cur)

@@ -50,7 +50,7 @@ def test_step_counts_from_the_bit_planes_change_nothing(built, tables, preset):
     """The HIP weight kernel computes how many steps an orthogonal search takes from whole words of two bit planes (smaa_device.h
     SearchPlanes) instead of walking the edge: with and without them the host build must produce the oracle's textures byte for byte -- on
     lines much longer than 2 x max_steps in both axes (full-length searches in all four directions), lines that end inside the window at
-    every offset and parity, crossings, frame borders (where the per-step loop takes over), widths that are not multiples of 32 and
+    every offset and parity, crossings, frame borders (where the counts repeat the border position), widths that are not multiples of 32 and
     heights that are not multiples of 8."""
     rng = np.random.default_rng(3)
     cases = [smaa_cases.pattern(7, 600, 90), smaa_cases.pattern(8, 97, 300)]
@@ -69,6 +69,18 @@ def test_step_counts_from_the_bit_planes_change_nothing(built, tables, preset):
     noise = rng.integers(0, 256, (70, 300, 4), dtype=np.uint8)
     noise[..., :3] = (noise[..., :3] // 128) * 128
     cases.append(noise)
+    # frames smaller than a search window: the window hangs over BOTH borders at once (the counts repeat the border position there, the way
+    # CLAMP_TO_EDGE repeats the border texel), last plane words / blocks only partly inside the frame
+    for hh, ww in ((9, 33), (7, 31), (17, 65), (64, 8), (1, 40), (40, 1), (3, 130)):
+        small = rng.integers(0, 256, (hh, ww, 4), dtype=np.uint8)
+        small[..., :3] = (small[..., :3] // 128) * 128
+        cases.append(small)
+        lines = np.full((hh, ww, 4), 255, np.uint8)
+        lines[hh // 2, :, :3] = 0
+        lines[:, ww // 2, :3] = 0
+        lines[0, :, :3] = 40
+        lines[:, ww - 1, :3] = 40
+        cases.append(lines)
     for img in cases:
         want = smaa.run(img, preset, *tables)
         _same(harness.smaa(img, preset, *tables, planes=True), want)
