@@ -47,10 +47,21 @@
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_smaa_ph[4096][9];
 #define SMAA_PH(k) do { g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// the same for the dense kernel: [0] entry, [1] luma tables built (barrier), [2] first rows loaded, [3] rows done, [4] planes written, [5] exit
+__device__ unsigned long long g_smaa_ep[8192][6];
+#define SMAA_EP(k) do { g_smaa_ep[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_edge_times(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ep), sizeof(unsigned long long) * 8192 * 6) == hipSuccess ? 0 : 1;
+}
 extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_phase_times(unsigned long long* out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ph), sizeof(unsigned long long) * 4096 * 9) == hipSuccess ? 0 : 1;
 }
+#endif
+
+#ifndef SMAA_EP
+#define SMAA_EP(k)
 #endif
 
 #include "smaa_device.h"
@@ -60,6 +71,9 @@ namespace {
 constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels = one 1 KiB row segment per load
 #ifndef SMAA_ABL
 #define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
+#endif
+#ifndef SMAA_LINEAR_STRIPS
+#define SMAA_LINEAR_STRIPS 1
 #endif
 #ifndef SMAA_STRIP_H
 #define SMAA_STRIP_H 8
@@ -89,11 +103,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     // spells out (smaa::luma_of), computed once per workgroup instead of per pixel -- a pixel's luma is three look-ups and two adds. The
     // dense pass is VALU-bound without this (25 us of luma arithmetic at 4K against 10 us of memory time, profiles/r02_smaa_ablation.txt).
     __shared__ float lut[3][256];
-    {
-        const float wgt[3] = {0.2126f, 0.7152f, 0.0722f};
-        for (int i = threadIdx.x; i < 768; i += 64 * WAVES_PER_WG) lut[i >> 8][i & 255] = smaa::unorm8((uint32_t)(i & 255)) * wgt[i >> 8];
-    }
-    __syncthreads();
+    SMAA_EP(0);
+    for (int k = 1; k < 6; k++) SMAA_EP(k);    // (waves that leave early: all stamps = entry)
+    // (the tables are built further down, after the strip's first rows have been requested. Measured per wave, tools/smaa_edge_times.py:
+    // every wave of the frame starts within a microsecond of the others and the first rows take 4 - 5 us to arrive whether the 1.1 us of
+    // table building come before or after the requests -- the opening burst of 4 050 x 4 KB is what the waves wait for)
 #if SMAA_ABL & 8
     auto luma = [&](uint32_t rgba) { return (float)(rgba & 255u) + (float)((rgba >> 8) & 255u) * 0.5f; };
 #else
@@ -103,8 +117,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     const uint32_t* __restrict__ color = b.color;      // the colour target and the screen are different allocations: let the loads of
     uint32_t* __restrict__ screen = b.screen;          // the next rows move above the stores of this one
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if SMAA_LINEAR_STRIPS
+    // strips are numbered row by row and dealt to the workgroups four at a time: 4 050 strips of a 4K frame are 1 013 workgroups -- at most
+    // four on each of the 256 CUs. (A grid of 4 x 270 workgroups of four strips side by side, the last of each row holding three, was 1 080:
+    // a fifth workgroup on 56 CUs.)
+    const int strips_x = (w + STRIP_W - 1) / STRIP_W, strip_id = (int)blockIdx.x * WAVES_PER_WG + wave;
+    const bool no_strip = strip_id >= strips_x * ((h + STRIP_H - 1) / STRIP_H);   // wave-uniform; such a wave leaves after the barrier below
+    const int x0 = (strip_id % strips_x) * STRIP_W, y0 = no_strip ? 0 : (strip_id / strips_x) * STRIP_H;
+#else
     const int x0 = (blockIdx.x * WAVES_PER_WG + wave) * STRIP_W, y0 = blockIdx.y * STRIP_H;
-    if (x0 >= w) return;                                                       // wave-uniform (after the barrier)
+    const bool no_strip = x0 >= w;
+#endif
     const int px = x0 + lane * 4;
     const bool vec_ok = ((w & 3) == 0) && (px + 3 < w);
     // what the RG8 edge texture still holds for this lane's pixels: the previous resolve's row plane (requested first, needed last)
@@ -136,18 +159,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     };
 
     // window: lumas of rows y-1 (Lt) and y (Lc), vertical deltas |row - row below| of rows y-1 (dyt) and y (dyc)
-    uint32_t c[4];
-    load_row(y0 - 2, c);
-    const Row4 Ltt = lumas(c);
-    load_row(y0 - 1, c);
-    Row4 Lt = lumas(c);
-    uint32_t cc[4], cb[4], cn[4];
+    uint32_t c0[4], c1[4], cc[4], cb[4], cn[4];
+    load_row(y0 - 2, c0);
+    load_row(y0 - 1, c1);
     load_row(y0, cc);
+    load_row(y0 + 1, cb);                                                      // two rows are always in flight ahead of the one being worked on
+    {
+        const float wgt[3] = {0.2126f, 0.7152f, 0.0722f};
+        for (int i = threadIdx.x; i < 768; i += 64 * WAVES_PER_WG) lut[i >> 8][i & 255] = smaa::unorm8((uint32_t)(i & 255)) * wgt[i >> 8];
+    }
+    __syncthreads();
+    SMAA_EP(1);
+    if (no_strip) return;
+    const Row4 Ltt = lumas(c0);
+    Row4 Lt = lumas(c1);
     Row4 Lc = lumas(cc);
     Row4 dyt, dyc;
 #pragma unroll
     for (int k = 0; k < 4; k++) { dyt.l[k] = fabsf(Lt.l[k] - Ltt.l[k]); dyc.l[k] = fabsf(Lc.l[k] - Lt.l[k]); }
-    load_row(y0 + 1, cb);                                                      // two rows are always in flight ahead of the one being
+    SMAA_EP(2);
     unsigned long long ebits[2] = {0, 0};                                      // worked on. 2 bits (R, G) per pixel: bit (row * 4 + k) * 2
     unsigned valid = 0;
 #pragma unroll
@@ -206,6 +236,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #pragma unroll
         for (int k = 0; k < 4; k++) { cc[k] = cb[k]; cb[k] = cn[k]; }
     }
+    SMAA_EP(3);
     // append: per-slot ballots rank the pixels; one atomic reserves the strip's entries
 #if SMAA_ABL & 16
     if (threshold > -1.0e30f) { if (ebits[0] == 0x123456789abcdefull) screen[0] = 1; return; }   // keep the arithmetic alive, skip the append
@@ -244,6 +275,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     // The RG8 edge texels: a lane's four pixels of a row as ONE 8-byte store wherever this frame or the previous one has an edge among them
     // -- this frame's edges go in, the previous frame's come out, and the texture is exact without a clearing pass (round 2 zeroed the
     // previous list's texels with a kernel of its own: 5 us, the fixed cost of any sparse kernel here).
+    SMAA_EP(4);
+    SMAA_EP(5);
     if (__ballot((ebits[0] | ebits[1] | pbits[0] | pbits[1]) != 0) == 0) return;   // wave-uniform: most strips leave here
 #pragma unroll
     for (int r = 0; r < STRIP_H; r++) {
@@ -273,7 +306,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
         const unsigned u = __shfl_up(incl, off, 64);
         if (lane >= off) incl += u;
     }
+#if SMAA_LINEAR_STRIPS
+    const unsigned strip = (unsigned)strip_id;
+#else
     const unsigned strip = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
+#endif
     const unsigned seg = strip % SMAA_SEGMENTS;
     unsigned base = 0;
     if (lane == 63) base = atomicAdd(b.count + cur * SMAA_COUNT_SET + seg * SMAA_COUNT_STRIDE, incl);   // lane 63's inclusive sum is the total
@@ -287,6 +324,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
             *out++ = (uint32_t)((size_t)(y0 + (s >> 2)) * w + px + (s & 3));
         }
     }
+    SMAA_EP(5);
 }
 
 // The sparse kernels see the segments as ONE list: the first wave of every workgroup scans the 64 counts (one per lane) into LDS, and
@@ -438,7 +476,11 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const unsigned cur = frame & 1u;
     const dim3 sparse(1024);                                                    // grid-stride over the device-side total of the segment counts
     const int strip_h = strip_rows();
+#if SMAA_LINEAR_STRIPS
+    const dim3 grid((((b.w + STRIP_W - 1) / STRIP_W) * ((b.h + strip_h - 1) / strip_h) + WAVES_PER_WG - 1) / WAVES_PER_WG);
+#else
     const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
+#endif
     const float thr = smaa::preset_of(preset).threshold;
     if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
     else hipLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
