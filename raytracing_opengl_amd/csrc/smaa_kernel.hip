@@ -72,6 +72,9 @@ constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels
 #ifndef SMAA_ABL
 #define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
 #endif
+#ifndef SMAA_XCD_BANDS
+#define SMAA_XCD_BANDS 1
+#endif
 #ifndef SMAA_LINEAR_STRIPS
 #define SMAA_LINEAR_STRIPS 1
 #endif
@@ -121,7 +124,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     // strips are numbered row by row and dealt to the workgroups four at a time: 4 050 strips of a 4K frame are 1 013 workgroups -- at most
     // four on each of the 256 CUs. (A grid of 4 x 270 workgroups of four strips side by side, the last of each row holding three, was 1 080:
     // a fifth workgroup on 56 CUs.)
+#if SMAA_XCD_BANDS
+    // workgroup g runs on XCD g % 8 (each XCD has its own L2): give every XCD one contiguous band of the frame, so that a strip and the
+    // strips above and below it -- which read its first / last rows as their halo -- share an L2
+    const int per_xcd = ((int)gridDim.x + 7) / 8, wg = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    const int strips_x = (w + STRIP_W - 1) / STRIP_W, strip_id = wg * WAVES_PER_WG + wave;
+#else
     const int strips_x = (w + STRIP_W - 1) / STRIP_W, strip_id = (int)blockIdx.x * WAVES_PER_WG + wave;
+#endif
     const bool no_strip = strip_id >= strips_x * ((h + STRIP_H - 1) / STRIP_H);   // wave-uniform; such a wave leaves after the barrier below
     const int x0 = (strip_id % strips_x) * STRIP_W, y0 = no_strip ? 0 : (strip_id / strips_x) * STRIP_H;
 #else
@@ -477,7 +487,11 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const dim3 sparse(1024);                                                    // grid-stride over the device-side total of the segment counts
     const int strip_h = strip_rows();
 #if SMAA_LINEAR_STRIPS
+#if SMAA_XCD_BANDS
+    const dim3 grid((((((b.w + STRIP_W - 1) / STRIP_W) * ((b.h + strip_h - 1) / strip_h) + WAVES_PER_WG - 1) / WAVES_PER_WG) + 7) / 8 * 8);
+#else
     const dim3 grid((((b.w + STRIP_W - 1) / STRIP_W) * ((b.h + strip_h - 1) / strip_h) + WAVES_PER_WG - 1) / WAVES_PER_WG);
+#endif
 #else
     const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
 #endif
