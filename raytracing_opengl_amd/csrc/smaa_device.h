@@ -24,6 +24,9 @@
 #define SM_HDM inline
 #endif
 
+#ifndef SMAA_DIAG_BATCH
+#define SMAA_DIAG_BATCH 4   /* steps fetched ahead per round of the in-step diagonal searches */
+#endif
 #ifndef SMAA_DIAG_IN_STEP
 #define SMAA_DIAG_IN_STEP 1
 #endif
@@ -434,6 +437,7 @@ struct BlendT {
     // No branch sits between a load and the next load: the compiler waits for a load where its value is first used.
     SM_HDM void diag_searches(float X, float Y, F2 e, F2 out[4]) const
     {
+        enum { DIAG_BATCH = SMAA_DIAG_BATCH };
         const float last = (float)(P.max_steps_diag - 1);
         const float dx[4] = {-1.0f, 1.0f, -1.0f, 1.0f}, dy[4] = {1.0f, -1.0f, -1.0f, 1.0f};
         float tx[4] = {X, X, X + 0.25f, X + 0.25f}, ty[4] = {Y, Y, Y, Y}, n[4] = {-1.0f, -1.0f, -1.0f, -1.0f}, wgt[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -446,11 +450,11 @@ struct BlendT {
         const bool gate0 = on[0], gate3 = on[3];
         const int wm = V.w - 1, hm = V.h - 1;
         while (SM_ANY(on[0] || on[1] || on[2] || on[3])) {
-            uint32_t r0[4][SEARCH_BATCH], r1[2][SEARCH_BATCH];     // r0: the texel at floor(position); r1: its right neighbour (second pair only)
+            uint32_t r0[4][DIAG_BATCH], r1[2][DIAG_BATCH];     // r0: the texel at floor(position); r1: its right neighbour (second pair only)
             for (int s = 0; s < 4; s++) {
                 if (!SM_ANY(on[s])) continue;                      // wave-uniform
                 float px = tx[s], py = ty[s];
-                for (int k = 0; k < SEARCH_BATCH; k++) {
+                for (int k = 0; k < DIAG_BATCH; k++) {
                     px = 1.0f * dx[s] + px;
                     py = 1.0f * dy[s] + py;
                     const int i = (int)floorf(px), j = clampi((int)floorf(py), hm);
@@ -460,7 +464,7 @@ struct BlendT {
             }
             for (int s = 0; s < 4; s++) {
                 if (!SM_ANY(on[s])) continue;
-                for (int k = 0; k < SEARCH_BATCH && on[s]; k++) {
+                for (int k = 0; k < DIAG_BATCH && on[s]; k++) {
                     tx[s] = 1.0f * dx[s] + tx[s];
                     ty[s] = 1.0f * dy[s] + ty[s];
                     n[s] = 1.0f * 1.0f + n[s];
@@ -483,6 +487,68 @@ struct BlendT {
         out[1] = F2{n[1], wgt[1]};
         out[2] = F2{n[2], wgt[2]};
         out[3] = gate3 ? F2{n[3] + ((end[3].y > 0.9f) ? 1.0f : 0.0f), wgt[3]} : F2{0.0f, 0.0f};
+    }
+    // The same weights with every load of a stage in flight together (round 3): the seven crossing-edge texels of both diagonal pairs, then
+    // both area texels. The positions are texel centres or lie a quarter texel beside / below one, so the taps are known: (0.75, 0.25)
+    // over two columns, (0.25, 0.75) over two rows, single texels -- the bilinear sums of edges_at with their exact zeros left out (x + 0 = x
+    // for the non-negative sums here). Should a position ever NOT have that form (it cannot: the distances are small whole numbers), the
+    // wave takes diag_weights_from.
+    SM_HDM F2 diag_weights_staged(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r) const
+    {
+        const int wm = V.w - 1, hm = V.h - 1;
+        const float dx1 = s0r.x, dz1 = s0r.y, dy1 = s1r.x, dw1 = s1r.y, dx2 = s2r.x, dz2 = s2r.y, dy2 = s3r.x, dw2 = s3r.y;
+        const bool on1 = dx1 + dy1 > 2.0f, on2 = dx2 + dy2 > 2.0f;
+        const float t0x = (-dx1 + 0.25f) * 1.0f + X, t0y = dx1 * 1.0f + Y, t1x = dy1 * 1.0f + X, t1y = (-dy1 - 0.25f) * 1.0f + Y;
+        const float ax = -dx2 * 1.0f + X, ay = -dx2 * 1.0f + Y, bx = dy2 * 1.0f + X, by = dy2 * 1.0f + Y;
+        const float f0x = floorf(t0x), f0y = floorf(t0y), f1x = floorf(t1x), f1y = floorf(t1y);
+        const bool form = (!on1 || (t0x - f0x == 0.25f && t0y == f0y && t1x == f1x && t1y - f1y == 0.75f)) &&
+                          (!on2 || (ax == floorf(ax) && ay == floorf(ay) && bx == floorf(bx) && by == floorf(by)));
+        if (SM_ANY(!form)) return diag_weights_from(X, Y, s0r, s1r, s2r, s3r);
+        uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 0u, c0 = 0u, c1 = 0u, c2 = 0u;
+        if (on1) {
+            const int j = clampi((int)f0y, hm), i = clampi((int)f1x + 1, wm);
+            a0 = src.raw(clampi((int)f0x - 1, wm), j);            // edges_at(t0x, t0y, -1, 0): columns fx - 1, fx
+            a1 = src.raw(clampi((int)f0x, wm), j);
+            b0 = src.raw(i, clampi((int)f1y, hm));                // edges_at(t1x, t1y, 1, 0): rows fy, fy + 1
+            b1 = src.raw(i, clampi((int)f1y + 1, hm));
+        }
+        if (on2) {
+            c0 = src.raw(clampi((int)ax - 1, wm), clampi((int)ay, hm));
+            c1 = src.raw(clampi((int)ax, wm), clampi((int)ay - 1, hm));
+            c2 = src.raw(clampi((int)bx + 1, wm), clampi((int)by, hm));
+        }
+        float e11 = 0.0f, e12 = 0.0f, e21 = 0.0f, e22 = 0.0f;
+        if (on1) {
+            const F2 s0{0.75f * unorm8(a0 & 255u) + 0.25f * unorm8(a1 & 255u), 0.75f * unorm8(a0 >> 8) + 0.25f * unorm8(a1 >> 8)};
+            const F2 s1{0.25f * unorm8(b0 & 255u) + 0.75f * unorm8(b1 & 255u), 0.25f * unorm8(b0 >> 8) + 0.75f * unorm8(b1 >> 8)};
+            const float cy = decode1(s0.x), cx = rintf(s0.y), cw = decode1(s1.x), cz = rintf(s1.y);
+            e11 = 2.0f * cx + cy;
+            e12 = 2.0f * cz + cw;
+            if (step_(0.9f, dz1) != 0.0f) e11 = 0.0f;
+            if (step_(0.9f, dw1) != 0.0f) e12 = 0.0f;
+        }
+        if (on2) {
+            const float cx = unorm8(c0 >> 8), cy = unorm8(c1 & 255u);
+            e21 = 2.0f * cx + cy;
+            e22 = 2.0f * unorm8(c2 >> 8) + unorm8(c2 & 255u);
+            if (step_(0.9f, dz2) != 0.0f) e21 = 0.0f;
+            if (step_(0.9f, dw2) != 0.0f) e22 = 0.0f;
+        }
+        // both area texels (SMAAAreaDiag): whole-numbered positions again, or the wave takes the general sampler
+        const float u1 = (20.0f * e11 + dx1) + 80.0f, v1 = 20.0f * e12 + dy1, u2 = (20.0f * e21 + dx2) + 80.0f, v2 = 20.0f * e22 + dy2;
+        const bool whole = (!on1 || (u1 == floorf(u1) && v1 == floorf(v1))) && (!on2 || (u2 == floorf(u2) && v2 == floorf(v2)));
+        F2 wts{0.0f, 0.0f};
+        if (SM_ANY(!whole)) {
+            if (on1) { const F2 a = area_diag(dx1, dy1, e11, e12); wts.x += a.x; wts.y += a.y; }
+            if (on2) { const F2 a = area_diag(dx2, dy2, e21, e22); wts.x += a.y; wts.y += a.x; }
+            return wts;
+        }
+        uint32_t p1 = 0u, p2 = 0u;
+        if (on1) p1 = V.area[(size_t)clampi((int)v1, AREA_H - 1) * AREA_W + clampi((int)u1, AREA_W - 1)];
+        if (on2) p2 = V.area[(size_t)clampi((int)v2, AREA_H - 1) * AREA_W + clampi((int)u2, AREA_W - 1)];
+        if (on1) { wts.x += unorm8(p1 & 255u); wts.y += unorm8(p1 >> 8); }
+        if (on2) { wts.x += unorm8(p2 >> 8); wts.y += unorm8(p2 & 255u); }
+        return wts;
     }
     SM_HDM F2 diag_weights_from(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r) const
     {
@@ -651,10 +717,15 @@ struct BlendT {
                 F2 ds[4];
                 diag_searches(X, Y, e, ds);
                 const F2 s0 = ds[0], s1 = ds[1], s2 = ds[2], s3 = ds[3];
+                SMAA_PH(9);
 #else
                 const F2 s0 = diag_search(0, X, Y, e), s1 = diag_search(1, X, Y, e), s2 = diag_search(2, X, Y, e), s3 = diag_search(3, X, Y, e);
 #endif
+#if SMAA_DIAG_IN_STEP
+                const F2 dwt = diag_weights_staged(X, Y, s0, s1, s2, s3);
+#else
                 const F2 dwt = diag_weights_from(X, Y, s0, s1, s2, s3);
+#endif
                 out.x = dwt.x;
                 out.y = dwt.y;
                 hv = (out.x == -out.y);

@@ -45,7 +45,7 @@
 // diagnostic build (tools/smaa_phase_times.py): per wave of the last smaa_weights_kernel launch, s_memrealtime (10 ns ticks) at [0] kernel
 // entry, [5] list prefix done, [6] list entry read, [1..4] the convergent points of smaa::BlendT::weights, [7] exit; [8] = 1 if the wave had a pixel
 #include <hip/hip_runtime.h>
-__device__ unsigned long long g_smaa_ph[4096][9];
+__device__ unsigned long long g_smaa_ph[4096][12];
 #define SMAA_PH(k) do { g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // the same for the dense kernel: [0] entry, [1] luma tables built (barrier), [2] first rows loaded, [3] rows done, [4] planes written, [5] exit
 __device__ unsigned long long g_smaa_ep[8192][6];
@@ -56,7 +56,7 @@ extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_edge_times(
 }
 extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_phase_times(unsigned long long* out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ph), sizeof(unsigned long long) * 4096 * 9) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ph), sizeof(unsigned long long) * 4096 * 12) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -28,7 +28,7 @@ def main():
     for _ in range(4):
         gl.smaa_resolve()
     gl.finish()
-    buf = np.zeros((4096, 9), dtype=np.uint64)
+    buf = np.zeros((4096, 12), dtype=np.uint64)
     assert fn(buf.ctypes.data) == 0
     t = buf.astype(np.float64)
     t0 = t[:, 0].min()
@@ -45,6 +45,11 @@ def main():
         for k in range(1, len(idx)):
             d = (tw[sel, idx[k]] - tw[sel, idx[k - 1]]) * 0.01
             print(f"    {order[k]:45s} {d.mean():6.2f}  (max {d.max():6.2f})")
+    dsel = tw[:, 9] > tw[:, 1]          # waves in which some lane ran the diagonal searches ([9] is stamped inside that branch)
+    if dsel.any():
+        a = (tw[dsel, 9] - tw[dsel, 1]) * 0.01
+        b = (tw[dsel, 2] - tw[dsel, 9]) * 0.01
+        print(f"  diagonal phase split ({int(dsel.sum())} waves): the four searches mean {a.mean():.2f} (p95 {np.percentile(a, 95):.2f}, max {a.max():.2f}), crossing edges + area {b.mean():.2f} (p95 {np.percentile(b, 95):.2f}, max {b.max():.2f})")
     gl.stop()
 
 
