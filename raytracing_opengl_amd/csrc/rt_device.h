@@ -886,7 +886,13 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
         t = -p3 / p1;
         return t > tmin;
     }
-    const float p4 = sqrtf(p1 * p1 - 4.0f * p2 * p3);
+    // No real root (negative discriminant): the square root below is NaN, neither root passes its tests, mn = mx = FLT_MAX, and whatever the
+    // clip test makes of the "point" at FLT_MAX the result is FLT_MAX < tmin -- false for every finite limit. A wave none of whose lanes
+    // has a real root (the line misses the unclipped quadric: common for the lanes a bounding sphere lets through) stops here, before the
+    // square root, the two divisions and the clip tests; t is left as the long way round leaves it.
+    const float disc = p1 * p1 - 4.0f * p2 * p3;
+    if (!RT_ANY(!(disc < 0.0f) || tmin > RT_FLT_MAX)) { t = RT_FLT_MAX; return false; }
+    const float p4 = sqrtf(disc);
     float mn = RT_FLT_MAX, mx = RT_FLT_MAX;
     const float t1 = (-p1 - p4) / (2.0f * p2);
     const float t2 = (-p1 + p4) / (2.0f * p2);
