@@ -5,10 +5,13 @@ from __future__ import annotations
 
 import hashlib
 import os
-import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-KERNEL_SOURCES = ("csrc/rt_device.h", "csrc/rt_kernel.hip", "csrc/rt_kernel.h", "csrc/rt_scene_dev.h")
+# Everything that decides which instructions a trace launch executes: the device code, the packer (rt_pack.h: the bounds and candidate
+# tables the kernel walks -- round 3's tight quadric bounds changed the VALU counts without touching a "kernel" file), the C-ABI
+# implementation (variant selection, launch parameters), the build configuration and the Makefile that applies it.
+KERNEL_SOURCES = ("csrc/rt_device.h", "csrc/rt_kernel.hip", "csrc/rt_kernel.h", "csrc/rt_scene_dev.h", "csrc/rt_pack.h",
+                  "csrc/rtx_capi.cpp", "kernel_build.cfg", "Makefile")
 
 
 def kernel_source_hash() -> str:
@@ -16,8 +19,4 @@ def kernel_source_hash() -> str:
     for rel in KERNEL_SOURCES:
         h.update(rel.encode())
         h.update(open(os.path.join(_HERE, rel), "rb").read())
-    mk = open(os.path.join(_HERE, "Makefile")).read()
-    for var in ("WAVES_PER_EU", "WPE_HEAVY", "HIPFLAGS"):
-        m = re.search(rf"^{var}\s*[:?]?=\s*(.*)$", mk, re.M)
-        h.update((var + "=" + (m.group(1).strip() if m else "")).encode())
     return h.hexdigest()[:16]
