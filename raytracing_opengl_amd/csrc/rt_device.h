@@ -637,9 +637,12 @@ RT_HD v2f mk2v(float x, float y) { v2f r; r[0] = x; r[1] = y; return r; }
 RT_HD v2f cmul(v2f p, v2f q)
 {
     const v2f a = c_xx(p) * q;
-    v2f b = c_yy(p) * c_yx(q);
-    b[0] = -b[0];
-    return a + b;
+    const v2f b = c_yy(p) * c_yx(q);
+    // a.x - b.x is a.x + (-b.x) in IEEE arithmetic. Spelled as two scalar operations: as "negate b.x, packed add" it compiled to a packed
+    // negation of both halves, a move to restore the upper one and the packed add (round 4, ISA of the sweep: 140 packed + 21 moves per
+    // sweep before, 100 packed + 53 scalar after; with -disable-vector-combine, which otherwise re-packs the pair into TWO packed
+    // operations and a move).
+    return mk2v(a[0] - b[0], a[1] + b[1]);
 }
 RT_HD v2f torus_poly(v2f t, const TorusRay& w)
 {
@@ -662,7 +665,32 @@ RT_HD float dk_step(v2f& c0, v2f c1, v2f c2, v2f c3, const TorusRay& w)
     return gl_max(fabsf(fc[0]), fabsf(fc[1]));
 }
 #if defined(RT_DK_STATS) && defined(__HIPCC__)
-__device__ unsigned long long g_dk[8];  // diagnostic build only: wave execs, lane solves, wave sweeps, lane sweeps, wave cycles
+__device__ unsigned long long g_dk[16];  // diagnostic build only: wave execs, lane solves, wave sweeps, lane sweeps, wave cycles, ...;
+                                         // [8] scans with a candidate, [9] sum over scans of the busiest lane's candidates (= passes),
+                                         // [10] candidates of all lanes, [11] sum of ceil(candidates / 64), [12] lanes with a candidate
+#endif
+RT_HD void dk_stats_scan(unsigned long long cand)
+{
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    const int mine = __builtin_popcountll(cand);
+    if (__ballot(mine != 0) == 0ull) return;
+    int mx = 0, tot = 0, lanes = 0;
+    unsigned long long m = __ballot(1);
+    const int first = __ffsll((long long)m) - 1;
+    while (m) { const int l = __ffsll((long long)m) - 1; const int v = __shfl(mine, l, 64); mx = v > mx ? v : mx; tot += v; lanes += v != 0; m &= m - 1; }
+    if ((int)(threadIdx.x & 63) == first) {
+        atomicAdd(&g_dk[8], 1ull);
+        atomicAdd(&g_dk[9], (unsigned long long)mx);
+        atomicAdd(&g_dk[10], (unsigned long long)tot);
+        atomicAdd(&g_dk[11], (unsigned long long)((tot + 63) / 64));
+        atomicAdd(&g_dk[12], (unsigned long long)lanes);
+    }
+#else
+    (void)cand;
+#endif
+}
+#if defined(RT_HOST_DK_PROBE) && !defined(__HIPCC__)
+void rt_host_dk_probe(const DevTorus& T, f3 ro, f3 rd, float tmin, int sweeps, v2f c0, v2f c1, v2f c2, v2f c3);
 #endif
 RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t)
 {
@@ -683,7 +711,13 @@ RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, 
     v2f c1 = mk2v(0.4f, 0.9f);
     v2f c2 = cmul(c1, mk2v(0.4f, 0.9f));
     v2f c3 = cmul(c2, mk2v(0.4f, 0.9f));
+#if defined(RT_HOST_DK_PROBE) && !defined(__HIPCC__)
+    int _probe_sweeps = 0;
+#endif
     for (int i = 0; i < 60; i++) {
+#if defined(RT_HOST_DK_PROBE) && !defined(__HIPCC__)
+        _probe_sweeps++;
+#endif
         float e = dk_step(c0, c1, c2, c3, w);
         e = gl_max(e, dk_step(c1, c2, c3, c0, w));
         e = gl_max(e, dk_step(c2, c3, c0, c1, w));
@@ -706,8 +740,20 @@ RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, 
             atomicAdd(&g_dk[2], (unsigned long long)mx);
             atomicAdd(&g_dk[4], (unsigned long long)clock64() - _dk_t0);
         }
+        {   // [13] solver runs with a lane at the 60-sweep cap, [14] sum over those runs of the SECOND-largest distinct stop (sweeps the run would take without its capped lanes)
+            const unsigned long long capm = __ballot(_dk_sweeps >= 60);
+            if (capm != 0ull) {
+                unsigned long long m2 = __ballot(_dk_sweeps < 60);
+                int mx2 = 0;
+                while (m2) { const int l = __ffsll((long long)m2) - 1; const int v = __shfl(_dk_sweeps, l, 64); mx2 = v > mx2 ? v : mx2; m2 &= m2 - 1; }
+                if ((int)(threadIdx.x & 63) == first) { atomicAdd(&g_dk[13], 1ull); atomicAdd(&g_dk[14], (unsigned long long)mx2); }
+            }
+        }
         if (_dk_sweeps >= 60) atomicAdd(&g_dk[6], 1ull);
     }
+#endif
+#if defined(RT_HOST_DK_PROBE) && !defined(__HIPCC__)
+    rt_host_dk_probe(T, ro, rd, tmin, _probe_sweeps, c0, c1, c2, c3);   // host experiments only (tools/dk_probe.cpp)
 #endif
     float r0 = c0[0], r1 = c1[0], r2 = c2[0], r3 = c3[0];
     if (fabsf(c0[1]) > eps || r0 < 0.0f) r0 = 10000.0f;
@@ -1446,6 +1492,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd, tmin)) cand |= 1ull << (i + k - base);)
             }
+            dk_stats_scan(cand);
             while (RT_ANY(cand != 0ull)) {
                 if (cand != 0ull) {
                     const int i = base + lane_pop(cand);          // differs from lane to lane
@@ -1610,6 +1657,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                     const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                     RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd, dist)) cand |= 1ull << (i + k - base);)
                 }
+                dk_stats_scan(cand);
                 while (RT_ANY(cand != 0ull)) {
                     if (cand != 0ull) {
                         const int i = base + lane_pop(cand);

@@ -19,9 +19,9 @@ using namespace rtdev;
 #ifdef RT_DK_STATS
 extern "C" __attribute__((visibility("default"))) int rtx_debug_dk_stats(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dk), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dk), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_dk), z, sizeof z) != hipSuccess) return 1;
     }
     return 0;

@@ -5,7 +5,8 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p raytracing_opengl_amd/variants
-BASE="-DRT_WAVES_PER_EU=6 -DRT_WPE_HEAVY=6 --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -disable-machine-licm -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc"
+cfg() { sed -n "s/^$1[ \t]*?=[ \t]*//p" raytracing_opengl_amd/kernel_build.cfg; }   # the product's own configuration
+BASE="-DRT_WAVES_PER_EU=$(cfg WAVES_PER_EU) -DRT_WPE_HEAVY=$(cfg WPE_HEAVY) --offload-arch=gfx950 $(cfg KERNEL_FLAGS) -Iinclude -Iraytracing_opengl_amd/csrc"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc $BASE $flags -shared -o raytracing_opengl_amd/variants/librtx_hip_$name.so \

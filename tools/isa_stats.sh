@@ -3,7 +3,8 @@
 # usage: [ISA_WPE=7] tools/isa_stats.sh [extra hipcc flags]     (ISA_WPE: which waves-per-SIMD instantiation; default 6 = the light one, 7 = the many-primitive variant)
 cd "$(dirname "$0")/.."
 OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
-/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=6 -DRT_WPE_HEAVY=6 --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -disable-machine-licm -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
+cfg() { sed -n "s/^$1[ \t]*?=[ \t]*//p" raytracing_opengl_amd/kernel_build.cfg; }   # the product's own configuration
+/opt/rocm/bin/hipcc -DRT_WAVES_PER_EU=$(cfg WAVES_PER_EU) -DRT_WPE_HEAVY=$(cfg WPE_HEAVY) --offload-arch=gfx950 $(cfg KERNEL_FLAGS) -Iinclude -Iraytracing_opengl_amd/csrc "$@" -S --cuda-device-only -o $OUT raytracing_opengl_amd/csrc/rt_kernel.hip 2>&1 | grep -v "warning\|^$"
 python3 - "$OUT" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
