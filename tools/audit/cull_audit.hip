@@ -1,0 +1,677 @@
+// cull_audit.hip -- TOOL, not product: audits the culls of the tracer (csrc/rt_device.h) at a scale the host tests cannot reach.
+//
+// Every cull of the tracer is a conservative predicate in front of an intersector whose arithmetic is the reference's (rt.frag:342-572).
+// "Conservative" has a proof only where the intersector is geometric; for the torus it rests on a premise about the reference's
+// Durand-Kerner iteration (rt.frag:462-487: "no root is reported for a ray that misses the inflated torus"), for open quadrics on a bound of
+// what the reference's FLOAT evaluation can take for the surface. This tool draws random and near-boundary rays per primitive record on the
+// GPU, evaluates the product's cull AND the literal intersector in the same lane and counts "culled and hit" -- 1e10 rays per family are a
+// few minutes here against hours on the host (tests/host_harness has the same checks at 1e6-1e8). It compiles the product's own headers
+// (rt_device.h, rt_pack.h): what is audited is the code that ships. The literal intersectors are the product's un-culled entry points
+// (intersect_torus, intersect_ring) and, for quadrics, a restatement of rt.frag:513-572 without the product's wave-level early exit.
+//
+// Built by tools/audit/Makefile into tools/audit/libcull_audit.so, driven by tools/cull_audit.py. Nothing under raytracing_opengl_amd/ uses it.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+#include "rt_pack.h"
+
+using namespace rtdev;
+
+namespace {
+
+enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4 };
+enum { N_COUNTERS = 48, BAD_FLOATS = 12 };
+
+struct AuditParams {
+    const char* scene;
+    const uint32_t* pencil_masks;
+    unsigned long long* counters;   // N_COUNTERS
+    float* bad;                     // max_bad x BAD_FLOATS: family-specific record of the first violations
+    unsigned int* n_bad;
+    int max_bad;
+    unsigned long long seed;
+    int iters;                      // rays per thread
+    int family;
+};
+
+// ---- random numbers: one stream per ray, SplitMix64 ----
+struct Rng {
+    unsigned long long x;
+    __device__ unsigned long long next() { x += 0x9e3779b97f4a7c15ull; unsigned long long z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+    __device__ float u01() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }               // [0, 1)
+    __device__ float sym() { return 2.0f * u01() - 1.0f; }
+    __device__ float gauss() { float a = 0.0f; for (int i = 0; i < 6; i++) a += u01(); return (a - 3.0f) * 1.41421356f; }
+    __device__ float logu(float lo, float hi) { return lo * __powf(hi / lo, u01()); }
+    __device__ f3 unit() { f3 v; float l2; do { v = mk3(gauss(), gauss(), gauss()); l2 = dot3(v, v); } while (!(l2 > 1e-12f)); return v * (1.0f / sqrtf(l2)); }
+};
+__device__ f3 any_perp(f3 n)
+{
+    const f3 a = fabsf(n.x) < 0.6f ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 1.0f, 0.0f);
+    return normalize3(cross3(n, a));
+}
+// a unit direction within a few degrees of the plane across n (any direction in that plane)
+__device__ f3 grazing_dir(Rng& R, f3 n)
+{
+    const f3 u = any_perp(n), v = cross3(n, u);
+    const float a = 6.2831853f * R.u01();
+    return normalize3(u * __cosf(a) + v * __sinf(a) + n * (0.05f * R.sym() * R.u01()));
+}
+__device__ float ray_tmin(Rng& R) { return R.u01() < 0.5f ? RT_MAXDIST : __powf(10.0f, -1.0f + 5.0f * R.u01()); }
+
+__device__ void record_bad(const AuditParams& p, int kind, int prim, f3 ro, f3 rd, float tmin, float t, float extra)
+{
+    const unsigned k = atomicAdd(p.n_bad, 1u);
+    if ((int)k >= p.max_bad) return;
+    float* o = p.bad + (size_t)k * BAD_FLOATS;
+    o[0] = (float)kind; o[1] = (float)prim; o[2] = ro.x; o[3] = ro.y; o[4] = ro.z; o[5] = rd.x; o[6] = rd.y; o[7] = rd.z; o[8] = tmin; o[9] = t; o[10] = extra; o[11] = 0.0f;
+}
+
+__device__ void flush(const AuditParams& p, const unsigned int* c)
+{
+    for (int k = 0; k < N_COUNTERS; k++) {
+        unsigned long long s = c[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63u) == 0u && s) atomicAdd(p.counters + k, s);
+    }
+}
+
+// ================================================================================================================================
+// tori: sphere cull (torus_cull), group sphere, convex-hull cull, puck / hole cull, and the premise of the candidate tables (the ray's LINE
+// 's part up to the limit stays 6 mm clear of the real tube, in exact arithmetic) -- each judged ON ITS OWN against the un-culled solver
+// counters: 0 rays, 1 culled by any, 2 sphere, 3 group, 4 hull, 5 puck, 6 line-miss, 7 solver runs, 8 literal hits among the solved,
+//           10 VIOLATIONS sphere, 11 group, 12 hull, 13 puck, 14 line-miss, 15 a non-unit direction was culled, 16 rays with a non-unit direction
+// ================================================================================================================================
+__device__ void torus_ray(Rng& R, const DevTorus& T, const f4 bound, int mode, f3& ro, f3& rd, float& tmin)
+{
+    const float Rm = fabsf(T.radii.x), rt = fabsf(T.radii.y), ext = Rm + rt;
+    const f3 c = xyz(T.pos);
+    tmin = ray_tmin(R);
+    if (mode <= 3) {                          // around the torus: from 0.02 ... 200 units (3 of 4) or 200 ... 1e5 units out, aimed at or near it
+        const float dist = mode == 3 ? R.logu(200.0f, 1.0e5f) : R.logu(0.02f, 200.0f);
+        ro = c + R.unit() * dist;
+        const float spread = ext * (R.u01() < 0.6f ? 1.2f : 6.0f);
+        const f3 target = c + mk3(R.gauss(), R.gauss(), R.gauss()) * spread;
+        rd = normalize3(target - ro);
+        if (R.u01() < 0.1f) rd = -rd;
+    } else if (mode <= 5) {                   // rays that START on the torus (its own shadow / mirror rays): a surface point pushed out by a gap,
+                                              // displaced along an incoming ray by the solver's +-1e-3; outward directions incl. grazing ones
+        const float phi = 6.2831853f * R.u01(), th = 6.2831853f * R.u01();
+        const float cp = __cosf(phi), sp = __sinf(phi), ct = __cosf(th), st = __sinf(th);
+        const f3 n = mk3(ct * cp, ct * sp, st);
+        const float gap = R.logu(1.0e-5f, 1.0e-1f);
+        f3 d = R.unit();
+        float dn = dot3(d, n);
+        if (R.u01() < 0.33f) { const float f = 0.05f * R.u01(); d = normalize3(d - n * ((1.0f - f) * dn)); dn = dot3(d, n); }
+        if ((dn < 0.0f) != (R.u01() < 0.1f)) d = -d;
+        const f3 in = R.unit();
+        const float jt = 1.0e-3f * R.sym();
+        const f3 ol = mk3((Rm + rt * ct) * cp, (Rm + rt * ct) * sp, rt * st) + n * gap + in * jt;
+        ro = quat_rotate(T.qinv, ol) + c;
+        rd = normalize3(quat_rotate(T.qinv, d));
+    } else if (mode == 6) {                   // grazing the cull sphere: a point within +-2 % of its surface, a direction near the tangent plane
+        const float rb = sqrtf(bound.w);
+        const f3 n = R.unit();
+        const f3 pb = c + n * (rb * (1.0f + 0.02f * R.sym()));
+        const f3 d = grazing_dir(R, n);
+        ro = pb - d * R.logu(0.01f, 300.0f);
+        rd = d;
+    } else {                                  // grazing the puck / the hole cylinder in the torus' frame
+        const float hz = T.cull.x, ro2 = sqrtf(T.k.z), rh = sqrtf(T.k.w);
+        const int which = (int)(R.u01() * 3.0f);
+        f3 pl;
+        if (which == 0) { const float rho = ro2 * sqrtf(R.u01()), a = 6.2831853f * R.u01(); pl = mk3(rho * __cosf(a), rho * __sinf(a), (R.u01() < 0.5f ? -hz : hz) * (1.0f + 0.02f * R.sym())); }
+        else { const float rad = (which == 1 || rh == 0.0f ? ro2 : rh) * (1.0f + 0.02f * R.sym()), a = 6.2831853f * R.u01(); pl = mk3(rad * __cosf(a), rad * __sinf(a), hz * R.sym()); }
+        f3 d = R.unit();
+        if (R.u01() < 0.5f) { const f3 n = which == 0 ? mk3(0.0f, 0.0f, 1.0f) : normalize3(mk3(pl.x, pl.y, 0.0f)); d = normalize3(d - n * (dot3(d, n) * (1.0f - 0.05f * R.u01()))); }
+        const f3 ol = pl - d * R.logu(0.01f, 120.0f);
+        ro = quat_rotate(T.qinv, ol) + c;
+        rd = normalize3(quat_rotate(T.qinv, d));
+    }
+}
+// Distances of a point (torus frame) from the zero set of the quartic. The zero set is { D- = r } and, for a self-intersecting torus (r > R:
+// tests/random_scenes.py nasty_scene has them), also { D+ = r }: D-, D+ = the distances to the nearest and the farthest point of the circle of
+// radius R through the point's meridian plane. tube_dist: unsigned distance from the zero set; tube_sd: negative inside the solid tube.
+__device__ double tube_sd(double Rm, double rt, double x, double y, double z)
+{
+    const double rho = sqrt(x * x + y * y);
+    return sqrt((rho - Rm) * (rho - Rm) + z * z) - rt;
+}
+__device__ double tube_dist(double Rm, double rt, double x, double y, double z)
+{
+    const double rho = sqrt(x * x + y * y);
+    const double dm = fabs(sqrt((rho - Rm) * (rho - Rm) + z * z) - rt);
+    if (rt <= Rm) return dm;
+    const double dp = fabs(sqrt((rho + Rm) * (rho + Rm) + z * z) - rt);
+    return dm < dp ? dm : dp;
+}
+// How close does the part 0 <= t <= tl of the ray come to the surface of the tube (torus frame, double)? 0 if it touches or enters it.
+// Sampled (256 points over the part inside the torus' bounding sphere + 0.5) and refined around the three best samples: an estimate from
+// above (a missed dip only makes the clearance look larger, i.e. the audit stricter).
+__device__ double ray_tube_clearance(const DevTorus& T, f3 of, f3 df, double tl)
+{
+    const double Rm = fabs((double)T.radii.x), rt = fabs((double)T.radii.y), Rb = Rm + rt + 0.5;
+    const double ox = of.x, oy = of.y, oz = of.z, dx = df.x, dy = df.y, dz = df.z;
+    const double a = dx * dx + dy * dy + dz * dz, b = ox * dx + oy * dy + oz * dz, c = ox * ox + oy * oy + oz * oz - Rb * Rb;
+    const double h = b * b - a * c;
+    if (!(h >= 0.0)) return 1.0e9;
+    const double sh = sqrt(h);
+    double t0 = (-b - sh) / a, t1 = (-b + sh) / a;
+    t0 = t0 < 0.0 ? 0.0 : t0;
+    t1 = t1 > tl ? tl : t1;
+    if (!(t0 <= t1)) return 1.0e9;
+    auto g = [&](double t) { return tube_dist(Rm, rt, ox + t * dx, oy + t * dy, oz + t * dz); };
+    const int N = 256;
+    const double dt = (t1 - t0) / N;
+    double bt[3] = {t0, t0, t0}, bg[3] = {1.0e30, 1.0e30, 1.0e30};
+    for (int k = 0; k <= N; k++) {
+        const double t = t0 + dt * k, v = g(t);
+        if (v < bg[0]) { bg[2] = bg[1]; bt[2] = bt[1]; bg[1] = bg[0]; bt[1] = bt[0]; bg[0] = v; bt[0] = t; }
+        else if (v < bg[1]) { bg[2] = bg[1]; bt[2] = bt[1]; bg[1] = v; bt[1] = t; }
+        else if (v < bg[2]) { bg[2] = v; bt[2] = t; }
+    }
+    double best = bg[0];
+    for (int s = 0; s < 3; s++) {
+        double lo = bt[s] - dt, hi = bt[s] + dt;
+        lo = lo < t0 ? t0 : lo; hi = hi > t1 ? t1 : hi;
+        for (int k = 0; k < 48; k++) { const double m1 = lo + (hi - lo) / 3.0, m2 = hi - (hi - lo) / 3.0; if (g(m1) < g(m2)) hi = m2; else lo = m1; }
+        const double v = g(0.5 * (lo + hi));
+        best = v < best ? v : best;
+    }
+    return best > 1.0e-9 ? best : 0.0;      // a crossing of the surface is a V-shaped minimum of the unsigned distance: the search ends within 1e-12 of 0
+}
+// The smallest t >= 0 at which the ray is within `thresh` of the tube's surface (torus frame, double; 512 samples over the part of the ray
+// inside the bounding sphere + 1, then bisection); a negative value if there is none up to t = 400.
+__device__ double ray_tube_first_entry(const DevTorus& T, f3 of, f3 df, double thresh)
+{
+    const double Rm = fabs((double)T.radii.x), rt = fabs((double)T.radii.y), Rb = Rm + rt + 1.0;
+    const double ox = of.x, oy = of.y, oz = of.z, dx = df.x, dy = df.y, dz = df.z;
+    const double a = dx * dx + dy * dy + dz * dz, b = ox * dx + oy * dy + oz * dz, c = ox * ox + oy * oy + oz * oz - Rb * Rb;
+    const double h = b * b - a * c;
+    if (!(h >= 0.0)) return -1.0;
+    const double sh = sqrt(h);
+    double t0 = (-b - sh) / a, t1 = (-b + sh) / a;
+    t0 = t0 < 0.0 ? 0.0 : t0;
+    t1 = t1 > 400.0 ? 400.0 : t1;
+    if (!(t0 <= t1)) return -1.0;
+    auto g = [&](double t) { return tube_sd(Rm, rt, ox + t * dx, oy + t * dy, oz + t * dz) - thresh; };
+    if (g(t0) <= 0.0) return t0;
+    const int N = 512;
+    const double dt = (t1 - t0) / N;
+    double prev = t0;
+    for (int k = 1; k <= N; k++) {
+        const double t = t0 + dt * k;
+        if (g(t) <= 0.0) {
+            double lo = prev, hi = t;
+            for (int j = 0; j < 50; j++) { const double m = 0.5 * (lo + hi); if (g(m) <= 0.0) hi = m; else lo = m; }
+            return hi;
+        }
+        prev = t;
+    }
+    return -1.0;
+}
+__device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = S.h->n_torus;
+    if (n == 0) return;
+    const bool grouped = n >= RT_GROUP_MIN;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevTorus T = S.tori()[i];
+        const f4 bound = S.torus_bound()[i];
+        f3 ro, rd;
+        float tmin;
+        torus_ray(R, T, bound, (int)(R.next() & 7ull), ro, rd, tmin);
+        const bool scaled = R.u01() < 0.02f;                       // a share of non-unit directions: nothing may cull them
+        if (scaled) rd = rd * (R.u01() < 0.5f ? 1.0f + R.logu(2.0e-3f, 1.0f) : 1.0f - R.logu(2.0e-3f, 0.7f));
+        const bool ident = ident_flag(T.pos.w);
+        const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
+        const bool unit = unit_direction(dot3(d, d));
+        const bool c_sphere = torus_cull(bound, ro, rd, tmin);
+        const bool c_group = grouped && torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin);
+        const bool c_hull = unit && torus_hull_cull(T, o, d);
+        const bool c_puck = unit && torus_puck_cull(T, o, d, tmin);
+        // the premise in its strongest form: the ray's part up to the limit stays 6 mm clear of the REAL tube (exact) -- every cull and every
+        // clear bit of a candidate table implies it (their margins are 1 % + 0.01 and more)
+        const bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)torus_limit(tmin) * 1.001 + 0.01) >= 6.0e-3;
+        const bool any = c_sphere || c_group || c_hull || c_puck || c_line;
+        c[0]++; c[1] += any; c[2] += c_sphere; c[3] += c_group; c[4] += c_hull; c[5] += c_puck; c[6] += c_line; c[16] += scaled;
+        // product's own composition must agree with the parts (intersect_torus_c<true> is what the scans call)
+        if (scaled && (c_sphere || c_group || c_hull || c_puck) && !unit_direction(dot3_fma(rd, rd))) { c[15]++; record_bad(p, 15, i, ro, rd, tmin, 0.0f, dot3(rd, rd)); }
+        if (any) {
+            float t = 0.0f;
+            const bool hit = intersect_torus(T, ro, rd, tmin, t);
+            c[7]++; c[8] += hit;
+            if (hit) {
+                if (c_sphere) { c[10]++; record_bad(p, 10, i, ro, rd, tmin, t, 0.0f); }
+                if (c_group) { c[11]++; record_bad(p, 11, i, ro, rd, tmin, t, 0.0f); }
+                if (c_hull) { c[12]++; record_bad(p, 12, i, ro, rd, tmin, t, 0.0f); }
+                if (c_puck) { c[13]++; record_bad(p, 13, i, ro, rd, tmin, t, 0.0f); }
+                if (c_line) { c[14]++; record_bad(p, 14, i, ro, rd, tmin, t, 0.0f); }
+            }
+        }
+    }
+}
+
+// The premise itself, measured: when the reference's solver reports a hit, how far from the REAL tube does the ray pass (0 if it touches
+// it)? Every ray is solved; for a reported hit the clearance of the ray's part 0 <= t <= 1.001 torus_limit(tmin) + 0.01 from the tube's
+// surface is evaluated in double (ray_tube_clearance). A hit with a positive clearance is a phantom: the culls stay correct as long as no
+// phantom has a clearance beyond their inflation (1 % of R + r, + 0.01: a ray that far out is what the sphere / puck culls remove).
+// Also: how far from the tube's surface is the reported hit POINT (accuracy of the accepted root, not a matter of the culls).
+// counters: 0 rays, 1 hits, 2 hits whose ray touches the tube, 3..11 phantoms with a clearance in [10^(k-10), 10^(k-9)) (3: below 1e-6 ...
+//           11: >= 10), 12 VIOLATIONS phantoms beyond the inflation, 13..18 |distance| of the hit point from the surface < 1e-5, < 1e-4, < 1e-3,
+//           < 1e-2, < 1e-1, >= 1e-1; 20 largest phantom clearance (float bits, atomicMax), 21 largest hit-point distance;
+//           22..27 hits by class of t, 28..33 of them reported earlier than 1e-3 t + 0.01 before the ray enters the inflated tube, 34..39 the largest lead
+__device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c, unsigned int& worst, unsigned int& worst_pt, unsigned int* lead_bits)
+{
+    const int n = S.h->n_torus;
+    if (n == 0) return;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevTorus T = S.tori()[i];
+        if (!(T.cull.y < RT_FLT_MAX)) continue;          // tori that are never culled (zero tube, non-unit quaternion) are outside every premise
+        f3 ro, rd;
+        float tmin;
+        torus_ray(R, T, S.torus_bound()[i], (int)(R.next() & 7ull), ro, rd, tmin);
+        float t = 0.0f;
+        c[0]++;
+        if (!intersect_torus(T, ro, rd, tmin, t)) continue;
+        c[1]++;
+        const bool ident = ident_flag(T.pos.w);
+        const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
+        const double tl = (double)torus_limit(tmin) * 1.001 + 0.01;
+        const double clr = ray_tube_clearance(T, o, d, tl);
+        const double infl = 0.01 * (fabs((double)T.radii.x) + fabs((double)T.radii.y)) + 0.01;
+        if (clr <= 0.0) c[2]++;
+        else {
+            int k = 3;
+            for (double lim = 1.0e-6; k < 11 && clr >= lim; lim *= 10.0) k++;
+            c[k]++;
+            if (clr > infl) { c[12]++; record_bad(p, 12, i, ro, rd, tmin, t, (float)clr); }
+            const unsigned bits = __builtin_bit_cast(unsigned, (float)clr);
+            worst = bits > worst ? bits : worst;
+        }
+        // how much EARLIER than the ray's true entry into the inflated tube is the hit reported? (the limit tests of the culls -- "entered beyond
+        // tlimit" -- assume at most 1e-3 tlimit + 0.01). Per class of the reported t: below 4, 8, 16, 32, 64, beyond.
+        {
+            const double tin = ray_tube_first_entry(T, o, d, infl);
+            if (tin >= 0.0) {
+                const float lead = (float)(tin - (double)t);
+                const int bin = t < 4.0f ? 0 : t < 8.0f ? 1 : t < 16.0f ? 2 : t < 32.0f ? 3 : t < 64.0f ? 4 : 5;
+                c[22 + bin]++;
+                if (lead > 1.0e-3f * t + 0.01f) { c[28 + bin]++; }
+                // candidates for a wider limit margin: 40 lead > 1e-3 t + 0.01 + 0.025 (t - 8) for t > 8; 41 lead > 1; 42 lead > 5
+                if (t > 8.0f && lead > 1.0e-3f * t + 0.01f + 0.025f * (t - 8.0f)) c[40]++;
+                if (lead > 1.0f) c[41]++;
+                if (lead > 5.0f) c[42]++;
+                if (lead > 0.0f) { const unsigned lb = __builtin_bit_cast(unsigned, lead); lead_bits[bin] = lb > lead_bits[bin] ? lb : lead_bits[bin]; }
+            }
+        }
+        const double px = (double)o.x + (double)t * d.x, py = (double)o.y + (double)t * d.y, pz = (double)o.z + (double)t * d.z;
+        const float a = (float)tube_dist(fabs((double)T.radii.x), fabs((double)T.radii.y), px, py, pz);
+        c[a < 1.0e-5f ? 13 : a < 1.0e-4f ? 14 : a < 1.0e-3f ? 15 : a < 1.0e-2f ? 16 : a < 1.0e-1f ? 17 : 18]++;
+#ifdef AUDIT_DEBUG_POINT
+        if (a >= 0.1f && t >= 4.0f && t < 8.0f) record_bad(p, 99, i, ro, rd, tmin, t, a);
+#endif
+        const unsigned pb = __builtin_bit_cast(unsigned, a);
+        worst_pt = pb > worst_pt ? pb : worst_pt;
+    }
+}
+
+// ================================================================================================================================
+// quadrics: surface_cull (segment test, tight / far bound, degenerate-branch margin), group sphere + quadric_may_degenerate, and the product's
+// intersect_surface (wave-level exit for waves without a real root) against the literal rt.frag:513-572
+// counters: 0 rays, 1 culled by surface_cull, 2 culled by the group test, 3 literal hits, 4 literal hits on the degenerate branch,
+//           10 VIOLATIONS surface_cull, 11 group, 12 product intersector != literal (hit flag, or t on a hit)
+// ================================================================================================================================
+__device__ bool intersect_surface_literal(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t, bool& degenerate)
+{
+    const f3 ro = quat_rotate(Q.quat, ro_w - xyz(Q.pos_a));
+    const f3 rd = quat_rotate(Q.quat, rd_w);
+    const float a = Q.pos_a.w, b = Q.bcde.x, c = Q.bcde.y, d = Q.bcde.z, e = Q.bcde.w, f = Q.f_vmin.x;
+    const float d1 = rd.x, d2 = rd.y, d3 = rd.z, o1 = ro.x, o2 = ro.y, o3 = ro.z;
+    const float p1 = 2.0f * a * d1 * o1 + 2.0f * b * d2 * o2 + 2.0f * c * d3 * o3 + d * d3 + d2 * e;
+    const float p2 = a * d1 * d1 + b * d2 * d2 + c * d3 * d3;
+    const float p3 = a * o1 * o1 + b * o2 * o2 + c * o3 * o3 + d * o3 + e * o2 + f;
+    degenerate = fabsf(p2) < 1e-6f;
+    if (degenerate) { t = -p3 / p1; return t > tmin; }
+    const float p4 = sqrtf(p1 * p1 - 4.0f * p2 * p3);
+    float mn = RT_FLT_MAX, mx = RT_FLT_MAX;
+    const float t1 = (-p1 - p4) / (2.0f * p2), t2 = (-p1 + p4) / (2.0f * p2);
+    const float epsilon = 1e-4f;
+    if (t1 > epsilon && t1 < mn) { mn = t1; mx = t2; }
+    if (t2 > epsilon && t2 < mn) { mn = t2; mx = t1; }
+    const f3 vmin = mk3(Q.f_vmin.y, Q.f_vmin.z, Q.f_vmin.w), vmax = xyz(Q.vmax);
+    f3 pt = rd_w * mn + ro_w;
+    if (!is_between(pt, vmin, vmax)) {
+        if (mx < epsilon) return false;
+        pt = rd_w * mx + ro_w;
+        if (!is_between(pt, vmin, vmax)) return false;
+        const float tmp = mn; mn = mx; mx = tmp;
+    }
+    t = mn;
+    return t < tmin;
+}
+__device__ f3 clip_centre(const DevSurface& Q, const DevSurfaceCull& C, float& ext)
+{
+    const f3 lo = mk3(Q.f_vmin.y, Q.f_vmin.z, Q.f_vmin.w), hi = xyz(Q.vmax);
+    const f3 pos = xyz(Q.pos_a);
+    f3 c = pos;
+    ext = 2.0f;
+    if (C.bound.w >= 0.0f && C.bound.w < 1.0e12f) { c = xyz(C.bound); ext = sqrtf(C.bound.w); }
+    (void)lo; (void)hi;
+    return c;
+}
+__device__ void quadric_ray(Rng& R, const DevSurface& Q, const DevSurfaceCull& C, int mode, f3& ro, f3& rd, float& tmin)
+{
+    float ext;
+    const f3 c = clip_centre(Q, C, ext);
+    tmin = ray_tmin(R);
+    if (mode <= 2 || mode == 3) {             // around the quadric: 0.05 ... 200 units (3 of 4) or 200 ... 1e5 units out
+        const float dist = mode == 3 ? R.logu(200.0f, 1.0e5f) : R.logu(0.05f, 200.0f);
+        ro = c + R.unit() * dist;
+        const float spread = ext * (R.u01() < 0.6f ? 1.5f : 8.0f);
+        rd = normalize3(c + mk3(R.gauss(), R.gauss(), R.gauss()) * spread - ro);
+        if (R.u01() < 0.1f) rd = -rd;
+    } else if (mode == 4) {                   // directions next to the asymptotic cone: |p2| from 1e-8 to a few times the cull's margin, origins
+                                              // anywhere incl. inside the clip box, finite limits (the ill-conditioned regime)
+        const float a = Q.pos_a.w, b = Q.bcde.x, cc = Q.bcde.y;
+        f3 u = R.unit(), v = R.unit();
+        auto p2 = [&](f3 w) { return a * w.x * w.x + b * w.y * w.y + cc * w.z * w.z; };
+        float pu = p2(u), pv = p2(v);
+        f3 dl = u;
+        if ((pu < 0.0f) != (pv < 0.0f)) {     // indefinite form: bisect along the arc for a root of p2, then step off it by a tiny angle
+            for (int k = 0; k < 24; k++) { const f3 m = normalize3(u + v); const float pm = p2(m); if ((pm < 0.0f) == (pu < 0.0f)) { u = m; pu = pm; } else { v = m; pv = pm; } }
+            dl = normalize3(u + R.unit() * R.logu(1.0e-8f, 3.0e-2f));
+        }
+        rd = normalize3(quat_rotate(Q.qinv, dl));
+        const f3 through = c + mk3(R.sym(), R.sym(), R.sym()) * (ext * (R.u01() < 0.7f ? 0.6f : 3.0f));
+        ro = through - rd * (R.u01() < 0.3f ? R.logu(1.0e-3f, 1.0f) * ext : R.logu(0.05f, 3000.0f));
+        if (R.u01() < 0.7f) tmin = R.logu(0.1f, 1000.0f);
+    } else if (mode == 5) {                   // origins inside the bound / the clip box, every direction, finite limits
+        ro = c + mk3(R.sym(), R.sym(), R.sym()) * (ext * 0.7f);
+        rd = R.unit();
+        if (R.u01() < 0.7f) tmin = R.logu(1.0e-3f, 50.0f);
+    } else if (mode == 6) {                   // grazing the cull sphere (the tight one within RT_QUADRIC_FAR, the clip box's beyond)
+        const f3 n = R.unit();
+        const bool far = R.u01() < 0.3f && C.sym1.w >= 0.0f;
+        const float rb = far ? sqrtf(C.sym1.w) : ext;
+        const f3 pb = c + n * (rb * (1.0f + 0.02f * R.sym()));
+        const f3 d = grazing_dir(R, n);
+        ro = pb - d * (far ? R.logu(60.0f, 3000.0f) : R.logu(0.01f, 60.0f));
+        rd = d;
+    } else {                                  // origins around the switch between the two bounds (RT_QUADRIC_FAR +- 10)
+        ro = c + R.unit() * ((float)RT_QUADRIC_FAR + 10.0f * R.sym());
+        rd = normalize3(c + mk3(R.gauss(), R.gauss(), R.gauss()) * (ext * 1.5f) - ro);
+    }
+}
+__device__ void audit_quadric(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = S.h->n_surface;
+    if (n == 0) return;
+    const bool grouped = n >= RT_GROUP_MIN;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevSurface Q = S.surfaces()[i];
+        const DevSurfaceCull C = S.surf_cull()[i];
+        f3 ro, rd;
+        float tmin;
+        quadric_ray(R, Q, C, (int)(R.next() & 7ull), ro, rd, tmin);
+        const bool c_cull = surface_cull(C, ro, rd, tmin);
+        const bool c_group = grouped && surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd) && !quadric_may_degenerate(C, rd);
+        float t_lit = 0.0f, t_prod = 0.0f;
+        bool deg = false;
+        const bool hit = intersect_surface_literal(Q, ro, rd, tmin, t_lit, deg);
+        const bool hit_p = intersect_surface(Q, ro, rd, tmin, t_prod);
+        c[0]++; c[1] += c_cull; c[2] += c_group; c[3] += hit; c[4] += hit && deg;
+        if (c_cull && hit) { c[10]++; record_bad(p, 10, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
+        if (c_group && hit) { c[11]++; record_bad(p, 11, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
+        if (hit != hit_p || (hit && __builtin_bit_cast(unsigned, t_lit) != __builtin_bit_cast(unsigned, t_prod))) { c[12]++; record_bad(p, 12, i, ro, rd, tmin, t_lit, t_prod); }
+    }
+}
+
+// ================================================================================================================================
+// rings: counters 0 rays, 1 culled, 2 literal hits, 10 VIOLATIONS
+// ================================================================================================================================
+__device__ void audit_ring(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = S.h->n_ring;
+    if (n == 0) return;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevRing G = S.rings()[i];
+        const f4 bound = S.ring_bound()[i];
+        const f3 cen = xyz(G.pos_tex);
+        const float ext = sqrtf(fabsf(G.radii.y)) + 1.0e-3f;
+        f3 ro, rd;
+        float tmin = ray_tmin(R);
+        const int mode = (int)(R.next() & 3ull);
+        if (mode <= 1) {
+            ro = cen + R.unit() * (mode == 0 ? R.logu(0.02f, 200.0f) : R.logu(200.0f, 1.0e5f));
+            rd = normalize3(cen + mk3(R.gauss(), R.gauss(), R.gauss()) * (ext * (R.u01() < 0.6f ? 1.2f : 6.0f)) - ro);
+            if (R.u01() < 0.1f) rd = -rd;
+        } else if (mode == 2) {               // through the rim: a point of the ring's plane within +-2 % of the outer radius
+            const float a = 6.2831853f * R.u01(), rad = ext * (1.0f + 0.02f * R.sym());
+            const f3 pl = mk3(rad * __cosf(a), rad * __sinf(a), 0.0f);
+            const f3 pw = quat_rotate(quat_inv(G.quat), pl) + cen;
+            rd = R.unit();
+            ro = pw - rd * R.logu(0.01f, 300.0f);
+        } else {                              // grazing the cull sphere
+            const f3 nn = R.unit();
+            const f3 pb = cen + nn * (sqrtf(bound.w) * (1.0f + 0.02f * R.sym()));
+            rd = grazing_dir(R, nn);
+            ro = pb - rd * R.logu(0.01f, 300.0f);
+        }
+        const bool cull = ring_cull(bound, ro, rd, tmin);
+        float t = 0.0f;
+        f2 uv;
+        const bool hit = intersect_ring(G, ro, rd, tmin, t, uv);
+        c[0]++; c[1] += cull; c[2] += hit;
+        if (cull && hit) { c[10]++; record_bad(p, 10, i, ro, rd, tmin, t, 0.0f); }
+    }
+}
+
+// ================================================================================================================================
+// candidate tables (ray pencils + slab tables + direction table): rays built like the tracer builds them; for a sample of the primitives
+// whose bit is CLEAR in the ray's mask: a quadric must not be hit by the literal intersector; a torus must stay 6 mm clear of the ray's part
+// up to its limit in exact arithmetic (the premise the torus family audits against the solver).
+// counters: 0 rays, 1 camera-pencil rays, 2 light-pencil rays, 3 slab-table rays, 4 rays that read every bit set, 5 set bits,
+//           6 quadric checks, 7 torus checks, 10 VIOLATIONS quadric, 11 torus
+// ================================================================================================================================
+__device__ f3 crowd_point(Rng& R, f3 c, f3 half)
+{
+    const float far = R.u01() < 0.1f ? 40.0f : 1.0f;
+    return c + mk3(R.gauss() * half.x, R.gauss() * half.y, R.gauss() * half.z) * (0.6f * far);
+}
+__device__ void audit_tables(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int ns = S.h->n_surface, nt = S.h->n_torus, nws = (ns + 31) >> 5, W = (int)S.h->pencil_stride;
+    if (S.pen == nullptr || ns + nt == 0 || W == 0) return;
+    const int n_lights = S.h->n_light_point + S.h->n_light_direct;
+    // where the primitives are: the slab box if there is one, else a default crowd box
+    f3 cen = mk3(0.0f, 0.0f, 16.0f), half = mk3(12.0f, 10.0f, 8.0f);
+    if (slabs_available(S)) { const DevSlabs& B = *S.slabs(); cen = (xyz(B.lo) + xyz(B.hi)) * 0.5f; half = (xyz(B.hi) - xyz(B.lo)) * 0.5f; }
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int kind = (int)(ray % 3ull);
+        f3 ro, rd;
+        float tlimit = RT_MAXDIST;
+        uint32_t words[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        bool have = false;
+        if (kind == 0) {
+            ro = xyz(S.h->cam_pos);
+            rd = normalize3(crowd_point(R, cen, half) - ro);
+            const PencilScan ps = pencil_open<true>(S, 0, ro, rd, 0.0f, true);
+            if (ps.use) { have = true; c[1]++; for (int w = 0; w < W && w < 8; w++) words[w] = S.pen[ps.cell + w]; }
+        } else if (kind == 1 && n_lights > 0) {
+            const int li = (int)(R.next() % (unsigned long long)n_lights);
+            ro = crowd_point(R, cen, half);
+            if (li < S.h->n_light_point) { const f3 ld = xyz(S.lights_point()[li].pos_r2) - ro; tlimit = length3(ld); rd = normalize3(ld); }
+            else rd = xyz(S.lights_direct()[li - S.h->n_light_point].dir_n);
+            const PencilScan ps = pencil_open<true>(S, 1 + li, ro, rd, tlimit, false);
+            if (ps.use) { have = true; c[2]++; for (int w = 0; w < W && w < 8; w++) words[w] = S.pen[ps.cell + w]; }
+        }
+        if (!have) {
+            if (!slabs_available(S)) continue;
+            ro = crowd_point(R, cen, half);
+            rd = normalize3(crowd_point(R, cen, half) - ro);
+            tlimit = R.u01() < 0.5f ? RT_MAXDIST : 1.0f + 40.0f * R.u01();
+            slab_ray_mask(S, ro, rd, tlimit, words);
+            c[3]++;
+        }
+        c[0]++;
+        int bits = 0;
+        for (int w = 0; w < W && w < 8; w++) bits += __builtin_popcount(words[w]);
+        c[5] += (unsigned)bits;
+        c[4] += bits == ns + nt;
+        for (int s = 0; s < 6; s++) {           // six primitives per ray, clear bits only
+            const int i = (int)(R.next() % (unsigned long long)(ns + nt));
+            const int w = i < ns ? i >> 5 : nws + ((i - ns) >> 5), b = (i < ns ? i : i - ns) & 31;
+            if ((words[w] >> b) & 1u) continue;
+            if (i < ns) {
+                float t = 0.0f;
+                bool deg;
+                c[6]++;
+                if (intersect_surface_literal(S.surfaces()[i], ro, rd, tlimit, t, deg)) { c[10]++; record_bad(p, 10 + kind * 100, i, ro, rd, tlimit, t, deg ? 1.0f : 0.0f); }
+            } else {
+                c[7]++;
+                const DevTorus T = S.tori()[i - ns];
+                const bool ident = ident_flag(T.pos.w);
+                const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
+                const double clr = ray_tube_clearance(T, o, d, (double)torus_limit(tlimit) * 1.001 + 0.01);
+                if (!(clr >= 6.0e-3)) { c[11]++; record_bad(p, 11 + kind * 100, i - ns, ro, rd, tlimit, 0.0f, (float)clr); }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
+{
+    const SceneView S = make_view(p.scene, reinterpret_cast<const DevSceneHeader*>(p.scene), p.pencil_masks);
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    unsigned int c[N_COUNTERS];                     // per thread: at most iters x 160 each
+    for (int k = 0; k < N_COUNTERS; k++) c[k] = 0u;
+    unsigned int worst = 0u, worst_pt = 0u, lead_bits[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (p.family == F_TORUS) audit_torus(p, S, gid, c);
+    else if (p.family == F_TORUS_MARGIN) audit_torus_margin(p, S, gid, c, worst, worst_pt, lead_bits);
+    else if (p.family == F_QUADRIC) audit_quadric(p, S, gid, c);
+    else if (p.family == F_RING) audit_ring(p, S, gid, c);
+    else audit_tables(p, S, gid, c);
+    flush(p, c);
+    if (p.family == F_TORUS_MARGIN && worst) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 20), worst);
+    if (p.family == F_TORUS_MARGIN && worst_pt) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 21), worst_pt);
+    if (p.family == F_TORUS_MARGIN)
+        for (int b = 0; b < 6; b++) if (lead_bits[b]) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 34 + b), lead_bits[b]);
+}
+
+__global__ __launch_bounds__(256) void audit_pencil_build(const char* scene, uint32_t* masks)
+{
+    __shared__ PencilPrim prims[2 * RT_PENCIL_MAX_PRIMS];
+    const SceneView S = make_view(scene);
+    const DevPencil P = S.pencils()[blockIdx.y];
+    if (P.kind == RT_PENCIL_OFF || blockIdx.x * 256u > P.cells) return;
+    const int n = S.h->n_surface + S.h->n_torus;
+    for (int k = threadIdx.x; k < n; k += 256) prims[k] = pencil_prim_at(S, P, k);
+    __syncthreads();
+    const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
+    if (cell > P.cells) return;
+    const PencilCell C = pencil_cell_geometry(P, cell);
+    masks[P.mask_off + (size_t)cell * S.h->pencil_stride + blockIdx.z] = pencil_cell_word(S, P, prims, C, cell, (int)blockIdx.z);
+}
+
+std::string g_err;
+#define TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e_); return -1; } } while (0)
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) const char* cull_audit_error() { return g_err.c_str(); }
+
+// One scene (the nine std140 blocks the boundary receives), one family, `rays` rays (rounded up to whole launches of 2^20 threads).
+// counters: N_COUNTERS x uint64, summed into (not cleared); bad: up to max_bad records of BAD_FLOATS floats; returns the number of records
+// written, or -1 (cull_audit_error()).
+__attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines* d, const void* const* blocks, const uint64_t* sizes, int family, uint64_t rays, uint64_t seed,
+                                                          uint64_t* counters, float* bad, int max_bad, double* seconds)
+{
+    std::vector<unsigned char> blk[rtpack::BLK_COUNT];
+    for (int b = 0; b < rtpack::BLK_COUNT; b++) {
+        const unsigned char* p = static_cast<const unsigned char*>(blocks[b]);
+        if (p && sizes[b]) blk[b].assign(p, p + sizes[b]);
+    }
+    std::vector<unsigned char> blob;
+    if (!rtpack::pack_scene(*d, blk, blob, g_err)) return -1;
+    const DevSceneHeader hdr = *reinterpret_cast<const DevSceneHeader*>(blob.data());
+    char* d_scene = nullptr;
+    uint32_t* d_masks = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    float* d_bad = nullptr;
+    unsigned int* d_nbad = nullptr;
+    TRY(hipMalloc(&d_scene, (blob.size() + 15) & ~size_t(15)));
+    TRY(hipMemcpy(d_scene, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    if (hdr.n_pencil > 0 && hdr.pencil_mask_words > 0) {
+        TRY(hipMalloc(&d_masks, (size_t)hdr.pencil_mask_words * 4));
+        TRY(hipMemset(d_masks, 0, (size_t)hdr.pencil_mask_words * 4));
+        const DevPencil* pencils = reinterpret_cast<const DevPencil*>(blob.data() + hdr.off_pencil);
+        const uint32_t records = hdr.n_pencil + (hdr.pencil_dir != 0xffffffffu ? 1u : 0u);
+        uint32_t most = 0;
+        for (uint32_t k = 0; k < records; k++) if (pencils[k].kind != RT_PENCIL_OFF && pencils[k].cells > most) most = pencils[k].cells;
+        if (most) hipLaunchKernelGGL(audit_pencil_build, dim3((most + 1 + 255) / 256, records, hdr.pencil_stride), dim3(256), 0, 0, d_scene, d_masks);
+        TRY(hipGetLastError());
+    }
+    TRY(hipMalloc(&d_cnt, N_COUNTERS * 8));
+    TRY(hipMemset(d_cnt, 0, N_COUNTERS * 8));
+    TRY(hipMalloc(&d_bad, (size_t)(max_bad > 0 ? max_bad : 1) * BAD_FLOATS * 4));
+    TRY(hipMalloc(&d_nbad, 4));
+    TRY(hipMemset(d_nbad, 0, 4));
+    AuditParams p;
+    p.scene = d_scene; p.pencil_masks = d_masks; p.counters = d_cnt; p.bad = d_bad; p.n_bad = d_nbad; p.max_bad = max_bad; p.family = family;
+    const uint64_t threads = 1ull << 20;                     // 4096 workgroups: 16 per CU
+    p.iters = 256;
+    const uint64_t per_launch = threads * (uint64_t)p.iters;
+    const uint64_t launches = (rays + per_launch - 1) / per_launch;
+    hipEvent_t e0, e1;
+    TRY(hipEventCreate(&e0));
+    TRY(hipEventCreate(&e1));
+    TRY(hipEventRecord(e0, 0));
+    for (uint64_t l = 0; l < launches; l++) {
+        p.seed = seed * 1000003ull + l;
+        hipLaunchKernelGGL(audit_kernel, dim3((unsigned)(threads / 256)), dim3(256), 0, 0, p);
+    }
+    TRY(hipGetLastError());
+    TRY(hipEventRecord(e1, 0));
+    TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (seconds) *seconds = ms * 1e-3;
+    unsigned long long host_cnt[N_COUNTERS];
+    TRY(hipMemcpy(host_cnt, d_cnt, sizeof host_cnt, hipMemcpyDeviceToHost));
+    for (int k = 0; k < N_COUNTERS; k++) {
+        if (family == F_TORUS_MARGIN && (k == 20 || k == 21 || (k >= 34 && k < 40))) counters[k] = counters[k] > host_cnt[k] ? counters[k] : host_cnt[k];
+        else counters[k] += host_cnt[k];
+    }
+    unsigned int nb = 0;
+    TRY(hipMemcpy(&nb, d_nbad, 4, hipMemcpyDeviceToHost));
+    const int wrote = (int)(nb < (unsigned)max_bad ? nb : (unsigned)max_bad);
+    if (wrote > 0) TRY(hipMemcpy(bad, d_bad, (size_t)wrote * BAD_FLOATS * 4, hipMemcpyDeviceToHost));
+    hipFree(d_scene); hipFree(d_masks); hipFree(d_cnt); hipFree(d_bad); hipFree(d_nbad);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return wrote;
+}
+
+}  // extern "C"
