@@ -39,7 +39,7 @@ LABELS = {
                 10: "VIOLATIONS surface_cull", 11: "VIOLATIONS group test", 12: "VIOLATIONS product intersector != literal rt.frag:513-572"},
     "ring": {0: "rays", 1: "culled", 2: "literal hits", 10: "VIOLATIONS"},
     "tables": {0: "rays", 1: "camera-pencil rays", 2: "light-pencil rays", 3: "slab-table rays", 4: "rays whose mask has every bit set", 5: "set bits", 6: "quadric checks (clear bit)",
-               7: "torus checks (clear bit)", 10: "VIOLATIONS quadric: bit clear, literal intersector hits", 11: "VIOLATIONS torus: bit clear, the ray up to its limit comes within 6 mm of the real tube"},
+               7: "torus checks (clear bit)", 10: "VIOLATIONS quadric: bit clear, literal intersector hits", 11: "VIOLATIONS torus: bit clear, the ray up to its limit comes within 5 mm of the real tube"},
 }
 
 
