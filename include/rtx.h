@@ -181,7 +181,10 @@ RTX_API int rtx_texture2d_create(rtx_context* ctx, int width, int height, int ch
                                  const uint8_t* texels, int wrap, uint32_t* handle);
 /* GLWrapper::load_cubemap(faces,genMipmap) minus the file decode  [GLWrapper.cpp:284-317]:
  * faces in +X,-X,+Y,-Y,+Z,-Z order; a NULL face is skipped (stays black) like a face that
- * failed to load. LINEAR, CLAMP_TO_EDGE, not seamless. */
+ * failed to load. LINEAR, CLAMP_TO_EDGE, not seamless.
+ * gen_mipmap must be 0 (the reference's default, what main.cpp:137-147 passes): with genMipmap = true the reference builds cube mips and
+ * filters the sky trilinearly (GLWrapper.cpp:307-310), which this library does not do -- gen_mipmap != 0 fails with RTX_ERR_INVALID and a
+ * message instead of rendering a different sky silently. On any failure *handle is 0. */
 RTX_API int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels,
                                const uint8_t* const faces[6], int gen_mipmap, uint32_t* handle);
 /* shader.setInt(uniformName, unit)  [GLWrapper.cpp:138,360]: sampler names skybox,
@@ -233,6 +236,10 @@ RTX_API int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t
 /* Device pointer of the colour target (W*H pixels of `format`), for zero-copy consumers. */
 RTX_API int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr);
 RTX_API int rtx_get_stats(rtx_context* ctx, rtx_stats* out);
+/* rtx_stats is append-only and has grown (last_smaa_ms and everything behind it came after round 1): rtx_get_stats writes sizeof(rtx_stats)
+ * of THIS header. A caller built against an older header -- or one that wants to stay binary compatible with newer libraries -- passes the
+ * size of its own struct here and gets that prefix, never a write beyond it. */
+RTX_API int rtx_get_stats_sized(rtx_context* ctx, void* out, size_t out_bytes);
 
 /* ---- diagnostics without a reference counterpart ---- */
 /* Sum of the HIP-event durations (ms) of the n most recent draws (n <= 128): the kernel time a

@@ -769,6 +769,7 @@ static void forget_texture(rtx_context* c, uint32_t h)
 #define RTX_FORWARD_TEXTURE(call)                                                                       \
     do {                                                                                                \
         const uint32_t _h = *handle;                                                                    \
+        uint32_t* const _root_handle = handle;   /* (the loop body shadows `handle`) */                  \
         for (rtx_context * _p : ctx->peers) {                                                           \
             rtx_context* ctx = _p;                                                                      \
             uint32_t _hp = 0;                                                                           \
@@ -782,6 +783,7 @@ static void forget_texture(rtx_context* c, uint32_t h)
                 for (rtx_context * _q : _root->peers) { forget_texture(_q, _h); forget_texture(_q, _hp); _q->next_handle = _root->next_handle; } \
                 (void)hipSetDevice(_root->device);                                                      \
                 g_error = _msg;                                                                         \
+                *_root_handle = 0;   /* the texture is gone on every device: the caller must not keep its number */ \
                 return _st;                                                                             \
             }                                                                                           \
         }                                                                                               \
@@ -1094,9 +1096,17 @@ int rtx_texture2d_create(rtx_context* ctx, int width, int height, int channels, 
     return RTX_OK;
 }
 
-int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint8_t* const faces[6], int /*gen_mipmap*/, uint32_t* handle)
+int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint8_t* const faces[6], int gen_mipmap, uint32_t* handle)
 {
     if (!ctx || !handle || !faces) return fail(RTX_ERR_INVALID, "rtx_cubemap_create: null argument");
+    *handle = 0;
+    // load_cubemap(faces, genMipmap = true) makes the reference generate cube mips and min-filter the sky trilinearly
+    // (GLWrapper.cpp:307-310), which changes what texture(skybox, rd) (rt.frag:893) returns. This library samples level 0 only. Accepting the
+    // flag and ignoring it (rounds 1-3) was a silent difference from the reference; it is refused instead. (The reference's own program passes
+    // the default, false: main.cpp:137-147. The call sits in non-uniform control flow, where GLSL leaves implicit derivatives undefined.)
+    if (gen_mipmap)
+        return fail(RTX_ERR_INVALID, "rtx_cubemap_create: gen_mipmap = 1 (GLWrapper::load_cubemap(faces, true): cube mips + trilinear sky) is not supported -- "
+                                     "the sky is sampled at level 0, as with the reference's default genMipmap = false");
     int st = use_device(ctx);
     if (st) return st;
     Texture t;
@@ -1360,7 +1370,20 @@ int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr)
     return RTX_OK;
 }
 
-int rtx_get_stats(rtx_context* ctx, rtx_stats* out)
+static int get_stats_impl(rtx_context* ctx, rtx_stats* out);
+int rtx_get_stats(rtx_context* ctx, rtx_stats* out) { return get_stats_impl(ctx, out); }
+// rtx_stats grows with the library (rounds 2 and 3 appended fields). A caller compiled against an older header passes ITS struct: this
+// entry point never writes beyond the size the caller names (the fields are append-only, so a prefix is a valid older struct).
+int rtx_get_stats_sized(rtx_context* ctx, void* out, size_t out_bytes)
+{
+    if (!out || out_bytes == 0) return fail(RTX_ERR_INVALID, "rtx_get_stats_sized: null argument");
+    rtx_stats full;
+    const int st = get_stats_impl(ctx, &full);
+    if (st != RTX_OK) return st;
+    std::memcpy(out, &full, out_bytes < sizeof full ? out_bytes : sizeof full);
+    return RTX_OK;
+}
+static int get_stats_impl(rtx_context* ctx, rtx_stats* out)
 {
     if (!ctx || !out) return fail(RTX_ERR_INVALID, "null argument");
     int st = use_device(ctx);
