@@ -424,29 +424,55 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             sc.sym0 = mk4(static_cast<float>(A[0][0]), static_cast<float>(A[0][1]), static_cast<float>(A[0][2]), static_cast<float>(A[1][1]));
             const float margin = 1e-6f + 1e-5f * (std::fabs(a) + std::fabs(b) + std::fabs(c));
             sc.sym1 = mk4(static_cast<float>(A[1][2]), static_cast<float>(A[2][2]), margin, 0.0f);
-            const double lo[3] = {vmin.x, vmin.y, vmin.z}, hi[3] = {vmax.x, vmax.y, vmax.z};
+            // The bounds are computed in the quadric's OWN frame of translation (position at the origin, clip box relative to it) and moved to
+            // the position afterwards: they are translation-covariant, and a quadric that only moves between two frames -- the usual
+            // animation -- then finds them in the cache below (keyed on the whole record, every moved or re-coloured quadric
+            // missed and paid 0.1-0.5 ms of branch and bound inside rtx_draw). Unbounded clip planes (|v| >= 1e30) stay where they are.
+            const double pw_abs[3] = {pw[0], pw[1], pw[2]};
+            // The relative box is rounded OUTWARDS to 16 significant bits: `vmin = pos - h` computed in float differs from one position to the
+            // next in its last bits, and so would the key; a box that only grows keeps every bound valid (the clipped surface of the true
+            // box lies inside the clipped surface of the larger one) and costs 1.5e-5 of the box' size.
+            auto rel = [&](double v, int k, bool up) {
+                if (!(std::fabs(v) < 1.0e30)) return v;
+                const double r = v - pw_abs[k];
+                const double g = std::ldexp(1.0, std::ilogb(std::fmax(std::fabs(r), 1.0e-3)) - 16);
+                return (up ? std::ceil(r / g) : std::floor(r / g)) * g;
+            };
+            const double lo[3] = {rel(vmin.x, 0, false), rel(vmin.y, 1, false), rel(vmin.z, 2, false)}, hi[3] = {rel(vmax.x, 0, true), rel(vmax.y, 1, true), rel(vmax.z, 2, true)};
+            const double pw0[3] = {0.0, 0.0, 0.0};
             double clo[3], chi[3];
             sc.bound = mk4(0.0f, 0.0f, 0.0f, -1.0f);
             sc.sym1.w = std::numeric_limits<float>::quiet_NaN();    // no bound that holds for origins at any distance (yet)
             bool from_surface = false;
-            // The bounds are a pure function of the 160-byte record and cost ~0.1 ms of branch and bound: a program that re-uploads all
-            // its blocks every frame (the reference's main loop does, main.cpp:246) gets them from a small cache.
-            struct CachedBounds { f4 bound; float far_w; double aabb[6]; };
+            // The bounds are a pure function of the rotation, the six coefficients and the clip box relative to the position, and cost
+            // 0.1-0.5 ms of branch and bound: a program that re-uploads all its blocks every frame (the reference's main loop does,
+            // main.cpp:246) gets them from a small cache. The material and the position are not part of the key.
+            struct CachedBounds { double c[3], tight2, far_w; double aabb[6]; bool has; };
             static std::mutex cache_mu;
             static std::unordered_map<std::string, CachedBounds> cache;
-            const std::string cache_key(reinterpret_cast<const char*>(p), SZ_SURFACE);
+            struct KeyBytes { float quat[4], coef[6]; double lo[3], hi[3]; } kb;
+            std::memset(&kb, 0, sizeof kb);
+            kb.quat[0] = s.quat.x; kb.quat[1] = s.quat.y; kb.quat[2] = s.quat.z; kb.quat[3] = s.quat.w;
+            kb.coef[0] = a; kb.coef[1] = b; kb.coef[2] = c; kb.coef[3] = dd; kb.coef[4] = e; kb.coef[5] = f;
+            for (int k = 0; k < 3; k++) { kb.lo[k] = lo[k]; kb.hi[k] = hi[k]; }
+            const std::string cache_key(reinterpret_cast<const char*>(&kb), sizeof kb);
             bool cached = false;
             {
                 std::lock_guard<std::mutex> g(cache_mu);
                 const auto it = cache.find(cache_key);
                 if (it != cache.end()) {
                     cached = true;
-                    sc.bound = it->second.bound;
-                    sc.sym1.w = it->second.far_w;
-                    for (int k = 0; k < 6; k++) surf_aabb[i * 6 + k] = it->second.aabb[k];
+                    const CachedBounds& cb = it->second;
+                    if (cb.has) {
+                        sc.bound = mk4(static_cast<float>(cb.c[0] + pw_abs[0]), static_cast<float>(cb.c[1] + pw_abs[1]), static_cast<float>(cb.c[2] + pw_abs[2]), static_cast<float>(cb.tight2));
+                        sc.sym1.w = static_cast<float>(cb.far_w);
+                        for (int k = 0; k < 6; k++) surf_aabb[i * 6 + k] = cb.aabb[k] + pw_abs[k % 3];
+                    }
                 }
             }
-            if (!cached && quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi, 0.0, from_surface)) {
+            CachedBounds fresh;
+            std::memset(&fresh, 0, sizeof fresh);
+            if (!cached && quadric_clip_bounds(A, wv, pw0, static_cast<double>(f), lo, hi, clo, chi, 0.0, from_surface)) {
                 auto sphere = [&](double& cx, double& cy, double& cz) {
                     cx = 0.5 * (clo[0] + chi[0]); cy = 0.5 * (clo[1] + chi[1]); cz = 0.5 * (clo[2] + chi[2]);
                     const double hx = 0.5 * (chi[0] - clo[0]), hy = 0.5 * (chi[1] - clo[1]), hz = 0.5 * (chi[2] - clo[2]);
@@ -467,10 +493,10 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                     const double coef = std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(dd) + std::fabs(e) + std::fabs(f);
                     const double far = RT_QUADRIC_FAR;
                     for (int pass = 0; pass < 3 && ok; pass++) {     // the fattened piece is larger, which raises tau a little: iterate
-                        const double reach = 2.0 * (far + rad) + 3.0 * std::sqrt((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2])) + 1.0;
+                        const double reach = 2.0 * (far + rad) + 3.0 * std::sqrt(cx * cx + cy * cy + cz * cz) + 1.0;
                         const double tau = 64.0 / 16777216.0 * coef * reach * reach;     // the estimate above with the rotation into the local frame and
                                                                                  // the solve on top (~22 * 2^-24), times three
-                        ok = quadric_clip_bounds(A, wv, pw, static_cast<double>(f), lo, hi, clo, chi, tau, from_surface);
+                        ok = quadric_clip_bounds(A, wv, pw0, static_cast<double>(f), lo, hi, clo, chi, tau, from_surface);
                         if (ok) rad = sphere(cx, cy, cz);
                     }
                     far2 = far * far;
@@ -482,10 +508,10 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                     double tight = rad, tc[3] = {cx, cy, cz};
                     if (rad < 1.0e6) {
                         QuadricCells cells;
-                        for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) cells.A[r][q] = A[r][q]; cells.w[r] = wv[r]; cells.p[r] = pw[r]; }
+                        for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) cells.A[r][q] = A[r][q]; cells.w[r] = wv[r]; cells.p[r] = 0.0; }
                         cells.f = f;
                         const double coef = std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(dd) + std::fabs(e) + std::fabs(f);
-                        const double reach = 2.0 * (RT_QUADRIC_FAR + rad) + 3.0 * std::sqrt((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2])) + 1.0;
+                        const double reach = 2.0 * (RT_QUADRIC_FAR + rad) + 3.0 * std::sqrt(cx * cx + cy * cy + cz * cz) + 1.0;
                         cells.tau = 64.0 / 16777216.0 * coef * reach * reach;     // as above: what the float evaluation can mistake for the surface
                         if (from_surface) cells.descend(clo, chi, 3);     // the leaves choose the centre; the radius is refined below
                         if (!cells.may_hold(clo, chi) || (from_surface && cells.leaves.empty())) {
@@ -500,20 +526,23 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                         }
                     }
                     if (!(tight == tight)) tight = rad;
-                    sc.bound = mk4(static_cast<float>(tc[0]), static_cast<float>(tc[1]), static_cast<float>(tc[2]), static_cast<float>(tight * tight * (1.0 + 1e-6)));
-                    sc.sym1.w = from_surface ? std::numeric_limits<float>::quiet_NaN() : static_cast<float>(rad * rad);
+                    fresh.has = true;
+                    for (int k = 0; k < 3; k++) { fresh.c[k] = tc[k]; fresh.aabb[k] = clo[k]; fresh.aabb[3 + k] = chi[k]; }
+                    fresh.tight2 = tight * tight * (1.0 + 1e-6);
+                    fresh.far_w = from_surface ? std::numeric_limits<double>::quiet_NaN() : rad * rad;
                     (void)far2;
-                    for (int k = 0; k < 3; k++) { surf_aabb[i * 6 + k] = clo[k]; surf_aabb[i * 6 + 3 + k] = chi[k]; }
+                    sc.bound = mk4(static_cast<float>(tc[0] + pw_abs[0]), static_cast<float>(tc[1] + pw_abs[1]), static_cast<float>(tc[2] + pw_abs[2]), static_cast<float>(fresh.tight2));
+                    sc.sym1.w = static_cast<float>(fresh.far_w);
+                    for (int k = 0; k < 6; k++) surf_aabb[i * 6 + k] = fresh.aabb[k] + pw_abs[k % 3];
                 }
             }
             if (!cached) {
-                CachedBounds cb;
-                cb.bound = sc.bound;
-                cb.far_w = sc.sym1.w;
-                for (int k = 0; k < 6; k++) cb.aabb[k] = surf_aabb[i * 6 + k];
                 std::lock_guard<std::mutex> g(cache_mu);
-                if (cache.size() > 4096) cache.clear();
-                cache.emplace(cache_key, cb);
+                if (cache.size() >= 4096) {       // drop half, not all: no frame pays for every quadric at once
+                    size_t n = 0;
+                    for (auto it = cache.begin(); it != cache.end();) { if ((n++ & 1u) == 0u) it = cache.erase(it); else ++it; }
+                }
+                cache.emplace(cache_key, fresh);
             }
         }
         std::memcpy(reinterpret_cast<DevSurface*>(blob.data() + h.off_surface) + i, &s, sizeof s);

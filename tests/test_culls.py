@@ -359,3 +359,143 @@ def test_candidate_tables_in_bulk(built, case):
     assert r["violations"] == 0, r
     n_prims = sc.defines[2] + sc.defines[4]
     assert r["hits"] > 2000 and r["mean_bits"] < 0.6 * n_prims, (r, n_prims)     # the rays do hit things, and the masks do prune
+
+
+def _surface_bound(rec):
+    import ctypes
+    L = harness.lib()
+    L.harness_surface_bound.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    out = (ctypes.c_float * 5)()
+    assert L.harness_surface_bound(ctypes.create_string_buffer(rec, len(rec)), out) == 0
+    return list(out)
+
+
+def test_quadric_bounds_follow_a_moving_quadric_and_come_from_the_cache(built):
+    """the bounds cache was keyed on the whole 160-byte record, so a quadric that moves or changes its material between
+    two frames -- the reference re-uploads every block every frame, main.cpp:246 -- paid 0.1-0.5 ms of branch and bound inside rtx_draw, per
+    quadric and frame. The bounds are translation-covariant: they are computed relative to the position and keyed without position and
+    material. Checked: (1) the bound of a moved quadric is the moved bound; (2) re-packing 96 moved + re-coloured quadrics costs what a
+    cache hit costs."""
+    import time
+    from scene_util import material, surface
+    rng = np.random.default_rng(3)
+    recs = []
+    for k in range(96):      # the six quadric types of configs[2], rotated, closed and half-open clip boxes
+        coef = [dict(a=1, b=1, c=1, f=-0.4), dict(a=4, b=4, c=-1), dict(a=4, b=4, f=-1), dict(a=1.5, b=1.5, d=-1), dict(a=1.5, b=-1.5, d=-1), dict(a=4, b=4, c=-1, f=-1)][k % 6]
+        recs.append((coef, _rand_quat_tuple(rng), k % 5 == 0))
+
+    def build(shift, color):
+        out = []
+        for k, (coef, q, open_y) in enumerate(recs):
+            p = np.array([k % 10 * 3.0, k // 10 * 3.0, 16.0]) + shift
+            if open_y:
+                clip = dict(vmin=(-3.0e38, p[1] - 1.0, -3.0e38), vmax=(3.0e38, p[1] + 1.0, 3.0e38))
+            else:
+                clip = dict(vmin=tuple(p - 1.2), vmax=tuple(p + 1.2))
+            out.append(surface(tuple(p), material(color, 10, 0.1), quat=q, **coef, **clip))
+        return out
+
+    first = build(np.zeros(3), (0.5, 0.5, 0.5))
+    t0 = time.perf_counter()
+    b0 = [_surface_bound(r) for r in first]
+    t_cold = time.perf_counter() - t0
+    shift = np.array([0.37, -1.25, 2.5])
+    moved = build(shift, (0.9, 0.1, 0.2))
+    t0 = time.perf_counter()
+    b1 = [_surface_bound(r) for r in moved]
+    t_moved = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    b2 = [_surface_bound(r) for r in moved]
+    t_same = time.perf_counter() - t0
+    for k, (u, v) in enumerate(zip(b0, b1)):
+        assert (u[3] < 0) == (v[3] < 0), k
+        if u[3] >= 0:
+            assert np.allclose(np.array(v[:3]) - np.array(u[:3]), shift, atol=2e-5), (k, u, v)
+            assert abs(v[3] - u[3]) <= 1e-5 * max(1.0, u[3]) and v[4] == u[4], (k, u, v)
+    assert b1 == b2
+    # a moved, re-coloured quadric must cost what an unchanged one costs (both are cache hits), and far less than the first pack
+    assert t_moved < 3.0 * t_same + 0.01, (t_cold, t_moved, t_same)
+    assert t_moved < 0.5 * t_cold, (t_cold, t_moved, t_same)
+
+
+def _rand_quat_tuple(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return tuple(float(np.float32(v)) for v in q)
+
+
+def test_hull_cull_stands_aside_for_infinite_and_overflowing_origins(built):
+    """tori that are never culled (zero tube, non-unit quaternion) carry cull.y = +inf, and an origin beyond ~1.8e19 -- they
+    follow a degenerate-quadric 'hit' with a huge t, trap T4 -- overflows the hull test's w2 to +inf as well: `inf >= inf` culled a torus
+    that must never be culled. Now: never culled, whatever the origin; and a cullable torus seen from such an origin is not culled by an
+    overflowed comparison either (cull decision False or a NaN-free miss of the literal solver)."""
+    from scene_util import material, torus
+    never = [torus((0.0, 0.0, 0.0), 1.0, 0.0, material((1, 1, 1), 0, 0)),                                   # zero tube
+             torus((0.0, 0.0, 0.0), 1.0, 0.3, material((1, 1, 1), 0, 0), quat=(0.0, 0.0, 0.0, 0.9))]        # non-unit quaternion
+    for rec in never:
+        for ro in [(3.0e19, 0.0, 0.0), (0.0, 0.0, 1.0e30), (float("inf"), 0.0, 0.0), (2.0e19, 2.0e19, 2.0e19), (0.0, 5.0, 0.0)]:
+            for rd in [(1.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 0.6, 0.8)]:
+                hit, t, culled = harness.kat(oracle.TYPE_TORUS, rec, ro, rd)
+                assert not culled, (ro, rd)
+    real = torus((0.0, 0.0, 0.0), 1.0, 0.3, material((1, 1, 1), 0, 0))
+    for ro in [(3.0e19, 0.0, 0.0), (0.0, 0.0, 1.0e30), (float("inf"), 0.0, 0.0)]:
+        for rd in [(1.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, -1.0)]:
+            hit, t, culled = harness.kat(oracle.TYPE_TORUS, real, ro, rd)
+            assert not (culled and hit), (ro, rd)
+
+
+@pytest.mark.parametrize("kind", ["hyperboloid", "cone", "saddle"])
+def test_quadric_cull_in_the_ill_conditioned_regime(built, kind):
+    """the segment-based surface_cull and the tight fattened-surface bound were only exercised with isotropic directions and
+    clip boxes centred on the quadric. The delicate regime: an indefinite quadric, a direction just outside the |p2| margin (the cancelling
+    root of the quadratic is ill-conditioned there), an off-centre or large clip box, an origin inside the box, a finite limit. About 10 000 rays per
+    kind through points of the clip box; the cull must never reject a ray the un-culled intersector hits. (tools/cull_audit.py runs the same
+    regime at 1e10 rays on the GPU.)"""
+    from scene_util import material, surface
+    rng = np.random.default_rng({"hyperboloid": 1, "cone": 2, "saddle": 3}[kind])
+    coef = {"hyperboloid": dict(a=4, b=4, c=-1, f=-1), "cone": dict(a=4, b=4, c=-1), "saddle": dict(a=1.5, b=-1.5, d=-1)}[kind]
+    bad = checked = culled_n = 0
+    for case in range(30):
+        pos = rng.normal(size=3) * 5.0 + np.array([0.0, 0.0, 12.0])
+        half = float(rng.choice([0.3, 1.0, 3.0, 10.0, 30.0]))
+        off = rng.normal(size=3) * half * 0.8                      # the clip box is NOT centred on the quadric
+        q = _rand_quat_tuple(rng) if rng.random() < 0.7 else (0.0, 0.0, 0.0, 1.0)
+        rec = surface(tuple(pos), material((1, 1, 1), 0, 0), quat=q, vmin=tuple(pos + off - half), vmax=tuple(pos + off + half), **coef)
+        a, b, c = coef.get("a", 0), coef.get("b", 0), coef.get("c", 0)
+        scale = abs(a) + abs(b) + abs(c)
+        qn = np.array(q, np.float64)
+
+        def to_world(v):          # rotate(quat_inv(q), v) for a unit quaternion
+            x, y, z, w = -qn[0], -qn[1], -qn[2], qn[3]
+            u = np.array([x, y, z])
+            return v + 2.0 * np.cross(u, np.cross(u, v) + w * v)
+
+        for _ in range(2000):
+            # a local direction on the asymptotic cone (p2 = 0), then off it until |p2| is in [1e-5, 3e-3] * scale
+            u, v = rng.normal(size=3), rng.normal(size=3)
+            u /= np.linalg.norm(u); v /= np.linalg.norm(v)
+            p2 = lambda w: a * w[0] ** 2 + b * w[1] ** 2 + c * w[2] ** 2
+            if (p2(u) < 0) == (p2(v) < 0):
+                continue
+            for _k in range(40):
+                m = u + v; m /= np.linalg.norm(m)
+                if (p2(m) < 0) == (p2(u) < 0): u = m
+                else: v = m
+            target = scale * 10 ** rng.uniform(-5.0, -2.5)
+            dl = u
+            step = rng.normal(size=3)
+            for s in np.geomspace(1e-7, 0.3, 40):
+                cand = u + step * s; cand /= np.linalg.norm(cand)
+                if abs(p2(cand)) >= target:
+                    dl = cand
+                    break
+            rd = to_world(dl)
+            rd = (rd / np.linalg.norm(rd)).astype(np.float32)
+            through = pos + off + rng.uniform(-1, 1, 3) * half
+            ro = (through - rd * (rng.uniform(0, 1) * half if rng.random() < 0.5 else 10 ** rng.uniform(-1, 3))).astype(np.float32)
+            tmin = 1e6 if rng.random() < 0.3 else float(10 ** rng.uniform(-1, 3))
+            hit, t, culled = harness.kat(oracle.TYPE_SURFACE, rec, tuple(float(x) for x in ro), tuple(float(x) for x in rd), tmin)
+            checked += 1
+            culled_n += culled
+            bad += culled and hit
+    assert checked > 8000 and culled_n > 500 and bad == 0, (checked, culled_n, bad)
