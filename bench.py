@@ -69,6 +69,23 @@ def keep_stdout_for_the_json_line():
         os.dup2(2, 1)
 
 
+CLOCK_RAMP_MS = 150.0
+
+
+def clock_ramp(draw, finish):
+    """Untimed: keep the device busy with the bench's own draws for CLOCK_RAMP_MS before the warm-up, so that the shader clock has settled when
+    the W warm-up steps start (round 3's timed region was 10 ms after 2.5 ms of warm-up: the PMC passes ran at 2.29 GHz, the longer kernels
+    at 2.39-2.40). Returns the number of draws and the wall time it took."""
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < CLOCK_RAMP_MS:
+        for _ in range(8):
+            draw()
+        finish()
+        n += 8
+    return n, (time.perf_counter() - t0) * 1e3
+
+
 def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     """N > 1 through the C boundary: one rtx_draw per step on a context that splits the frame itself (rtx_create_multi in one process,
     rtx_create_rank in one process per GPU). Timed exactly like the single-GPU line: W warm-up draws, barrier + finish, K draws, finish +
@@ -111,6 +128,7 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     gl.set_option(wrapper.RTX_OPT_SCENE_LDS, args.lds)
     gl.set_option(wrapper.RTX_OPT_XCD_REMAP, args.xcd)
     gl.set_option(wrapper.RTX_OPT_RAY_PENCILS, args.pencils)
+    gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, {"interleaved": 0, "contiguous": 1, "balanced": 1}[args.bands])
 
     # exact reference-defined ray count of the frame (untimed, counting kernel variant; summed over the ranks)
     gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
@@ -120,24 +138,86 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     rays_frame, rays_cast_frame = (int(v) for v in reduce_([st["rays_closest"] + st["rays_shadow"], st["rays_closest"] + st["rays_shadow_cast"]], dist.ReduceOp.SUM))
     gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 0)
 
+    def rank_ms():
+        """every rank's kernel time of its last launch, in rank order (all of them known to this process, or gathered over the rendezvous)"""
+        ms = gl.rank_draw_ms()
+        return ranks.gather_values(ms[rank]) if multi_proc else [float(v) for v in ms]
+
+    def timed(steps):
+        """`steps` draws bracketed like the contract says (barrier + finish on both sides); -> (seconds, slowest rank's mean kernel ms, gather ms)"""
+        gl.finish()
+        gl.stats()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gl.draw()
+        gl.finish()   # every device's launch and transfer streams, incl. the placement of the last frame on rank 0
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        n_ev = min(steps, 128)
+        tr = gl.sum_recent_draw_ms(n_ev) / n_ev     # HIP events on the launch streams; the slowest rank of this process
+        gms = gl.stats()["last_gather_ms"]
+        dt, tr = reduce_([dt, tr], dist.ReduceOp.MAX)
+        return dt, tr, gms
+
+    def balance(rounds=6):
+        """contiguous bands weighted by measured kernel time: a few frames with the split in use, every rank's time, the new split -- the same
+        arithmetic on every rank (bands.weighted_split), so a per-process group agrees without any further exchange"""
+        for _ in range(rounds):
+            for _ in range(3):
+                gl.draw()
+            gl.finish()
+            rows = gl.band_split()
+            ms = rank_ms()
+            if max(ms) <= 1.04 * min(ms):
+                break
+            gl.set_band_split(bands.weighted_split(H, rows, ms, damping=0.7))
+        return gl.band_split(), rank_ms()
+
+    ramp_draws, ramp_ms = clock_ramp(gl.draw, gl.finish)
+    if args.bands == "balanced":
+        balance()
     for _ in range(args.warmup):
         gl.draw()
-    gl.finish()
-    gl.stats()   # retire warm-up events
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gl.draw()
-    gl.finish()   # every device's launch and transfer streams, incl. the placement of the last frame on rank 0
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    n_ev = min(args.steps, 128)
-    trace_ms = gl.sum_recent_draw_ms(n_ev) / n_ev   # HIP events on the launch streams; the slowest rank of this process
+    elapsed, trace_ms_max, gather_ms = timed(args.steps)
+    ranks_trace_ms = rank_ms()
+    layout_name = {"interleaved": "interleaved 8-row bands", "contiguous": "contiguous equal ranges", "balanced": "contiguous ranges weighted by kernel time"}[args.bands]
+    split_used = gl.band_split()
     st_end = gl.stats()
-    elapsed, trace_ms_max = reduce_([elapsed, trace_ms], dist.ReduceOp.MAX)
+
+    # Untimed additions to the SAME line (one run on an 8-GPU node is all there may be): the other colour target and the other band layout,
+    # each timed exactly like the value above, with K steps.
+    extras = {}
+    if n_ranks > 1 or args.transport == "loopback":
+        other_target = "rgba8" if target == "rgba32f" else "rgba32f"
+        gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 2 if other_target == "rgba8" else 1)
+        for _ in range(3):
+            gl.draw()
+        e2, t2, g2 = timed(args.steps)
+        extras[other_target] = {"ms_per_step": round(e2 / args.steps * 1e3, 4), "trace_ms_max_rank": round(t2, 4), "gather_ms": round(g2, 4),
+                                "value_Mray_s": round(rays_frame * args.steps / e2 / 1e6, 2)}
+        gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 1 if target == "rgba32f" else 2)
+        for other_layout in ("balanced", "interleaved"):
+            if other_layout == args.bands:
+                continue
+            gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 1 if other_layout == "balanced" else 0)
+            if other_layout == "balanced":
+                bal_split, bal_ms = balance()
+            for _ in range(3):
+                gl.draw()
+            e3, t3, g3 = timed(args.steps)
+            extras["bands_" + other_layout] = {"ms_per_step": round(e3 / args.steps * 1e3, 4), "trace_ms_max_rank": round(t3, 4), "gather_ms": round(g3, 4),
+                                               "value_Mray_s": round(rays_frame * args.steps / e3 / 1e6, 2), "rows_per_rank": gl.band_split(),
+                                               "trace_ms_per_rank": [round(v, 4) for v in rank_ms()]}
+            break
+        # back to the configuration the value was measured with (the parity check below reads its frame)
+        gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, {"interleaved": 0, "contiguous": 1, "balanced": 1}[args.bands])
+        if args.bands != "interleaved":
+            gl.set_band_split(split_used)
+        gl.draw()
+        gl.finish()
     if rank != 0:
         gl.stop()
         return
@@ -153,9 +233,10 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     one.stop()
     same = bool(np.array_equal(got.view(np.uint32 if target == "rgba32f" else np.uint8), want.view(np.uint32 if target == "rgba32f" else np.uint8)))
     ms_per_step = elapsed / args.steps * 1e3
-    rows0 = bands.local_rows(H, 8, 0, n_ranks)
+    rows0 = split_used[0]
     achieved = rows0 * W * px_bytes / (trace_ms_max * 1e-3) / 1e9
-    moved = sum(bands.local_rows(H, 8, r, n_ranks) for r in range(0 if args.transport == "loopback" else 1, n_ranks)) * W * px_bytes
+    moved = sum(split_used[r] for r in range(0 if args.transport == "loopback" else 1, n_ranks)) * W * px_bytes
+    links = max(1, n_ranks - 1)
     out = {
         "metric": f"Mray/s at {W}x{H} depth-{args.depth} {args.scene} scene (reference-defined rays: closest-hit + shadow scans)",
         "value": round(rays_frame * args.steps / elapsed / 1e6, 2),
@@ -172,16 +253,19 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
         "config": {"workload": f"{args.scene} scene (reference main.cpp:43-132, t=0), {W}x{H}, reflection depth {args.depth}, "
                                f"{target.upper()} target, seeded synthetic textures at reference sizes/{args.texture_scale}",
                    "rays_per_frame": rays_frame, "rays_executed_per_frame": rays_cast_frame,
-                   "parallelism": f"{n_ranks} GPU{'s' if n_ranks > 1 else ''}, interleaved 8-row bands, one rtx_draw per frame on "
+                   "parallelism": f"{n_ranks} GPU{'s' if n_ranks > 1 else ''}, {layout_name}, one rtx_draw per frame on "
                                   + ("one rtx_create_rank context per process" if per_process else "one rtx_create_multi context")
                                   + f", gather of the {target.upper()} frame to rank 0",
                    "launcher": "torch.distributed.run, one process per GPU" if per_process else "one process, N devices",
                    "transport": {"rccl": "RCCL: grouped ncclSend/ncclRecv, every peer straight to rank 0 (librtx_hip.so)",
                                  "loopback": "RCCL incl. rank 0 -> rank 0 (diagnostic)",
                                  "peer": "hipMemcpyPeerAsync issued by rank 0 (librtx_hip.so)"}[args.transport],
-                   "trace_ms_max_rank": round(trace_ms_max, 4), "gather_ms": round(st_end["last_gather_ms"], 4),
-                   "gather_bytes_per_frame": int(moved),
-                   "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd},
+                   "trace_ms_max_rank": round(trace_ms_max, 4), "trace_ms_per_rank": [round(v, 4) for v in ranks_trace_ms], "rows_per_rank": split_used,
+                   "gather_ms": round(gather_ms, 4), "gather_bytes_per_frame": int(moved),
+                   "gather_GB_s_into_rank0": round(moved / max(gather_ms, 1e-6) / 1e6, 1), "gather_GB_s_per_link": round(moved / links / max(gather_ms, 1e-6) / 1e6, 1),
+                   "also_measured": extras,
+                   "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd,
+                   "clock_ramp": {"draws": ramp_draws, "ms": round(ramp_ms, 1), "note": "untimed draws in front of the warm-up"}},
         "ms_per_frame": round(ms_per_step, 4),
         "kernel_ms": round(trace_ms_max, 4),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -216,6 +300,11 @@ def main():
                     help="colour target the bands are traced into and gathered as -- the SAME at every N, so that a 1/2/4/8 series is one "
                          "workload: rgba32f (default) = the 16 B/pixel parity buffer of the BASELINE metric; rgba8 = what the reference's "
                          "framebuffer holds (GLWrapper.cpp:127,209-222), a quarter of the gather traffic")
+    ap.add_argument("--bands", choices=("interleaved", "contiguous", "balanced"), default="interleaved",
+                    help="N > 1: how the frame is split (rtx.h RTX_OPT_BAND_LAYOUT): interleaved 8-row bands (default; landing buffers + a placement "
+                         "pass on rank 0), contiguous = one equal range of rows per rank traced / received straight into place, balanced = contiguous "
+                         "ranges weighted by the ranks' measured kernel times. The line's value is this layout; the other one and the other colour "
+                         "target are measured too and reported under config.also_measured")
     ap.add_argument("--no-smaa", action="store_true", help="skip the untimed SMAA post-process measurement (N = 1)")
     ap.add_argument("--launcher", choices=("auto", "torch"), default="auto",
                     help="N > 1 without torch.distributed.run around it: auto = one process drives the N devices through rtx_create_multi; "
@@ -324,6 +413,12 @@ def main():
         return out
 
     pending = [None, None]
+    ramp_k = [0]
+
+    def ramp_draw():
+        step(ramp_k[0], pending)
+        ramp_k[0] += 1
+    ramp_draws, ramp_ms = clock_ramp(ramp_draw, lambda: (drain(pending), torch.cuda.synchronize(device)))
     for k in range(args.warmup):
         step(k, pending)
     drain(pending)
@@ -375,7 +470,8 @@ def main():
                        "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd,
                        # ray pencils: candidate masks built on the device when the scene changes (not per frame: the bench scene is static,
                        # like its packed tables); build_ms is the cost a scene update adds
-                       "ray_pencils": {"count": st_end["pencils"], "build_ms": round(st_end["last_pencil_build_ms"], 4)}},
+                       "ray_pencils": {"count": st_end["pencils"], "build_ms": round(st_end["last_pencil_build_ms"], 4)},
+                       "clock_ramp": {"draws": ramp_draws, "ms": round(ramp_ms, 1), "note": "untimed draws in front of the warm-up"}},
             "ms_per_frame": round(ms_per_step, 4),
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -410,8 +506,7 @@ def main():
                 cyc = peak["cycles_per_wave_inst_per_simd"]
                 clock = (v.get("shader_clock_GHz") or 2.3) * 1e9
                 val = {"insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1), "unit": "G wave-instructions/s",
-                       "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "valu_pipe_busy_measured": v.get("valu_pipe_busy"),
-                       "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash}
+                       "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash}
                 cls = v.get("classes")
                 if cls:
                     # Mix-weighted issue ceiling: every instruction class at its MEASURED issue cost (cycles per wave-instruction per SIMD,
@@ -428,7 +523,7 @@ def main():
                                 "shader_clock_GHz": v.get("shader_clock_GHz")})
                     val["note"] = ("mix-weighted VALU issue ceiling: per-class instruction counts (rocprofv3 PMC, " + v.get("source", "") + ") x measured issue "
                                    "cycles per class (" + peak.get("source", "") + "), unnamed classes at the cheapest measured cost, so frac <= 1 by "
-                                   "construction; duration live; valu_pipe_busy_measured is SQ_ACTIVE_INST_VALU against GRBM_GUI_ACTIVE (nominal units)")
+                                   "construction; duration live")
                 else:
                     val.update({"peak": peak["simple_op_peak_G_per_s"], "frac": round(rate / 1e9 / peak["simple_op_peak_G_per_s"], 4),
                                 "note": "no per-class counts in the profile: peak = the issue rate of an all-v_add stream (a loose ceiling)"})
@@ -437,6 +532,25 @@ def main():
             if t:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / float(W * H * px_bytes), 3)
+        if world == 1 and args.scene == "default":
+            # The reference animates every frame (main.cpp:197-246: update_scene + an update_buffer of every block); the line above times the
+            # t = 0 frame. Untimed addition: the kernel time of the same workload at other animation times, blocks re-uploaded like the
+            # reference does (SceneUploader.update), 10 launches each.
+            anim = {}
+            for tt in (0.0, 1.0, 3.0, 7.5, 12.5):
+                gl.uploader.update(scenes.build_scene(args.scene, W, H, args.depth, time=tt, delta=tt))
+                for _ in range(3):
+                    gl.draw()
+                gl.finish()
+                gl.stats()
+                for _ in range(10):
+                    gl.draw()
+                gl.finish()
+                anim[f"t={tt:g}"] = round(gl.sum_recent_draw_ms(10) / 10, 4)
+            gl.uploader.update(sc)
+            out["animated"] = {"kernel_ms_per_frame": anim, "mean_ms": round(sum(anim.values()) / len(anim), 4),
+                               "note": "default scene at animation times t (update_scene of main.cpp:197-246 with time = deltaTime = t, every block "
+                                       "re-uploaded); value / ms_per_step above are the t = 0 frame"}
         if world == 1 and not args.no_smaa:
             # the post-process that follows the tracer in the reference's draw(). Untimed addition to the line: ULTRA (main.cpp:32)
             # on the frame just traced, HIP events around the four kernels of one resolve. Algorithmic bytes: W*H*4 read + W*H*4 written.

@@ -89,6 +89,13 @@ typedef enum rtx_option {
                                 camera rays by direction, shadow rays by direction from a point light or by position across a directional
                                 light -- built on the device whenever the scene changes; scans of such rays walk the wave's candidates
                                 instead of the whole table. 0: two-level scans only. Same results. */
+    RTX_OPT_BAND_LAYOUT = 9,  /* multi-device contexts: how the frame is split over the ranks. 0 (default): interleaved 8-row bands (band b -> rank
+                                b mod N: sky and object rows alternate between the ranks; the root receives into landing buffers and a copy
+                                kernel puts the bands in place). 1: ONE contiguous range of rows per rank (rtx_set_band_split; equal ranges
+                                until it is called): the root traces its range straight into the colour targets and receives the others
+                                straight into place -- no landing buffers, no placement pass. 2: as 1, and the library moves the boundaries
+                                towards equal kernel times (rates of two frames back; single-process contexts only). Same pixels in every
+                                layout. A per-process group (rtx_create_rank) must set the same value on every rank. */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which build of the trace kernel runs: 0 = the default one, 1 = the many-primitive one (group culls, ray
                                 pencils and slab tables compiled in; its own register budget -- 7 waves/SIMD in round 1, hence the
                                 name, 6 now), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
@@ -235,6 +242,15 @@ RTX_API int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host,
 RTX_API int rtx_read_pixels(rtx_context* ctx, int format, void* dst_host, size_t dst_bytes);
 /* Device pointer of the colour target (W*H pixels of `format`), for zero-copy consumers. */
 RTX_API int rtx_framebuffer_device(rtx_context* ctx, int format, void** device_ptr);
+/* Contiguous bands (RTX_OPT_BAND_LAYOUT 1): rank r traces rows_per_rank[r] rows, in rank order from row 0 (the bottom row). Every count
+ * but the last non-zero one must be a multiple of 8 (the kernel's tile height) and together they must cover the frame. Switches layout 0
+ * to 1. In a per-process group every rank must make the same call with the same numbers (the launcher has them from rtx_get_rank_draw_ms
+ * of the warm-up frames, say). rtx_get_band_split reports the split in use (any layout: rows per rank). */
+RTX_API int rtx_set_band_split(rtx_context* ctx, const int* rows_per_rank, int n_ranks);
+RTX_API int rtx_get_band_split(rtx_context* ctx, int* rows_per_rank, int n_ranks);
+/* Kernel time (HIP events, ms) of every rank's last finished trace launch: all ranks of a single-process context; in a per-process
+ * group only the caller's own entry (the others are -1). Waits for the launches issued so far. */
+RTX_API int rtx_get_rank_draw_ms(rtx_context* ctx, float* ms_per_rank, int n_ranks);
 RTX_API int rtx_get_stats(rtx_context* ctx, rtx_stats* out);
 /* rtx_stats is append-only and has grown (last_smaa_ms and everything behind it came after round 1): rtx_get_stats writes sizeof(rtx_stats)
  * of THIS header. A caller built against an older header -- or one that wants to stay binary compatible with newer libraries -- passes the

@@ -111,3 +111,36 @@ class FrameGather:
         if self.rank != self.dst:
             return None
         return unpermute(self.recv_all[slot & 1], self.height, self.band_rows, self.world)
+
+
+def weighted_split(height: int, rows_now, ms_now, damping: float = 1.0):
+    """Contiguous bands (rtx.h RTX_OPT_BAND_LAYOUT 1, rtx_set_band_split): the rows each rank should trace so that the ranks' kernel times
+    come out equal, from the split in use and the kernel time each rank measured with it. rate_r = rows_r / ms_r; the new share is
+    proportional to the rate (moved `damping` of the way), in units of 8 rows (the kernel's tile height), at least one unit per rank,
+    the last rank taking what is left of a frame whose height is not a multiple of 8. Pure arithmetic: every rank of a per-process group
+    computes the same split from the same gathered numbers (bench.py, tests/test_bands_gloo.py)."""
+    n = len(rows_now)
+    units = (height + 7) // 8
+    if n < 1 or len(ms_now) != n or units < n:
+        raise ValueError("weighted_split: need one time per rank and at least one 8-row unit per rank")
+    rates = [(r / m) if (m > 0 and r > 0) else 0.0 for r, m in zip(rows_now, ms_now)]
+    total = sum(rates)
+    if total <= 0:
+        rates, total = [1.0] * n, float(n)
+    u = []
+    for r, rate in zip(rows_now, rates):
+        have, want = r / 8.0, units * rate / total
+        u.append(max(1, int(have + damping * (want - have) + 0.5)))
+    k = 0
+    while sum(u) != units:          # rounding: hand the difference round, one unit at a time
+        if sum(u) < units:
+            u[k % n] += 1
+        elif u[k % n] > 1:
+            u[k % n] -= 1
+        k += 1
+    rows, y = [], 0
+    for v in u:
+        take = min(v * 8, height - y)
+        rows.append(take)
+        y += take
+    return rows

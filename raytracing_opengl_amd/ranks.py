@@ -36,3 +36,12 @@ def reduce_values(values, op="max") -> list:
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+def gather_values(value: float) -> list:
+    """Every rank's number, in rank order, on every rank."""
+    if world_size() == 1:
+        return [float(value)]
+    out = [torch.zeros(1, dtype=torch.float64) for _ in range(world_size())]
+    dist.all_gather(out, torch.tensor([float(value)], dtype=torch.float64))
+    return [float(t[0]) for t in out]

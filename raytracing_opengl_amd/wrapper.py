@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from ._capi import (RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL, RTX_GATHER_RCCL_LOOPBACK, RTX_OPT_GATHER_TARGETS, RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_RAY_PENCILS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
+from ._capi import (RTX_OPT_BAND_LAYOUT, RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL, RTX_GATHER_RCCL_LOOPBACK, RTX_OPT_GATHER_TARGETS, RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_RAY_PENCILS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
                     RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_HIGH, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_OFF, RTX_SMAA_ULTRA, RTX_SMAA_WEIGHTS_RGBA8,
                     RTX_WRAP_CLAMP_TO_EDGE, RTX_WRAP_REPEAT)
 
@@ -193,6 +193,28 @@ class GLWrapper:
         s = _capi.Stats()
         _check(self._lib.rtx_get_stats(self._ctx, ctypes.byref(s)), "stats")
         return {n: getattr(s, n) for n, _t in _capi.Stats._fields_}
+
+    # --- multi-device: how the frame is split (rtx.h RTX_OPT_BAND_LAYOUT) ---------------------------
+    def n_ranks(self) -> int:
+        n = ctypes.c_int()
+        _check(self._lib.rtx_device_count(self._ctx, ctypes.byref(n)), "device_count")
+        return n.value
+
+    def set_band_split(self, rows_per_rank):
+        arr = (ctypes.c_int * len(rows_per_rank))(*[int(v) for v in rows_per_rank])
+        _check(self._lib.rtx_set_band_split(self._ctx, arr, len(rows_per_rank)), "set_band_split")
+
+    def band_split(self):
+        n = self.n_ranks()
+        arr = (ctypes.c_int * n)()
+        _check(self._lib.rtx_get_band_split(self._ctx, arr, n), "get_band_split")
+        return list(arr)
+
+    def rank_draw_ms(self):
+        n = self.n_ranks()
+        arr = (ctypes.c_float * n)()
+        _check(self._lib.rtx_get_rank_draw_ms(self._ctx, arr, n), "get_rank_draw_ms")
+        return list(arr)
 
     def sum_recent_draw_ms(self, n: int) -> float:
         v = ctypes.c_float()

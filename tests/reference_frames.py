@@ -62,6 +62,11 @@ CASES = {
     # quarter of its size, two animation times
     "app_default_t3": (lambda: _strip_textures(scenes.build_scene("default", 320, 180, 5, time=3.0, delta=0.016)), False, (0.004, 0.0006)),
     "app_default_t7_5": (lambda: _strip_textures(scenes.build_scene("default", 320, 180, 5, time=7.5, delta=0.016)), False, (0.004, 0.0006)),
+    # ---- round 4: the two configurations the reference itself is run at, at their FULL size and as the reference runs them (textured,
+    # glGenerateMipmap): BASELINE configs[0] (640 x 480, depth 1, the animated scene at t = 12.5 under the yaw 25 / pitch 10 camera) and the
+    # reference's own program (main.cpp:7-8: 1280 x 720; SceneManager.cpp:233: reflect_depth 5) at animation time t = 3
+    "config0_full": (lambda: scenes.build_scene("default", 640, 480, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0), True, (0.10, 0.012)),
+    "app_default_full": (lambda: scenes.build_scene("default", 1280, 720, 5, time=3.0, delta=0.016), True, (0.10, 0.012)),
     # a moved and rotated camera (SceneManager.cpp:43-50: quat(vec3(radians(-pitch), radians(yaw), 0)))
     "moved_camera": (lambda: _strip_textures(scenes.build_scene("default", W, H, 4, time=1.25, delta=0.016, yaw=-38.0, pitch=-14.0, cam_pos=(2.5, 1.5, -6.0))), False, (0.004, 0.0006)),
 }
@@ -77,7 +82,8 @@ def _fuzz(seed):
 
 for _s in FUZZ_SEEDS:
     CASES[f"fuzz_{_s}"] = ((lambda s=_s: _fuzz(s)), False, (0.02, 0.004))
-SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180)}
+SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180),
+         "config0_full": (640, 480), "app_default_full": (1280, 720)}
 SIZES.update({f"fuzz_{_s}": FUZZ_SIZE for _s in FUZZ_SEEDS})
 
 
@@ -96,6 +102,9 @@ SAME_MIPS = ("default_same_mips", 0.025, 0.008)   # name, max fraction > 1e-4, >
 #   <case>_level0    : GL was given level 0 only (GL_TEXTURE_MAX_LEVEL = 0) -> compared with the oracle at texture_lod = 0
 TEXTURED = ("default", "trap_degenerate_rings")     # pinned three ways (variants below)
 TEXTURED_PLAIN_ONLY = ("config0",)                  # textured, plain run only (with llvmpipe's generated mip levels stored)
+FULL_SIZE = ("config0_full", "app_default_full")    # textured, plain run only, at the configuration's own size: the pixel-by-pixel accounting of
+                                                    # these runs on the GPU box (GPU_PLAN; its host has the cores for the oracle's probes), the
+                                                    # CPU suite holds the oracle to their limits only
 # fixtures that also hold what the FIRST calcInter of every pixel returned in the reference's shader (t, type, num): instrumented run
 PRIMARY_HITS = ("torus", "default_untextured")
 VARIANTS = {f"{c}_{v}": (c, v) for c in TEXTURED for v in ("same_mips", "level0")}

@@ -119,7 +119,10 @@ def _rendezvous_worker(rank, world, port, q):
         rays = ranks.reduce_values([1000 + rank, 3], "sum")      # per-rank ray counts -> the frame's
         worst = ranks.reduce_values([0.5 + 0.25 * rank, 2.0 - rank], "max")   # elapsed / trace time: the slowest rank's
         ranks.barrier()
-        q.put((rank, uid, calls, rays, worst))
+        # contiguous bands weighted by kernel time (bench.py --bands balanced): every rank gathers every rank's time and computes the SAME split
+        ms = ranks.gather_values(0.30 if rank == 0 else 0.10)
+        split = bands.weighted_split(1080, [544, 536], ms)
+        q.put((rank, uid, calls, rays, worst, ms, split))
     finally:
         dist.destroy_process_group()
 
@@ -140,6 +143,33 @@ def test_rank_rendezvous_hands_the_unique_id_round_and_reduces():
     assert [r[1] for r in results] == [want, want]
     assert results[0][2] == [0] and results[1][2] == []          # the id was created on rank 0 only
     assert all(r[3] == [2001.0, 6.0] and r[4] == [0.75, 2.0] for r in results)
+    assert all(r[5] == [0.30, 0.10] for r in results)            # every rank's time, in rank order, on every rank
+    assert results[0][6] == results[1][6] and sum(results[0][6]) == 1080 and results[0][6][0] < results[0][6][1]
+
+
+def test_weighted_split_is_a_valid_split_whatever_the_times():
+    """bands.weighted_split: ranges in units of 8 rows, at least one unit per rank, together the frame (the last range takes the odd rows);
+    equal times keep an equal split, a slower rank gets fewer rows; and what rtx_set_band_split accepts (rtx_capi.cpp split_set)."""
+    import numpy as np
+    rng = np.random.default_rng(4)
+    for _ in range(500):
+        n = int(rng.integers(1, 9))
+        h = int(rng.integers(8 * n, 5000))
+        rows = bands.weighted_split(h, [h // n] * n, [1.0] * n)
+        ms = list(rng.uniform(0.01, 3.0, n))
+        for damping in (1.0, 0.5):
+            new = bands.weighted_split(h, rows, ms, damping)
+            assert sum(new) == h and len(new) == n and all(v >= 1 for v in new), (h, rows, ms, new)
+            assert all(v % 8 == 0 for v in new[:-1]) and all(v >= 8 for v in new[:-1]), new
+    assert bands.weighted_split(2160, [544, 536, 544, 536], [1.0, 1.0, 1.0, 1.0]) == [544, 536, 544, 536]
+    slow_first = bands.weighted_split(2160, [544, 536, 544, 536], [3.0, 1.0, 1.0, 1.0])
+    assert slow_first[0] < 300 and sum(slow_first) == 2160
+    assert ranks_identity()
+
+
+def ranks_identity():
+    from raytracing_opengl_amd import ranks
+    return ranks.gather_values(0.25) == [0.25]
 
 
 def test_rank_rendezvous_on_one_rank_is_the_identity():

@@ -1,9 +1,12 @@
 """Random scenes (tests/random_scenes.py): the product's device code must reproduce the oracle -- bit for bit on the host
 build (level-0 textures, culls on and off), within 1e-4 with identical ray counts on the GPU (reference texture state)."""
+import os
+
 import numpy as np
 import pytest
 
 import harness
+import parity_bar
 import random_scenes
 from oracle import oracle
 
@@ -130,20 +133,19 @@ def test_scaled_quaternion_scene_on_gpu(built, small_textures, seed):
     img = gl.read_pixels()
     st = gl.stats()
     gl.stop()
-    fin = np.isfinite(img) & np.isfinite(ref)
-    assert (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all(), seed
-    with np.errstate(invalid="ignore", over="ignore"):       # non-unit quaternions scale normals: pixels can reach 1e13 -> relative above 1
-        assert float((np.abs(np.where(fin, img - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()) <= 1e-4, seed
+    v = parity_bar.judge(img, ref)      # absolute 1e-4 where |oracle| <= 1; non-unit quaternions scale normals: pixels can reach 1e13 -> relative above 1
+    assert v["ok"], (seed, v)
     assert st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"], seed
 
 
-SWEEP = 500   # seeds per generator in the -m gpu suite (milliseconds each; tools/fuzz_gpu.py runs the 10^4-scale sweeps)
+SWEEP = 150   # seeds per generator in the -m gpu suite (0.18 s each, nearly all of it the oracle on the box's host: round 3's 500 were 277 s of the
+              # suite's 495, against a 1 200 s budget for everything the driver runs; tools/fuzz_gpu.py runs the 10^4-scale sweeps)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gen", ["random_scene", "nasty_scene", "scaled_quat_scene", "crowd_scene", "pencil_scene"])
 def test_fuzz_sweep_on_gpu(built, small_textures, gen):
-    """500 seeds of each generator through ONE context per frame size (re-specialised per scene, as a program that swaps scenes
+    """150 seeds of each generator (80 of the long-table ones) through ONE context per frame size (re-specialised per scene, as a program that swaps scenes
     would): culls on against the un-culled oracle -- max 1e-4, NaN/inf in the same places, identical ray counts (counting variant of the
     kernel: first-level culls); then the product variant (no counters; group culls and ray pencils where the scene has long tables)
     must reproduce the counting variant's frame bit for bit."""
@@ -152,6 +154,7 @@ def test_fuzz_sweep_on_gpu(built, small_textures, gen):
     sizes = [(96, 64), (97, 65)]
     ctx = {}
     bad = []
+    tally = dict(needed_relative=0, above_one=0, values=0)
     long_tables = gen in ("crowd_scene", "pencil_scene")
     for seed in range(20000, 20000 + (80 if long_tables else SWEEP)):   # long tables: ~30x the oracle time each
         w, h = sizes[seed % 2]
@@ -171,14 +174,21 @@ def test_fuzz_sweep_on_gpu(built, small_textures, gen):
         gl.set_option(wrapper.RTX_OPT_COUNT_RAYS, 0)
         gl.draw()
         product = gl.read_pixels()
-        fin = np.isfinite(img) & np.isfinite(ref)
-        ok = (np.isnan(img) == np.isnan(ref)).all() and (np.isinf(img) == np.isinf(ref)).all()
-        with np.errstate(invalid="ignore", over="ignore"):   # 1e-4 on colours; relative to the pixel where a degenerate scene's values exceed 1
-            ok = ok and float((np.abs(np.where(fin, img - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()) <= 1e-4
+        v = parity_bar.judge(img, ref)   # absolute 1e-4 on colours up to 1; relative to the pixel where a degenerate scene's values exceed 1
+        ok = v["ok"]
+        for k in ("needed_relative", "above_one", "values"):
+            tally[k] += v[k]
         ok = ok and st["rays_closest"] == cnt["rays_closest"] and st["rays_shadow"] == cnt["rays_shadow"]
         ok = ok and np.array_equal(product.view(np.uint32), img.view(np.uint32))
         if not ok:
             bad.append(seed)
     for gl in ctx.values():
         gl.stop()
+    # how much of the verdict rests on the relative part of the bar (parity_bar.py): said, and kept with the run's output
+    line = (f"{gen}: {tally['values']} channel values, {tally['above_one']} with |oracle| > 1, of which {tally['needed_relative']} differ by more than 1e-4 absolute "
+            f"(inside 1e-4 relative); everything at or below 1 is within 1e-4 absolute")
+    print(line)
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_bar_tally.txt"), "a") as f:
+        f.write(line + "\n")
     assert not bad, f"{gen}: {len(bad)} scenes differ from the oracle or between kernel variants, seeds {bad[:20]}"

@@ -47,6 +47,89 @@ def test_peer_copy_group_reproduces_the_single_device_frame(small_textures, rank
         assert gst["last_gather_ms"] > 0.0
 
 
+@pytest.mark.parametrize("kind,w,h,depth,ranks", [("default", 640, 360, 4, 4), ("torus", 333, 207, 6, 3), ("quadric", 320, 100, 4, 2)])
+def test_contiguous_bands_reproduce_the_single_device_frame(small_textures, kind, w, h, depth, ranks):
+    """RTX_OPT_BAND_LAYOUT 1 / 2 (round 4): one contiguous range of rows per rank, the root's range traced straight into the colour targets,
+    the others received straight into place (no landing buffers, no placement pass) -- equal ranges, a caller's weighted split
+    (rtx_set_band_split), the library's own re-balancing over a run of frames with scene updates in between, back to interleaved bands:
+    every frame bit-identical to the single device's, both targets, summed ray counters; odd frame heights incl."""
+    seq = [None, scenes.build_scene(kind, w, h, depth, time=3.0, delta=0.1, yaw=20.0), None, scenes.build_scene(kind, w, h, depth, time=6.5, delta=0.1, yaw=-15.0, pitch=4.0), None, None]
+    sc0 = scenes.build_scene(kind, w, h, depth)
+    single = wrapper.make_renderer(sc0, w, h, small_textures["textures"], small_textures["cubemap"])
+    single.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    want = _frames(single, seq)
+    single.stop()
+
+    def check(group, tag):
+        got = _frames(group, seq)
+        for k, ((f32, u8, st), (g32, g8, gst)) in enumerate(zip(want, got)):
+            assert np.array_equal(f32.view(np.uint32), g32.view(np.uint32)), (tag, k, int((f32.view(np.uint32) != g32.view(np.uint32)).sum()))
+            assert np.array_equal(u8, g8), (tag, k)
+            assert (st["rays_closest"], st["rays_shadow"]) == (gst["rays_closest"], gst["rays_shadow"]), (tag, k)
+        group.uploader.update(sc0)
+
+    group = wrapper.make_renderer(sc0, w, h, small_textures["textures"], small_textures["cubemap"], devices=[0] * ranks, gather=wrapper.RTX_GATHER_PEER_COPY)
+    group.set_option(wrapper.RTX_OPT_COUNT_RAYS, 1)
+    group.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 1)
+    split = group.band_split()
+    assert sum(split) == h and all(v % 8 == 0 for v in split[:-1]) and len(split) == ranks, split
+    check(group, "equal ranges")
+    # a weighted split: most of the frame to the last rank, one tile row to the first
+    units = (h + 7) // 8
+    rows = [8] * (ranks - 1)
+    rows.append(h - sum(rows))
+    assert rows[-1] > 0 and units >= ranks
+    group.set_band_split(rows)
+    assert group.band_split() == rows
+    check(group, "weighted split")
+    with pytest.raises(wrapper.RtxError, match="multiple of 8|cover"):
+        group.set_band_split([5] + [h - 5] + [0] * (ranks - 2))
+    with pytest.raises(wrapper.RtxError, match="cover"):
+        group.set_band_split([8] * ranks)
+    # the library's own re-balancing: more frames than it needs to move the boundaries, scene updates in between
+    group.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 2)
+    before = group.band_split()
+    for _ in range(3):
+        check(group, "re-balanced")
+    after = group.band_split()
+    assert sum(after) == h and all(v % 8 == 0 and v >= 8 for v in after[:-1]), after
+    ms = group.rank_draw_ms()
+    assert len(ms) == ranks and all(v > 0 for v in ms), ms
+    group.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 0)
+    check(group, "back to interleaved bands")
+    group.stop()
+    print(f"{kind} {w}x{h} over {ranks} ranks: split {before} -> {after} after re-balancing, rank kernel ms {['%.3f' % v for v in ms]}")
+
+
+def test_contiguous_bands_over_the_rccl_transport_and_with_smaa(small_textures):
+    """The same layout through RCCL (loopback: the root's own range travels too and is received in place) in both launch forms, with the
+    SMAA resolve on the assembled frame."""
+    w, h, depth = 480, 272, 4
+    sc = scenes.build_scene("default", w, h, depth)
+    tables = smaa_tables.area_table(), smaa_tables.search_table()
+    single = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    single.enable_SMAA("ULTRA")
+    single.set_smaa_tables(*tables)
+    single.draw()
+    want32, want8, want_screen = single.read_pixels(wrapper.RTX_RGBA32F), single.read_pixels(wrapper.RTX_RGBA8), single.read_pixels(wrapper.RTX_SCREEN_RGBA8)
+    single.stop()
+    uid = wrapper.rccl_unique_id()
+    for kw in (dict(devices=[0], gather=wrapper.RTX_GATHER_RCCL_LOOPBACK), dict(gather=wrapper.RTX_GATHER_RCCL_LOOPBACK, rank=(0, 1, uid))):
+        g = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"], **kw)
+        g.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 1)
+        g.enable_SMAA("ULTRA")
+        g.set_smaa_tables(*tables)
+        for _ in range(3):
+            g.draw()
+        assert np.array_equal(g.read_pixels(wrapper.RTX_RGBA32F).view(np.uint32), want32.view(np.uint32))
+        assert np.array_equal(g.read_pixels(wrapper.RTX_RGBA8), want8)
+        assert np.array_equal(g.read_pixels(wrapper.RTX_SCREEN_RGBA8), want_screen)
+        if "rank" in kw:
+            with pytest.raises(wrapper.RtxError, match="one process"):
+                g.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 2)
+        g.stop()
+
+
 def test_group_with_smaa_and_target_selection(small_textures):
     w, h = 480, 272
     sc = scenes.build_scene("default", w, h, 4)
@@ -186,6 +269,15 @@ def test_bench_multi_gpu_forms_run_through_the_c_boundary():
     assert r.returncode == 0 and line, r.stderr[-2000:]
     assert line["n_gpus"] == 1 and line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical"
     assert "rtx_create_multi" in line["config"]["parallelism"] and line["config"]["gather_ms"] > 0 and line["config"]["trace_ms_max_rank"] > 0
+    # one line carries what a single run on an 8-GPU node has to answer: per-rank kernel times, the split, gather rate, and -- timed like the
+    # value -- the other colour target and the other band layout
+    cfg = line["config"]
+    assert len(cfg["trace_ms_per_rank"]) == 1 and cfg["rows_per_rank"] == [360] and cfg["gather_GB_s_into_rank0"] > 0 and cfg["clock_ramp"]["ms"] >= 100
+    also = cfg["also_measured"]
+    assert also["rgba8"]["ms_per_step"] > 0 and also["bands_balanced"]["ms_per_step"] > 0 and sum(also["bands_balanced"]["rows_per_rank"]) == 360
+    r, line = _run_bench(["--gpus", "1", "--transport", "loopback", "--bands", "balanced", "--target", "rgba8"])
+    assert r.returncode == 0 and line and "weighted by kernel time" in line["config"]["parallelism"], r.stderr[-2000:]
+    assert line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical" and "bands_interleaved" in line["config"]["also_measured"]
     r, line = _run_bench(["--gpus", "1", "--transport", "loopback"], torchrun=True)
     assert r.returncode == 0 and line, r.stderr[-2000:]
     assert "rtx_create_rank" in line["config"]["parallelism"] and line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical"

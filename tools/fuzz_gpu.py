@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
+import parity_bar  # noqa: E402
 import random_scenes  # noqa: E402
 from oracle import oracle  # noqa: E402
 from raytracing_opengl_amd import textures, wrapper  # noqa: E402
@@ -22,6 +23,7 @@ def main():
     sizes = [(160, 96), (161, 97), (323, 181), (97, 161), (200, 120)]   # odd sizes: helper invocations, axis-parallel centre rays
     ts = textures.default_texture_set(scale=16)
     worst, bad = 0.0, 0
+    tally = dict(needed_relative=0, above_one=0, values=0)
     ctx = {}   # one context per frame size, re-specialised per scene (creating a context costs ~0.2 s -- 40 GPU-minutes per 10 000 scenes)
     for seed in range(first, first + count):
         w, h = fixed or sizes[seed % len(sizes)]
@@ -44,12 +46,13 @@ def main():
         img_product = gl.read_pixels()
         nan_bad, mx = 0, 0.0
         for im in (img, img_product):
-            nan_bad += int((np.isnan(im) ^ np.isnan(ref)).sum()) + int((np.isinf(im) ^ np.isinf(ref)).sum())
-            fin = np.isfinite(im) & np.isfinite(ref)
-            with np.errstate(invalid="ignore", over="ignore"):
-                # the bar is 1e-4 on colours; a scene whose pixels reach 1e13 (non-unit quaternions scale normals, pow() of values > 1)
-                # is judged relative to the pixel: 1e-4 * max(1, |reference|)
-                mx = max(mx, float((np.abs(np.where(fin, im - ref, 0.0)) / np.maximum(1.0, np.abs(np.where(fin, ref, 0.0)))).max()))
+            # the bar (tests/parity_bar.py): 1e-4 absolute where |oracle| <= 1; a scene whose pixels reach 1e13 (non-unit quaternions scale
+            # normals, pow() of values > 1) is judged relative to the pixel above 1 -- and how many values needed that is counted
+            v = parity_bar.judge(im, ref)
+            nan_bad += v["special_mismatch"]
+            mx = max(mx, v["worst"])
+            for k in tally:
+                tally[k] += v[k]
         # the product variant (group culls, ray pencils) against the counting variant (first-level culls only): bit for bit
         variants_differ = int((img.view(np.uint32) != img_product.view(np.uint32)).any(-1).sum())
         nan_bad += variants_differ
@@ -61,6 +64,8 @@ def main():
         if (seed - first + 1) % 1000 == 0:
             print(f"... {seed - first + 1} scenes, {bad} outside the bar so far, worst {worst:.3e}", flush=True)
     print(f"{os.environ.get('FUZZ_GEN', 'random_scene')}: {count} scenes from seed {first} ({'%dx%d' % fixed if fixed else 'mixed sizes'}): {bad} outside the bar, worst max-abs difference {worst:.3e}")
+    print(f"   the bar: 1e-4 absolute up to |oracle| = 1, relative above: {tally['values']} channel values judged (both kernel variants), {tally['above_one']} above 1, of which "
+          f"{tally['needed_relative']} differ by more than 1e-4 absolute")
 
 
 if __name__ == "__main__":
