@@ -217,6 +217,9 @@ RTX_API int rtx_draw(rtx_context* ctx);
  * context's stream). band_rows must be a multiple of 8. */
 RTX_API int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride,
                            void* dst_device, int format, void* stream);
+/* The same for ONE contiguous range of rows -- a rank's share in the contiguous band layout (RTX_OPT_BAND_LAYOUT 1): rows
+ * [row_first, row_first + n_rows), row_first a multiple of 8, stored from the start of `dst`. */
+RTX_API int rtx_draw_rows(rtx_context* ctx, int row_first, int n_rows, void* dst_device, int format, void* stream);
 RTX_API int rtx_finish(rtx_context* ctx);
 
 /* ---- SMAA post-process: the three passes GLWrapper::draw runs after the tracer (GLWrapper.cpp:173-204) ----

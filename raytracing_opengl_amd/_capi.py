@@ -24,7 +24,7 @@ SYMBOLS = (
     "rtx_last_error", "rtx_version", "rtx_create", "rtx_destroy", "rtx_current", "rtx_make_current", "rtx_get_size",
     "rtx_specialize", "rtx_block_create", "rtx_block_update", "rtx_texture2d_create", "rtx_cubemap_create",
     "rtx_sampler_unit", "rtx_bind_texture", "rtx_texture_destroy", "rtx_set_option", "rtx_get_option", "rtx_draw",
-    "rtx_draw_bands", "rtx_finish", "rtx_read_pixels", "rtx_framebuffer_device", "rtx_get_stats", "rtx_get_stats_sized",
+    "rtx_draw_bands", "rtx_draw_rows", "rtx_finish", "rtx_read_pixels", "rtx_framebuffer_device", "rtx_get_stats", "rtx_get_stats_sized",
     "rtx_sum_recent_draw_ms", "rtx_selftest",
     "rtx_enable_smaa", "rtx_smaa_set_tables", "rtx_smaa_default_tables", "rtx_smaa_resolve", "rtx_write_pixels",
     "rtx_create_multi", "rtx_device_count", "rtx_rank", "rtx_rccl_unique_id", "rtx_create_rank",
@@ -89,6 +89,7 @@ def load():
     lib.rtx_get_option.argtypes = [vp, i, P(i)]
     lib.rtx_draw.argtypes = [vp]
     lib.rtx_draw_bands.argtypes = [vp, i, i, i, vp, i, vp]
+    lib.rtx_draw_rows.argtypes = [vp, i, i, vp, i, vp]
     lib.rtx_finish.argtypes = [vp]
     lib.rtx_read_pixels.argtypes = [vp, i, vp, c.c_size_t]
     lib.rtx_framebuffer_device.argtypes = [vp, i, P(vp)]

@@ -1552,6 +1552,16 @@ int rtx_write_pixels(rtx_context* ctx, int format, const void* src_host, size_t 
     return RTX_OK;
 }
 
+int rtx_draw_rows(rtx_context* ctx, int row_first, int n_rows, void* dst_device, int format, void* stream)
+{
+    if (!ctx || !dst_device) return fail(RTX_ERR_INVALID, "rtx_draw_rows: null argument");
+    if (ctx->banded) return fail(RTX_ERR_INVALID, "rtx_draw_rows on a multi-device context: it splits the frame itself (rtx_draw)");
+    if (row_first < 0 || (row_first % 8) != 0 || n_rows < 0 || row_first + n_rows > ctx->height) return fail(RTX_ERR_INVALID, "rtx_draw_rows: rows [%d, %d) of a %d-row frame (the first must be a multiple of 8)", row_first, row_first + n_rows, ctx->height);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    if (format == RTX_RGBA32F) return draw_impl(ctx, 8, row_first / 8, 1, static_cast<float*>(dst_device), nullptr, s, n_rows);
+    if (format == RTX_RGBA8) return draw_impl(ctx, 8, row_first / 8, 1, nullptr, static_cast<uint32_t*>(dst_device), s, n_rows);
+    return fail(RTX_ERR_INVALID, "unknown format %d", format);
+}
 int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride, void* dst_device, int format, void* stream)
 {
     if (!ctx || !dst_device) return fail(RTX_ERR_INVALID, "rtx_draw_bands: null argument");

@@ -180,6 +180,9 @@ class GLWrapper:
         _check(self._lib.rtx_draw_bands(self._ctx, band_rows, band_first, band_stride, ctypes.c_void_p(dst_device_ptr), fmt,
                                         ctypes.c_void_p(stream) if stream else None), "draw_bands")
 
+    def draw_rows(self, row_first: int, n_rows: int, dst_device_ptr: int, fmt: int = RTX_RGBA32F, stream: int = 0):
+        _check(self._lib.rtx_draw_rows(self._ctx, row_first, n_rows, ctypes.c_void_p(dst_device_ptr), fmt, ctypes.c_void_p(stream) if stream else None), "draw_rows")
+
     def finish(self):
         _check(self._lib.rtx_finish(self._ctx), "finish")
 

@@ -192,6 +192,32 @@ def test_row_bands_reassemble_the_frame(small_textures):
     gl.stop()
 
 
+def test_contiguous_row_ranges_reassemble_the_frame(small_textures):
+    """rtx_draw_rows: one rank's share in the contiguous band layout -- ranges starting on multiples of 8, of any length incl. the odd rest of
+    the frame and zero rows -- packed from the start of the destination; together the ranges are the frame, bit for bit."""
+    import torch
+    w, h = 333, 207
+    sc = scenes.build_scene("default", w, h, 4)
+    gl = wrapper.make_renderer(sc, w, h, small_textures["textures"], small_textures["cubemap"])
+    gl.draw()
+    want = gl.read_pixels(wrapper.RTX_RGBA32F)
+    stream = torch.cuda.current_stream().cuda_stream
+    buf = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    got = np.zeros_like(want)
+    y = 0
+    for n in (8, 0, 64, 72, 40, 23):
+        gl.draw_rows(y, n, buf.data_ptr(), wrapper.RTX_RGBA32F, stream)
+        gl.finish()
+        got[y:y + n] = buf[:n].cpu().numpy()
+        y += n
+    assert y == h and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    with pytest.raises(wrapper.RtxError, match="multiple of 8"):
+        gl.draw_rows(4, 8, buf.data_ptr(), wrapper.RTX_RGBA32F, stream)
+    with pytest.raises(wrapper.RtxError):
+        gl.draw_rows(200, 16, buf.data_ptr(), wrapper.RTX_RGBA32F, stream)
+    gl.stop()
+
+
 def test_high_occupancy_variant_is_bit_identical(small_textures):
     """RTX_OPT_HIGH_OCCUPANCY selects another register budget of the same kernel (7 waves/SIMD instead of 6;
     auto-selected for scenes with >= 32 primitives): the frames must not differ in a single bit."""
