@@ -562,8 +562,13 @@ def main():
                 ts_ms.append(gl.stats()["last_smaa_ms"])
             sm = gl.stats()
             smaa_ms = float(np.median(ts_ms[2:]))
+            in_draw = []
+            for _ in range(10):             # the same passes right behind the tracer, as draw() runs them (GLWrapper.cpp:155-204): the colour target
+                gl.draw()                   # then comes from HBM, not from the 256 MB last-level cache a repeated resolve finds it in
+                in_draw.append(gl.stats()["last_smaa_ms"])
             gl.enable_SMAA(wrapper.RTX_SMAA_OFF)
-            out["smaa"] = {"preset": "ULTRA", "ms_per_resolve": round(smaa_ms, 4), "edge_pixels": int(sm["smaa_edge_pixels"]),
+            out["smaa"] = {"preset": "ULTRA", "ms_per_resolve": round(smaa_ms, 4), "ms_per_resolve_inside_draw": round(float(np.median(in_draw[2:])), 4),
+                           "edge_pixels": int(sm["smaa_edge_pixels"]),
                            "roofline": {"bound": "hbm", "achieved": round(W * H * 8 / smaa_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(W * H * 8 / smaa_ms / 1e6 / HBM_PEAK_GBS, 4)},
                            "note": "all kernels of one resolve of the traced frame (RGBA8 in, RGBA8 screen out); area and search tables generated "
