@@ -86,7 +86,8 @@ __device__ void flush(const AuditParams& p, const unsigned int* c)
 // tori: sphere cull (torus_cull), group sphere, convex-hull cull, puck / hole cull, and the premise of the candidate tables (the ray's LINE
 // 's part up to the limit stays 6 mm clear of the real tube, in exact arithmetic) -- each judged ON ITS OWN against the un-culled solver
 // counters: 0 rays, 1 culled by any, 2 sphere, 3 group, 4 hull, 5 puck, 6 line-miss, 7 solver runs, 8 literal hits among the solved,
-//           10 VIOLATIONS sphere, 11 group, 12 hull, 13 puck, 14 line-miss, 15 a non-unit direction was culled, 16 rays with a non-unit direction
+//           10 VIOLATIONS sphere, 11 group, 12 hull, 13 puck, 14 line-miss, 15 a non-unit direction was culled, 16 rays with a non-unit direction,
+//           17 culled by the tube (Bernstein) test behind the puck test, 18 VIOLATIONS of it
 // ================================================================================================================================
 __device__ void torus_ray(Rng& R, const DevTorus& T, const f4 bound, int mode, f3& ro, f3& rd, float& tmin)
 {
@@ -245,14 +246,16 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         const bool c_sphere = torus_cull(bound, ro, rd, tmin);
         const bool c_group = grouped && torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin);
         const bool c_hull = unit && torus_hull_cull(T, o, d);
-        const bool c_puck = unit && torus_puck_cull(T, o, d, tmin);
+        float pk0 = 0.0f, pk1 = 0.0f;
+        const bool c_puck = unit && torus_puck_cull(T, o, d, tmin, pk0, pk1);
+        const bool c_tube = unit && !c_puck && torus_tube_cull(T, o, d, pk0, pk1);     // the Bernstein test of the inflated tube, behind the puck test
         // the premise in its strongest form: the ray's part up to the limit stays 6 mm clear of the REAL tube (exact) -- every cull and every
         // clear bit of a candidate table implies it (their margins are 1 % + 0.01 and more)
         const bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)torus_limit(tmin) * 1.001 + 0.01) >= 6.0e-3;
-        const bool any = c_sphere || c_group || c_hull || c_puck || c_line;
-        c[0]++; c[1] += any; c[2] += c_sphere; c[3] += c_group; c[4] += c_hull; c[5] += c_puck; c[6] += c_line; c[16] += scaled;
+        const bool any = c_sphere || c_group || c_hull || c_puck || c_tube || c_line;
+        c[0]++; c[1] += any; c[2] += c_sphere; c[3] += c_group; c[4] += c_hull; c[5] += c_puck; c[6] += c_line; c[16] += scaled; c[17] += c_tube;
         // product's own composition must agree with the parts (intersect_torus_c<true> is what the scans call)
-        if (scaled && (c_sphere || c_group || c_hull || c_puck) && !unit_direction(dot3_fma(rd, rd))) { c[15]++; record_bad(p, 15, i, ro, rd, tmin, 0.0f, dot3(rd, rd)); }
+        if (scaled && (c_sphere || c_group || c_hull || c_puck || c_tube) && !unit_direction(dot3_fma(rd, rd))) { c[15]++; record_bad(p, 15, i, ro, rd, tmin, 0.0f, dot3(rd, rd)); }
         if (any) {
             float t = 0.0f;
             const bool hit = intersect_torus(T, ro, rd, tmin, t);
@@ -262,6 +265,7 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
                 if (c_group) { c[11]++; record_bad(p, 11, i, ro, rd, tmin, t, 0.0f); }
                 if (c_hull) { c[12]++; record_bad(p, 12, i, ro, rd, tmin, t, 0.0f); }
                 if (c_puck) { c[13]++; record_bad(p, 13, i, ro, rd, tmin, t, 0.0f); }
+                if (c_tube) { c[18]++; record_bad(p, 18, i, ro, rd, tmin, t, 0.0f); }
                 if (c_line) { c[14]++; record_bad(p, 14, i, ro, rd, tmin, t, 0.0f); }
             }
         }

@@ -25,7 +25,8 @@ FAMILIES = {"torus": 0, "torus_margin": 1, "quadric": 2, "ring": 3, "tables": 4}
 NEEDS = {"torus": 4, "torus_margin": 4, "quadric": 2, "ring": 5}      # index into defines of the count that must be > 0
 LABELS = {
     "torus": {0: "rays", 1: "culled by any test", 2: "sphere cull", 3: "group sphere", 4: "convex-hull cull", 5: "puck / hole cull", 6: "the ray up to its limit stays >= 6 mm clear of the real tube (exact)",
-              7: "solver runs", 8: "solver hits among them", 16: "rays with a non-unit direction",
+              7: "solver runs", 8: "solver hits among them", 16: "rays with a non-unit direction", 17: "tube (Bernstein) cull, behind the puck test",
+              18: "VIOLATIONS tube (Bernstein) cull",
               10: "VIOLATIONS sphere cull", 11: "VIOLATIONS group sphere", 12: "VIOLATIONS convex-hull cull", 13: "VIOLATIONS puck / hole cull",
               14: "VIOLATIONS clearance premise: >= 6 mm clear of the real tube, yet a hit is reported", 15: "VIOLATIONS a non-unit direction was culled"},
     "torus_margin": {0: "rays (every one solved)", 1: "hits reported", 2: "hits whose ray touches the real tube", 3: "phantom hits, clearance < 1e-6", 4: "1e-6 .. 1e-5",
