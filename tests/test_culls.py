@@ -499,3 +499,24 @@ def test_quadric_cull_in_the_ill_conditioned_regime(built, kind):
             culled_n += culled
             bad += culled and hit
     assert checked > 8000 and culled_n > 500 and bad == 0, (checked, culled_n, bad)
+
+
+def test_tube_cull_leaves_horn_and_spindle_tori_alone(built):
+    """Round 4's Bernstein test of the inflated torus' quartic (rt_device.h torus_tube_cull) is sound for RING tori only: a horn or spindle
+    torus (r >= R) has a second sheet around its centre inside which the quartic is positive again, and a ray that starts in there and hits
+    that sheet lies where the inflated quartic is positive too. Its first form passed every frame test and was caught by tools/cull_audit.py
+    (6.2 M culled hits in 7.9e9 culled rays, all on nasty_scene's r >= R tori); these are rays of that kind: from near the centre, short."""
+    from scene_util import material, torus
+    rng = np.random.default_rng(8)
+    bad = hits = 0
+    for R, r in ((1.0, 1.0), (0.3, 1.0), (1.0, 1.5), (1.0, 0.995), (2.0, 1.99)):
+        rec = torus((3.0, 3.0, 3.0), R, r, material((1, 1, 1), 0, 0))
+        for _ in range(3000):
+            ro = np.array([3.0, 3.0, 3.0]) + rng.normal(size=3) * 0.05 * max(R, r)
+            rd = rng.normal(size=3)
+            rd /= np.linalg.norm(rd)
+            tmin = float(10 ** rng.uniform(-1.2, 1.0))
+            hit, t, culled = harness.kat(oracle.TYPE_TORUS, rec, tuple(float(np.float32(v)) for v in ro), tuple(float(np.float32(v)) for v in rd), tmin)
+            hits += hit
+            bad += hit and culled
+    assert hits > 2000 and bad == 0, (hits, bad)

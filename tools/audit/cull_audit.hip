@@ -248,7 +248,10 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         const bool c_hull = unit && torus_hull_cull(T, o, d);
         float pk0 = 0.0f, pk1 = 0.0f;
         const bool c_puck = unit && torus_puck_cull(T, o, d, tmin, pk0, pk1);
-        const bool c_tube = unit && !c_puck && torus_tube_cull(T, o, d, pk0, pk1);     // the Bernstein test of the inflated tube, behind the puck test
+        // the Bernstein test of the inflated tube, behind the puck test: taken from the product's own composition (what the scans call), so that
+        // whatever conditions it puts in front of the test are the ones audited
+        const bool c_tube = unit && !c_hull && !c_puck && torus_local_cull<true>(T, o, d, tmin);
+        (void)pk0; (void)pk1;
         // the premise in its strongest form: the ray's part up to the limit stays 6 mm clear of the REAL tube (exact) -- every cull and every
         // clear bit of a candidate table implies it (their margins are 1 % + 0.01 and more)
         const bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)torus_limit(tmin) * 1.001 + 0.01) >= 6.0e-3;
