@@ -190,34 +190,44 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     # Untimed additions to the SAME line (one run on an 8-GPU node is all there may be): the other colour target and the other band layout,
     # each timed exactly like the value above, with K steps.
     extras = {}
-    if n_ranks > 1 or args.transport == "loopback":
-        other_target = "rgba8" if target == "rgba32f" else "rgba32f"
-        gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 2 if other_target == "rgba8" else 1)
-        for _ in range(3):
-            gl.draw()
-        e2, t2, g2 = timed(args.steps)
-        extras[other_target] = {"ms_per_step": round(e2 / args.steps * 1e3, 4), "trace_ms_max_rank": round(t2, 4), "gather_ms": round(g2, 4),
-                                "value_Mray_s": round(rays_frame * args.steps / e2 / 1e6, 2)}
-        gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 1 if target == "rgba32f" else 2)
-        for other_layout in ("balanced", "interleaved"):
-            if other_layout == args.bands:
-                continue
-            gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 1 if other_layout == "balanced" else 0)
-            if other_layout == "balanced":
-                bal_split, bal_ms = balance()
+    try:
+        if n_ranks > 1 or args.transport == "loopback":
+            other_target = "rgba8" if target == "rgba32f" else "rgba32f"
+            gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 2 if other_target == "rgba8" else 1)
             for _ in range(3):
                 gl.draw()
-            e3, t3, g3 = timed(args.steps)
-            extras["bands_" + other_layout] = {"ms_per_step": round(e3 / args.steps * 1e3, 4), "trace_ms_max_rank": round(t3, 4), "gather_ms": round(g3, 4),
-                                               "value_Mray_s": round(rays_frame * args.steps / e3 / 1e6, 2), "rows_per_rank": gl.band_split(),
-                                               "trace_ms_per_rank": [round(v, 4) for v in rank_ms()]}
-            break
-        # back to the configuration the value was measured with (the parity check below reads its frame)
-        gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, {"interleaved": 0, "contiguous": 1, "balanced": 1}[args.bands])
-        if args.bands != "interleaved":
-            gl.set_band_split(split_used)
-        gl.draw()
-        gl.finish()
+            e2, t2, g2 = timed(args.steps)
+            extras[other_target] = {"ms_per_step": round(e2 / args.steps * 1e3, 4), "trace_ms_max_rank": round(t2, 4), "gather_ms": round(g2, 4),
+                                    "value_Mray_s": round(rays_frame * args.steps / e2 / 1e6, 2)}
+            gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 1 if target == "rgba32f" else 2)
+            for other_layout in (("balanced", "interleaved") if args.also_bands else ()):
+                if other_layout == args.bands:
+                    continue
+                gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, 1 if other_layout == "balanced" else 0)
+                if other_layout == "balanced":
+                    bal_split, bal_ms = balance()
+                for _ in range(3):
+                    gl.draw()
+                e3, t3, g3 = timed(args.steps)
+                extras["bands_" + other_layout] = {"ms_per_step": round(e3 / args.steps * 1e3, 4), "trace_ms_max_rank": round(t3, 4), "gather_ms": round(g3, 4),
+                                                   "value_Mray_s": round(rays_frame * args.steps / e3 / 1e6, 2), "rows_per_rank": gl.band_split(),
+                                                   "trace_ms_per_rank": [round(v, 4) for v in rank_ms()]}
+                break
+            # back to the configuration the value was measured with (the parity check below reads its frame)
+            gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, {"interleaved": 0, "contiguous": 1, "balanced": 1}[args.bands])
+            if args.bands != "interleaved":
+                gl.set_band_split(split_used)
+            gl.draw()
+            gl.finish()
+    except Exception as e:      # the additions must never cost the line itself (N > 1 on distinct devices has not run before the driver runs it)
+        extras["error"] = f"{type(e).__name__}: {e}"
+        try:
+            gl.set_option(wrapper.RTX_OPT_GATHER_TARGETS, 1 if target == "rgba32f" else 2)
+            gl.set_option(wrapper.RTX_OPT_BAND_LAYOUT, {"interleaved": 0, "contiguous": 1, "balanced": 1}[args.bands])
+            gl.draw()
+            gl.finish()
+        except Exception:
+            pass
     if rank != 0:
         gl.stop()
         return
@@ -305,6 +315,10 @@ def main():
                          "pass on rank 0), contiguous = one equal range of rows per rank traced / received straight into place, balanced = contiguous "
                          "ranges weighted by the ranks' measured kernel times. The line's value is this layout; the other one and the other colour "
                          "target are measured too and reported under config.also_measured")
+    ap.add_argument("--also-bands", action="store_true",
+                    help="N > 1: also time the other band layout (config.also_measured.bands_*). Off by default: measured alone on one GPU the contiguous "
+                         "ranges lose to interleaved bands at every N (profiles/r04_time_bands_*.txt), and the line's run on real devices should not "
+                         "depend on a second layout's code")
     ap.add_argument("--no-smaa", action="store_true", help="skip the untimed SMAA post-process measurement (N = 1)")
     ap.add_argument("--launcher", choices=("auto", "torch"), default="auto",
                     help="N > 1 without torch.distributed.run around it: auto = one process drives the N devices through rtx_create_multi; "

@@ -265,7 +265,7 @@ def _run_bench(extra, torchrun=False, timeout=600):
 def test_bench_multi_gpu_forms_run_through_the_c_boundary():
     """bench.py's N > 1 code on one GPU: the single-process form (rtx_create_multi) and the torch.distributed.run form (rtx_create_rank),
     both with the loopback transport; and --gpus 2 on a box without a second GPU is one clear line, exit code 2."""
-    r, line = _run_bench(["--gpus", "1", "--transport", "loopback"])
+    r, line = _run_bench(["--gpus", "1", "--transport", "loopback", "--also-bands"])
     assert r.returncode == 0 and line, r.stderr[-2000:]
     assert line["n_gpus"] == 1 and line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical"
     assert "rtx_create_multi" in line["config"]["parallelism"] and line["config"]["gather_ms"] > 0 and line["config"]["trace_ms_max_rank"] > 0
