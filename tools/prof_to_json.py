@@ -63,10 +63,9 @@ if valu["active_inst_valu_quad_cycles"]:
     valu["lane_utilisation"] = round(valu["thread_cycles_valu"] / (64.0 * valu["active_inst_valu_quad_cycles"]), 4)
     valu["cycles_per_valu_inst"] = round(4.0 * valu["active_inst_valu_quad_cycles"] / valu["valu_insts_per_launch"], 3)
 if valu["grbm_gui_active"]:
-    # SQ_ACTIVE_INST_VALU: quad-cycles (4 shader cycles) with a VALU instruction in flight, summed over the 1024 SIMDs; GRBM_GUI_ACTIVE:
-    # busy cycles summed over the 8 XCDs. busy = VALU-active time per SIMD / kernel time. (Comes out a few per cent above 1 on a saturated
-    # pipe -- the two counters' units are nominal -- and is reported as measured.)
-    valu["valu_pipe_busy"] = round(4.0 * valu["active_inst_valu_quad_cycles"] / 1024.0 / (valu["grbm_gui_active"] / 8.0), 4)
+    # GRBM_GUI_ACTIVE: busy cycles summed over the 8 XCDs -> the shader clock the launches ran at. (Rounds 1-3 also derived a `valu_pipe_busy`
+    # from SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE; the two counters' units are nominal and the ratio came out above 1 on a saturated pipe, so it
+    # is no longer written: cycles_per_valu_inst and the mix-weighted issue ceiling in bench.py carry the information.)
     valu["shader_clock_GHz"] = round(valu["grbm_gui_active"] / 8.0 / (stamp["kernel_us_rocprof"] * 1e3), 3) if stamp["kernel_us_rocprof"] else None
 json.dump(valu, open(os.path.join(ROOT, "profiles", f"valu{suffix}.json"), "w"), indent=1)
 fetch_kb, write_kb = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)
