@@ -435,7 +435,9 @@ struct BlendT {
     // trip per round instead of one per search and round (a wave is as slow as its slowest lane: with four searches of up to four rounds
     // one after the other, the waves that held a long diagonal were the last of the kernel to finish -- tools/smaa_phase_times.py).
     // No branch sits between a load and the next load: the compiler waits for a load where its value is first used.
-    SM_HDM void diag_searches(float X, float Y, F2 e, F2 out[4]) const
+    // `pairs`: bit 0 = the first pair of searches (0, 1), bit 1 = the second (2, 3); a search that is left out issues no fetch and its
+    // out[] entry is not meaningful (round 4: the device kernel gives each pair to a wave of its own).
+    SM_HDM void diag_searches(float X, float Y, F2 e, F2 out[4], unsigned pairs = 3u) const
     {
         enum { DIAG_BATCH = SMAA_DIAG_BATCH };
         const float last = (float)(P.max_steps_diag - 1);
@@ -443,10 +445,11 @@ struct BlendT {
         float tx[4] = {X, X, X + 0.25f, X + 0.25f}, ty[4] = {Y, Y, Y, Y}, n[4] = {-1.0f, -1.0f, -1.0f, -1.0f}, wgt[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         F2 end[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
         bool on[4];
-        on[0] = e.x > 0.0f;
-        on[1] = true;
-        on[2] = true;
-        on[3] = edges_at(X, Y, 1, 0).x > 0.0f;
+        const bool p1 = (pairs & 1u) != 0u, p2 = (pairs & 2u) != 0u;
+        on[0] = p1 && e.x > 0.0f;
+        on[1] = p1;
+        on[2] = p2;
+        on[3] = p2 && edges_at(X, Y, 1, 0).x > 0.0f;
         const bool gate0 = on[0], gate3 = on[3];
         const int wm = V.w - 1, hm = V.h - 1;
         while (SM_ANY(on[0] || on[1] || on[2] || on[3])) {
@@ -493,17 +496,17 @@ struct BlendT {
     // over two columns, (0.25, 0.75) over two rows, single texels -- the bilinear sums of edges_at with their exact zeros left out (x + 0 = x
     // for the non-negative sums here). Should a position ever NOT have that form (it cannot: the distances are small whole numbers), the
     // wave takes diag_weights_from.
-    SM_HDM F2 diag_weights_staged(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r) const
+    SM_HDM F2 diag_weights_staged(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r, unsigned pairs = 3u) const
     {
         const int wm = V.w - 1, hm = V.h - 1;
         const float dx1 = s0r.x, dz1 = s0r.y, dy1 = s1r.x, dw1 = s1r.y, dx2 = s2r.x, dz2 = s2r.y, dy2 = s3r.x, dw2 = s3r.y;
-        const bool on1 = dx1 + dy1 > 2.0f, on2 = dx2 + dy2 > 2.0f;
+        const bool on1 = (pairs & 1u) != 0u && dx1 + dy1 > 2.0f, on2 = (pairs & 2u) != 0u && dx2 + dy2 > 2.0f;
         const float t0x = (-dx1 + 0.25f) * 1.0f + X, t0y = dx1 * 1.0f + Y, t1x = dy1 * 1.0f + X, t1y = (-dy1 - 0.25f) * 1.0f + Y;
         const float ax = -dx2 * 1.0f + X, ay = -dx2 * 1.0f + Y, bx = dy2 * 1.0f + X, by = dy2 * 1.0f + Y;
         const float f0x = floorf(t0x), f0y = floorf(t0y), f1x = floorf(t1x), f1y = floorf(t1y);
         const bool form = (!on1 || (t0x - f0x == 0.25f && t0y == f0y && t1x == f1x && t1y - f1y == 0.75f)) &&
                           (!on2 || (ax == floorf(ax) && ay == floorf(ay) && bx == floorf(bx) && by == floorf(by)));
-        if (SM_ANY(!form)) return diag_weights_from(X, Y, s0r, s1r, s2r, s3r);
+        if (SM_ANY(!form)) return diag_weights_from(X, Y, s0r, s1r, s2r, s3r, pairs);
         uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 0u, c0 = 0u, c1 = 0u, c2 = 0u;
         if (on1) {
             const int j = clampi((int)f0y, hm), i = clampi((int)f1x + 1, wm);
@@ -550,10 +553,10 @@ struct BlendT {
         if (on2) { wts.x += unorm8(p2 >> 8); wts.y += unorm8(p2 & 255u); }
         return wts;
     }
-    SM_HDM F2 diag_weights_from(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r) const
+    SM_HDM F2 diag_weights_from(float X, float Y, F2 s0r, F2 s1r, F2 s2r, F2 s3r, unsigned pairs = 3u) const
     {
         F2 wts{0.0f, 0.0f};
-        {
+        if (pairs & 1u) {
             const float dx = s0r.x, dz = s0r.y, dy = s1r.x, dw = s1r.y;
             if (dx + dy > 2.0f) {
                 const F2 s0 = edges_at((-dx + 0.25f) * 1.0f + X, dx * 1.0f + Y, -1, 0), s1 = edges_at(dy * 1.0f + X, (-dy - 0.25f) * 1.0f + Y, 1, 0);
@@ -567,7 +570,7 @@ struct BlendT {
                 wts.y += a.y;
             }
         }
-        {
+        if (pairs & 2u) {
             const float dx = s2r.x, dz = s2r.y, dy = s3r.x, dw = s3r.y;
             if (dx + dy > 2.0f) {
                 const float ax = -dx * 1.0f + X, ay = -dx * 1.0f + Y, bx = dy * 1.0f + X, by = dy * 1.0f + Y;
@@ -701,31 +704,80 @@ struct BlendT {
     }
     SM_HDM static uint32_t pack_weights(F4 w) { return to_unorm8(w.x) | (to_unorm8(w.y) << 8) | (to_unorm8(w.z) << 16) | (to_unorm8(w.w) << 24); }
 
-    // SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) for the pixel at (x, y); returns the RGBA8 texel. One thread does everything in
-    // the shader's order (host build, reference for the lane-parallel form in smaa_kernel.hip).
+    // SMAABlendingWeightCalculationPS (SMAA.h:1145-1243) for the pixel at (x, y) in three independent parts -- the diagonal weights, the
+    // north edge's weights, the west edge's weights -- and the rule that picks among them (combine). One thread may run them one after the
+    // other (weights(): the shader's order; host build, reference for the device kernel), or three WAVES may run one part each for the same
+    // 64 pixels at the same time (smaa_kernel.hip, round 4): every part is a chain of ~6-10 dependent memory round trips, and a wave that
+    // runs all three is as slow as their sum. The parts do not depend on each other; a part whose result combine() then discards was
+    // computed from the same inputs it would have seen anyway (its inputs are the pass-1 textures only).
+    SM_HDM F2 own_edges(int x, int y) const
+    {
+        const uint32_t own = src.raw(clampi(x, V.w - 1), clampi(y, V.h - 1));   // texel-centre fetch of the pixel's own edges
+        return F2{unorm8(own & 255u), unorm8(own >> 8)};
+    }
+    SM_HDM bool has_diag_part(F2 e) const { return e.y > 0.0f && P.max_steps_diag > 0; }
+    // SMAACalculateDiagWeights (SMAA.h:1157). With `pairs` = 1 or 2 only that pair of diagonals: the function's result is
+    // (0 + a1.x) + a2.y, (0 + a1.y) + a2.x with a1 / a2 the area texels of the pairs that found a diagonal -- bytes / 255, never negative --
+    // so part_diag(.., 1) + part_diag(.., 2), component by component, is the same float (x + 0 = x for x >= +0).
+    SM_HDM F2 part_diag(float X, float Y, F2 e, unsigned pairs = 3u) const
+    {
+#if SMAA_DIAG_IN_STEP
+        F2 ds[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+        diag_searches(X, Y, e, ds, pairs);
+        SMAA_PH(9);
+        return diag_weights_staged(X, Y, ds[0], ds[1], ds[2], ds[3], pairs);
+#else
+        const F2 s0 = diag_search(0, X, Y, e), s1 = diag_search(1, X, Y, e), s2 = diag_search(2, X, Y, e), s3 = diag_search(3, X, Y, e);
+        return diag_weights_from(X, Y, s0, s1, s2, s3, pairs);
+#endif
+    }
+    SM_HDM F2 part_north(float X, float Y) const                 // SMAA.h:1165-1204
+    {
+        const float cx = ortho_search(0, X, Y);
+        const float cz = ortho_search(1, X, Y);
+        return north_from(X, Y, cx, cz);
+    }
+    SM_HDM F2 part_west(float X, float Y) const                  // SMAA.h:1211-1240
+    {
+        const float cy = ortho_search(2, X, Y);
+        const float cz = ortho_search(3, X, Y);
+        return west_from(X, Y, cy, cz);
+    }
+    // which parts the shader's control flow USES (SMAA.h:1152-1163, 1206-1209): the diagonal weights stand unless they cancel
+    // (weights.r == -weights.g), in which case the north weights replace them; a standing diagonal also skips the west edge.
+    SM_HDM static uint32_t combine(F2 e, bool diag_enabled, F2 dwt, F2 north, F2 west)
+    {
+        F4 out{0.0f, 0.0f, 0.0f, 0.0f};
+        if (e.y > 0.0f) {
+            bool hv = true;
+            if (diag_enabled) {
+                out.x = dwt.x;
+                out.y = dwt.y;
+                hv = (out.x == -out.y);
+            }
+            if (hv) {
+                out.x = north.x;
+                out.y = north.y;
+            } else {
+                e.x = 0.0f;
+            }
+        }
+        if (e.x > 0.0f) {
+            out.z = west.x;
+            out.w = west.y;
+        }
+        return pack_weights(out);
+    }
     SM_HDM uint32_t weights(int x, int y) const
     {
         const float X = (float)x, Y = (float)y;
         F4 out{0.0f, 0.0f, 0.0f, 0.0f};
-        const uint32_t own = src.raw(clampi(x, V.w - 1), clampi(y, V.h - 1));   // texel-centre fetch of the pixel's own edges
-        F2 e{unorm8(own & 255u), unorm8(own >> 8)};
+        F2 e = own_edges(x, y);
         SMAA_PH(1);
         bool hv = e.y > 0.0f;
         if (e.y > 0.0f) {
             if (P.max_steps_diag > 0) {
-#if SMAA_DIAG_IN_STEP
-                F2 ds[4];
-                diag_searches(X, Y, e, ds);
-                const F2 s0 = ds[0], s1 = ds[1], s2 = ds[2], s3 = ds[3];
-                SMAA_PH(9);
-#else
-                const F2 s0 = diag_search(0, X, Y, e), s1 = diag_search(1, X, Y, e), s2 = diag_search(2, X, Y, e), s3 = diag_search(3, X, Y, e);
-#endif
-#if SMAA_DIAG_IN_STEP
-                const F2 dwt = diag_weights_staged(X, Y, s0, s1, s2, s3);
-#else
-                const F2 dwt = diag_weights_from(X, Y, s0, s1, s2, s3);
-#endif
+                const F2 dwt = part_diag(X, Y, e);
                 out.x = dwt.x;
                 out.y = dwt.y;
                 hv = (out.x == -out.y);
@@ -734,9 +786,7 @@ struct BlendT {
         SMAA_PH(2);
         if (e.y > 0.0f) {
             if (hv) {
-                const float cx = ortho_search(0, X, Y);
-                const float cz = ortho_search(1, X, Y);
-                const F2 wgt = north_from(X, Y, cx, cz);
+                const F2 wgt = part_north(X, Y);
                 out.x = wgt.x;
                 out.y = wgt.y;
             } else {
@@ -745,9 +795,7 @@ struct BlendT {
         }
         SMAA_PH(3);
         if (e.x > 0.0f) {
-            const float cy = ortho_search(2, X, Y);
-            const float cz = ortho_search(3, X, Y);
-            const F2 wgt = west_from(X, Y, cy, cz);
+            const F2 wgt = part_west(X, Y);
             out.z = wgt.x;
             out.w = wgt.y;
         }

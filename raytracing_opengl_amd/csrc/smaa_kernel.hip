@@ -10,10 +10,11 @@
 //                        word; and 16 bits per column and strip, 8 pixels of a column; dense, 2 x 2 MB at 4K), brings the RG8 edge texture up to
 //                        date (texels where this frame or the previous one has an edge) and appends the strip's edge pixels to a list --
 //                        one atomic per 256 x 8 strip, none for the strips without an edge;
-//   smaa_weights_kernel  over the list, one thread per listed pixel: blending weights (SMAA.h:1145-1243) -> RGBA8 weight texel. The step
-//                        counts of the four orthogonal searches come from whole plane words (smaa_device.h SearchPlanes), single edge
-//                        texels from the RG8 texture. (Round 2 walked every edge on the texture: up to 32 dependent 4-tap fetches per
-//                        direction.)
+//   smaa_weights_roles_kernel  over the list: blending weights (SMAA.h:1145-1243) -> RGBA8 weight texel. The step counts of the four
+//                        orthogonal searches come from whole plane words (smaa_device.h SearchPlanes), single edge texels from the RG8
+//                        texture. (Round 2 walked every edge on the texture: up to 32 dependent 4-tap fetches per direction.) Round 4: four
+//                        waves per 64 listed pixels, one independent part of the computation each (first / second pair of diagonals,
+//                        north edge, west edge); round 3's one-thread-per-pixel kernel (smaa_weights_kernel) is the -DSMAA_ROLE_WAVES=0 build.
 //   smaa_blend_kernel    over the list: neighbourhood blending (SMAA.h:1252-1300) of the listed pixel, its left and its lower
 //                        neighbour -- the only pixels whose four weights can be non-zero -- overwriting their screen texels; a weight
 //                        texel is looked at only where the row plane has an edge pixel.
@@ -45,7 +46,7 @@
 // diagnostic build (tools/smaa_phase_times.py): per wave of the last smaa_weights_kernel launch, s_memrealtime (10 ns ticks) at [0] kernel
 // entry, [5] list prefix done, [6] list entry read, [1..4] the convergent points of smaa::BlendT::weights, [7] exit; [8] = 1 if the wave had a pixel
 #include <hip/hip_runtime.h>
-__device__ unsigned long long g_smaa_ph[4096][12];
+__device__ unsigned long long g_smaa_ph[8192][12];
 #define SMAA_PH(k) do { g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // the same for the dense kernel: [0] entry, [1] luma tables built (barrier), [2] first rows loaded, [3] rows done, [4] planes written, [5] exit
 __device__ unsigned long long g_smaa_ep[8192][6];
@@ -56,12 +57,25 @@ extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_edge_times(
 }
 extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_phase_times(unsigned long long* out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ph), sizeof(unsigned long long) * 4096 * 12) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_ph), sizeof(unsigned long long) * 8192 * 12) == hipSuccess ? 0 : 1;
+}
+// the role-split weight kernel (tools/smaa_role_times.py): per wave [0] entry, [1] list prefix done, [2] list entry + own texel read, [3] the wave's
+// part done, [4] past the barrier (every part of the workgroup done), [5] exit; [6] = 1 + role if some lane had a pixel, [7] = 1 if some lane ran the part
+__device__ unsigned long long g_smaa_rp[8192][8];
+#define SMAA_RP(k) do { g_smaa_rp[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SMAA_RP_SET(k, v) do { g_smaa_rp[blockIdx.x * 4 + (threadIdx.x >> 6)][k] = (v); } while (0)
+extern "C" __attribute__((visibility("default"))) int rtx_debug_smaa_role_times(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smaa_rp), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : 1;
 }
 #endif
 
 #ifndef SMAA_EP
 #define SMAA_EP(k)
+#endif
+#ifndef SMAA_RP
+#define SMAA_RP(k)
+#define SMAA_RP_SET(k, v)
 #endif
 
 #include "smaa_device.h"
@@ -431,6 +445,107 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
 #endif
 }
 
+// The same weights with the three independent parts of a pixel's computation -- diagonal, north edge, west edge (smaa_device.h part_*) -- on
+// WAVES of a workgroup at the same time (round 4; four waves: the diagonal part once per pair of diagonals, whose two results add up to it exactly). A listed pixel's weights are a chain of dependent memory round trips (step counts
+// from the planes -> the search's last fetch -> the search table -> the crossing edges -> the area table, twice per edge, after up to four
+// rounds of diagonal fetches): 14 us for the median wave and 22 for the slowest when one wave walks all of it, on a GPU that is otherwise idle
+// -- the list of a traced 4K frame fills 1 200 waves. Each wave of a workgroup takes the same 64 list entries and ONE part; the north and west
+// waves leave their two floats in LDS, the diagonal wave applies the shader's selection rule (smaa::Blend::combine) and stores the texel.
+// A part the rule then discards was computed from the pass-1 textures like any other, so the bytes are those of weights().
+#ifndef SMAA_ROLE_WAVES
+#define SMAA_ROLE_WAVES 1
+#endif
+#ifndef SMAA_ROLE_GRID
+#define SMAA_ROLE_GRID 2048   /* x 3 waves = 6 144 = six per SIMD: every workgroup resident at once (1 024 / 4 096: traced ULTRA 20.2 / 17.0 against 16.5 us) */
+#endif
+#ifndef SMAA_ROLE_PLANETEX
+#define SMAA_ROLE_PLANETEX 0   /* A/B: 1 = every role reads single edge texels from the row bit plane instead of the RG8 texture, 2 = the diagonal roles only */
+#endif
+#ifndef SMAA_ROLE_MAX_PIXELS
+#define SMAA_ROLE_MAX_PIXELS (SMAA_ROLE_GRID * 64u)   /* what the grid takes in ONE pass */
+#endif
+__global__ __launch_bounds__(256) void smaa_weights_roles_kernel(SmaaBuffers b, int preset, unsigned cur)
+{
+    __shared__ SegmentedList L;
+    __shared__ smaa::F2 part[3][64];
+    SMAA_RP(0);
+    SMAA_RP_SET(6, 0ull);
+    SMAA_RP_SET(7, 0ull);
+    const unsigned n = L.load(b.count + cur * SMAA_COUNT_SET);
+    SMAA_RP(1);
+    if (blockIdx.x == 0 && threadIdx.x < SMAA_SEGMENTS) b.count[(cur ^ 1u) * SMAA_COUNT_SET + threadIdx.x * SMAA_COUNT_STRIDE] = 0;   // free for the next frame's appends
+    const smaa::Preset P = smaa::preset_of(preset);
+    const smaa::Views V{b.w, b.h, b.color, b.edges, b.blend, b.area, b.search};
+    const smaa::SearchPlanes planes{b.bits, b.cbits, b.w, b.h};
+    const smaa::TexEdges src{b.edges, b.w};
+#if SMAA_ROLE_PLANETEX == 1
+    const smaa::PlaneTex psrc{b.bits, smaa::SearchPlanes::plane_words(b.w)};
+    const smaa::BlendT<smaa::PlaneTex> B{V, P, planes, psrc};
+    const smaa::BlendT<smaa::PlaneTex>& BD = B;
+#elif SMAA_ROLE_PLANETEX == 2
+    const smaa::Blend B{V, P, planes, src};
+    const smaa::PlaneTex psrc{b.bits, smaa::SearchPlanes::plane_words(b.w)};
+    const smaa::BlendT<smaa::PlaneTex> BD{V, P, planes, psrc};
+#else
+    const smaa::Blend B{V, P, planes, src};
+    const smaa::Blend& BD = B;
+#endif
+    if (n > SMAA_ROLE_MAX_PIXELS) {
+        // A long list (a frame full of edges: 6 % of the pixels in the synthetic pattern) keeps every SIMD busy whatever the order, and then
+        // the parts the selection rule discards are plain extra work (pattern ULTRA 76 -> 96 us with the roles): one thread per pixel, all
+        // parts in the shader's order, as in rounds 2-3.
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const uint32_t p = L.entry(b, i);
+            const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
+            b.blend[p] = B.weights(x, y);
+        }
+        return;
+    }
+    const unsigned role = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (unsigned base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {   // workgroup-uniform
+        const unsigned i = base + lane;
+        const bool valid = i < n;
+        uint32_t p = 0u;
+        int x = 0, y = 0;
+        smaa::F2 e{0.0f, 0.0f};
+        if (valid) {
+            p = L.entry(b, i);
+            y = (int)(p / (uint32_t)b.w);
+            x = (int)(p - (uint32_t)y * (uint32_t)b.w);
+            e = B.own_edges(x, y);
+        }
+        const float X = (float)x, Y = (float)y;
+        smaa::F2 r{0.0f, 0.0f};
+#ifdef SMAA_PHASE_TIMES
+        if (e.x == 123.0f) return;       // (keeps the own-texel fetch in front of the stamp)
+        SMAA_RP(2);
+        SMAA_RP_SET(6, 1ull + role);
+        if (__any(role == 1u ? (valid && e.y > 0.0f) : role == 2u ? (valid && e.x > 0.0f) : (valid && B.has_diag_part(e)))) SMAA_RP_SET(7, 1ull);
+#endif
+        if (role == 1u) {
+            if (valid && e.y > 0.0f) r = B.part_north(X, Y);
+            part[0][lane] = r;
+        } else if (role == 2u) {
+            if (valid && e.x > 0.0f) r = B.part_west(X, Y);
+            part[1][lane] = r;
+        } else if (role == 3u) {
+            if (valid && B.has_diag_part(e)) r = BD.part_diag(X, Y, e, 2u);
+            part[2][lane] = r;
+        } else {
+            if (valid && B.has_diag_part(e)) r = BD.part_diag(X, Y, e, 1u);
+        }
+#ifdef SMAA_PHASE_TIMES
+        if (r.x == 123.0f) return;
+        SMAA_RP(3);
+#endif
+        __syncthreads();
+        SMAA_RP(4);
+        if (role == 0u && valid) b.blend[p] = smaa::Blend::combine(e, P.max_steps_diag > 0, smaa::F2{r.x + part[2][lane].x, r.y + part[2][lane].y}, part[0][lane], part[1][lane]);
+        __syncthreads();
+    }
+    SMAA_RP(5);
+}
+
 __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned cur)
 {
     __shared__ SegmentedList L;
@@ -498,7 +613,11 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const float thr = smaa::preset_of(preset).threshold;
     if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
     else hipLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
+#if SMAA_ROLE_WAVES
+    hipLaunchKernelGGL(smaa_weights_roles_kernel, dim3(SMAA_ROLE_GRID), dim3(256), 0, stream, b, preset, cur);
+#else
     hipLaunchKernelGGL(smaa_weights_kernel, sparse, dim3(256), 0, stream, b, preset, cur);
+#endif
     hipLaunchKernelGGL(smaa_blend_kernel, sparse, dim3(256), 0, stream, b, cur);
     return hipGetLastError();
 }

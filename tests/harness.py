@@ -127,15 +127,17 @@ def kat(type_, record: bytes, ro, rd, tmin=1e6):
     return bool(out[0]), out[1], bool(out[2])
 
 
-def smaa(color_rgba8, preset, area, search, planes: bool = True):
+def smaa(color_rgba8, preset, area, search, planes: bool = True, roles: bool = False):
     """The product's SMAA arithmetic (csrc/smaa_device.h, host build) run densely: {'edges', 'blend', 'screen'} like oracle.smaa.run.
-    planes: the orthogonal searches count their steps on the bit planes, like the HIP weight kernel (False: per-step loops only)."""
+    planes: the orthogonal searches count their steps on the bit planes, like the HIP weight kernel (False: per-step loops only).
+    roles: a pixel's weights composed from its independent parts the way the role-split HIP kernel composes them (four waves, one part each)."""
     color = np.ascontiguousarray(color_rgba8, np.uint8)
     h, w = color.shape[:2]
     area, search = np.ascontiguousarray(area, np.uint8), np.ascontiguousarray(search, np.uint8)
     edges, blend, screen = np.empty((h, w, 2), np.uint8), np.empty((h, w, 4), np.uint8), np.empty((h, w, 4), np.uint8)
     l = lib()
     l.harness_smaa_use_planes(1 if planes else 0)
+    l.harness_smaa_use_roles(1 if roles else 0)
     l.harness_smaa.restype = ctypes.c_int
     l.harness_smaa.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
     p = ("LOW", "MEDIUM", "HIGH", "ULTRA").index(preset) if isinstance(preset, str) else int(preset)

@@ -11,6 +11,21 @@
 
 static int use_planes = 1;   // 0: every orthogonal search takes the per-step loop (the form the planes' step count is checked against)
 extern "C" void harness_smaa_use_planes(int on) { use_planes = on; }
+static int use_roles = 0;    // 1: a pixel's weights from the independent parts + the selection rule, the diagonal part once per pair of diagonals --
+                             // the composition smaa_weights_roles_kernel runs on four waves (smaa_kernel.hip) -- instead of weights()
+extern "C" void harness_smaa_use_roles(int on) { use_roles = on; }
+template <class B>
+static uint32_t weights_by_roles(const B& b, const smaa::Preset& P, int x, int y)
+{
+    const float X = (float)x, Y = (float)y;
+    const smaa::F2 e = b.own_edges(x, y);
+    smaa::F2 d1{0.0f, 0.0f}, d2{0.0f, 0.0f}, north{0.0f, 0.0f}, west{0.0f, 0.0f};
+    if (b.has_diag_part(e)) d1 = b.part_diag(X, Y, e, 1u);
+    if (b.has_diag_part(e)) d2 = b.part_diag(X, Y, e, 2u);
+    if (e.y > 0.0f) north = b.part_north(X, Y);
+    if (e.x > 0.0f) west = b.part_west(X, Y);
+    return B::combine(e, P.max_steps_diag > 0, smaa::F2{d1.x + d2.x, d1.y + d2.y}, north, west);
+}
 extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, const uint16_t* area, const uint8_t* search, uint16_t* edges,
                             uint32_t* blend, uint32_t* screen)
 {
@@ -48,7 +63,7 @@ extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, con
 #pragma omp parallel for schedule(dynamic, 4)
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++)
-                blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? B.weights(x, y) : (0x9e3779b9u * (uint32_t)(y * w + x + 1)) | 0x01010101u;
+                blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? (use_roles ? weights_by_roles(B, P, x, y) : B.weights(x, y)) : (0x9e3779b9u * (uint32_t)(y * w + x + 1)) | 0x01010101u;
 #pragma omp parallel for
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) {
@@ -64,7 +79,7 @@ extern "C" int harness_smaa(const uint32_t* color, int w, int h, int preset, con
     const smaa::Blend B{V, P, planes, src};
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? B.weights(x, y) : 0u;
+        for (int x = 0; x < w; x++) blend[(size_t)y * w + x] = edges[(size_t)y * w + x] ? (use_roles ? weights_by_roles(B, P, x, y) : B.weights(x, y)) : 0u;
 #pragma omp parallel for
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {

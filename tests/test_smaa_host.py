@@ -34,6 +34,20 @@ def test_traced_frames_byte_exact(built, tables, kind, w, h, depth, preset):
     _same(harness.smaa(img, preset, *tables), smaa.run(img, preset, *tables))
 
 
+@pytest.mark.parametrize("planes", [True, False])
+@pytest.mark.parametrize("preset", ["HIGH", "ULTRA", "MEDIUM"])
+def test_weights_composed_from_independent_parts_are_the_same_bytes(built, tables, preset, planes):
+    """smaa_weights_roles_kernel (round 4) gives the diagonal part -- once per pair of diagonals --, the north part and the west part of a
+    pixel to four waves and applies the shader's selection rule to the results (smaa::BlendT::combine). The same composition on the host
+    must give weights()' bytes: on patterns with every slope (diagonals of both orientations, crossing ones), on traced frames, odd sizes."""
+    frames = [smaa_cases.pattern(seed, w, h) for seed, w, h in ((1, 320, 200), (2, 203, 131), (7, 97, 160), (4, 5, 3))]
+    frames += [smaa_cases.traced("default", 256, 144, 4), smaa_cases.traced("torus", 224, 126, 6)]
+    for img in frames:
+        a = harness.smaa(img, preset, *tables, planes=planes, roles=True)
+        _same(a, harness.smaa(img, preset, *tables, planes=planes))
+        _same(a, smaa.run(img, preset, *tables))
+
+
 def test_random_tables_and_noise_byte_exact(built):
     """Arbitrary table contents and pure noise frames: no structure to hide an indexing error behind."""
     rng = np.random.default_rng(9)

@@ -28,7 +28,7 @@ def main():
     for _ in range(4):
         gl.smaa_resolve()
     gl.finish()
-    buf = np.zeros((4096, 12), dtype=np.uint64)
+    buf = np.zeros((8192, 12), dtype=np.uint64)[:8192]
     assert fn(buf.ctypes.data) == 0
     t = buf.astype(np.float64)
     t0 = t[:, 0].min()
