@@ -991,6 +991,9 @@ RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t
 
 // ---- general quadric (rt.frag:499-572) ----
 RT_HD bool is_between(f3 v, f3 lo, f3 hi) { return (v.x > lo.x && v.y > lo.y && v.z > lo.z) && (v.x < hi.x && v.y < hi.y && v.z < hi.z); }
+// WAVE = false (tools/audit only): the early exits below are taken by each lane on its own condition, so that an audit whose lanes hold
+// unrelated rays exercises them for every ray (a wave of the product leaves only if ALL its lanes may).
+template <bool WAVE = true>
 RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t)
 {
     const bool ident = ident_flag(Q.vmax.w);
@@ -1010,7 +1013,11 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
     // has a real root (the line misses the unclipped quadric: common for the lanes a bounding sphere lets through) stops here, before the
     // square root, the two divisions and the clip tests; t is left as the long way round leaves it.
     const float disc = p1 * p1 - 4.0f * p2 * p3;
-    if (!RT_ANY(!(disc < 0.0f) || tmin > RT_FLT_MAX)) { t = RT_FLT_MAX; return false; }
+    // (Round 4 also tried leaving here for real roots of which provably none lies above epsilon -- Descartes' rule on the float values p1, p2, p3,
+    // and the noise case F(origin) ~ 0 of a quadric's own shadow rays: exact, 8 % of all rays and 41 % of those that start on their quadric
+    // leave by it, audited on 2e10 rays -- and measured no gain: a wave leaves only if ALL its lanes may. profiles/r04a_solver_sweep_ab.txt item 10.)
+    const bool may_hit = !(disc < 0.0f) || tmin > RT_FLT_MAX;
+    if (!(WAVE ? RT_ANY(may_hit) : may_hit)) { t = RT_FLT_MAX; return false; }
     const float p4 = sqrtf(disc);
     float mn = RT_FLT_MAX, mx = RT_FLT_MAX;
     const float t1 = (-p1 - p4) / (2.0f * p2);

@@ -472,6 +472,7 @@ int smaa_alloc(rtx_context* ctx)
 {
     if (ctx->d_screen) return RTX_OK;
     const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
+    if (px >= (size_t(1) << 30)) return fail(RTX_ERR_INVALID, "SMAA: frames of 2^30 pixels or more are not supported (%d x %d)", ctx->width, ctx->height);   // edge-list entries: 30 bits of pixel index
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_screen), px * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_edges), px * 2));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_blend), px * 4));

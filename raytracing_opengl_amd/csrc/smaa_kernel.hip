@@ -343,9 +343,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     for (int half = 0; half < (STRIP_H * 4 + 31) / 32; half++) {
         unsigned long long m = any[half];
         while (m != 0ull) {                                                    // this lane's own slots (divergent, a handful at most)
-            const int s = half * 32 + (__builtin_ctzll(m) >> 1);
+            const int k = __builtin_ctzll(m), s = half * 32 + (k >> 1);
             m &= m - 1ull;
-            *out++ = (uint32_t)((size_t)(y0 + (s >> 2)) * w + px + (s & 3));
+            // an entry: the pixel's index, and in bits 30 / 31 its own two edge bits (red = left edge, green = top edge), which the weight
+            // kernel would otherwise fetch with a load that depends on this one (round 4; frames below 2^30 pixels: smaa_alloc)
+            *out++ = (uint32_t)((size_t)(y0 + (s >> 2)) * w + px + (s & 3)) | ((uint32_t)((ebits[half] >> k) & 3ull) << 30);
         }
     }
     SMAA_EP(5);
@@ -380,6 +382,7 @@ struct SegmentedList {
         within = i - prefix[lo];
         return lo;
     }
+    static constexpr uint32_t PIXEL_MASK = 0x3fffffffu;   // entry = pixel index | own edge bits << 30 (red, green)
     __device__ __forceinline__ uint32_t entry(const SmaaBuffers& b, unsigned i) const
     {
         unsigned k;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void smaa_weights_kernel(SmaaBuffers b, int pr
     const smaa::TexEdges src{b.edges, b.w};
     const smaa::Blend B{V, P, planes, src};
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = L.entry(b, i);
+        const uint32_t p = L.entry(b, i) & SegmentedList::PIXEL_MASK;
         const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
 #ifdef SMAA_PHASE_TIMES
         g_smaa_ph[blockIdx.x * 4 + (threadIdx.x >> 6)][8] = 1ull;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void smaa_weights_roles_kernel(SmaaBuffers b, 
         // the parts the selection rule discards are plain extra work (pattern ULTRA 76 -> 96 us with the roles): one thread per pixel, all
         // parts in the shader's order, as in rounds 2-3.
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-            const uint32_t p = L.entry(b, i);
+            const uint32_t p = L.entry(b, i) & SegmentedList::PIXEL_MASK;
             const int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
             b.blend[p] = B.weights(x, y);
         }
@@ -509,10 +512,11 @@ __global__ __launch_bounds__(256) void smaa_weights_roles_kernel(SmaaBuffers b, 
         int x = 0, y = 0;
         smaa::F2 e{0.0f, 0.0f};
         if (valid) {
-            p = L.entry(b, i);
+            const uint32_t raw = L.entry(b, i);
+            p = raw & SegmentedList::PIXEL_MASK;
             y = (int)(p / (uint32_t)b.w);
             x = (int)(p - (uint32_t)y * (uint32_t)b.w);
-            e = B.own_edges(x, y);
+            e = smaa::F2{(raw & 0x40000000u) ? 1.0f : 0.0f, (raw & 0x80000000u) ? 1.0f : 0.0f};   // = own_edges(x, y): the texels are 0 or 255
         }
         const float X = (float)x, Y = (float)y;
         smaa::F2 r{0.0f, 0.0f};
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void smaa_blend_kernel(SmaaBuffers b, unsigned
     const unsigned items = n * 3u;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
         const unsigned which = i / n;                                           // all "itself" first, then the neighbours: coalesced list reads
-        const uint32_t p = L.entry(b, i - which * n);
+        const uint32_t p = L.entry(b, i - which * n) & SegmentedList::PIXEL_MASK;
         int y = (int)(p / (uint32_t)b.w), x = (int)(p - (uint32_t)y * (uint32_t)b.w);
         if (which == 1) x -= 1;
         if (which == 2) y -= 1;

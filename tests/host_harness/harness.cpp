@@ -322,6 +322,94 @@ int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float 
     return n_bad;
 }
 
+// The product's intersect_surface against the shader's sequence written out (rt.frag:513-572, no early exit) on rays that START on the
+// quadric -- the shadow and mirror rays of its own hits, where F(origin) is rounding noise of either sign and one root sits next to the
+// `t > 1e-4` test. Origins: hit
+// points of rays from outside, as the shader forms them (ro + t rd in float), half of them pushed off by 1e-7 ... 1e-3; directions: any,
+// a third of them grazing. counts: [0] rays, [1] hits (literal), [2] rays the product left early although the roots are real (none today), [3] MISMATCHES (hit flag, or t on a hit).
+static bool surface_literal(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t, bool& real_roots)
+{
+    const f3 ro = quat_rotate(Q.quat, ro_w - xyz(Q.pos_a));
+    const f3 rd = quat_rotate(Q.quat, rd_w);
+    const float a = Q.pos_a.w, b = Q.bcde.x, c = Q.bcde.y, d = Q.bcde.z, e = Q.bcde.w, f = Q.f_vmin.x;
+    const float d1 = rd.x, d2 = rd.y, d3 = rd.z, o1 = ro.x, o2 = ro.y, o3 = ro.z;
+    const float p1 = 2.0f * a * d1 * o1 + 2.0f * b * d2 * o2 + 2.0f * c * d3 * o3 + d * d3 + d2 * e;
+    const float p2 = a * d1 * d1 + b * d2 * d2 + c * d3 * d3;
+    const float p3 = a * o1 * o1 + b * o2 * o2 + c * o3 * o3 + d * o3 + e * o2 + f;
+    real_roots = false;
+    if (fabsf(p2) < 1e-6f) { t = -p3 / p1; return t > tmin; }
+    const float disc = p1 * p1 - 4.0f * p2 * p3;
+    real_roots = !(disc < 0.0f);
+    const float p4 = sqrtf(disc);
+    float mn = RT_FLT_MAX, mx = RT_FLT_MAX;
+    const float t1 = (-p1 - p4) / (2.0f * p2), t2 = (-p1 + p4) / (2.0f * p2);
+    const float epsilon = 1e-4f;
+    if (t1 > epsilon && t1 < mn) { mn = t1; mx = t2; }
+    if (t2 > epsilon && t2 < mn) { mn = t2; mx = t1; }
+    const f3 vmin = mk3(Q.f_vmin.y, Q.f_vmin.z, Q.f_vmin.w), vmax = xyz(Q.vmax);
+    f3 pt = rd_w * mn + ro_w;
+    if (!is_between(pt, vmin, vmax)) {
+        if (mx < epsilon) return false;
+        pt = rd_w * mx + ro_w;
+        if (!is_between(pt, vmin, vmax)) return false;
+        const float tmp = mn; mn = mx; mx = tmp;
+    }
+    t = mn;
+    return t < tmin;
+}
+int harness_quadric_self_rays(const void* record, int64_t n, uint64_t seed, float extent, int64_t counts[4], float* bad, int max_bad)
+{
+    rtpack::Defines d;
+    std::memset(&d, 0, sizeof d);
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    blocks[rtpack::BLK_SCENE].assign(64, 0);
+    d.surface_size = 1;
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    blocks[rtpack::BLK_SURFACES].assign(p, p + rtpack::kRecordSize[rtpack::BLK_SURFACES]);
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(d, blocks, blob, err)) return -2;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
+    const DevSurface Q = S.surfaces()[0];
+    int64_t c_rays = 0, c_hit = 0, c_exit = 0, c_bad = 0;
+    int n_bad = 0;
+#pragma omp parallel for schedule(static, 4096) reduction(+ : c_rays, c_hit, c_exit, c_bad)
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t x = seed * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(k) * 0xbf58476d1ce4e5b9ull + 1;
+        auto u01 = [&]() { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return (x >> 11) * (1.0 / 9007199254740992.0); };
+        auto gauss = [&]() { double a = 0; for (int i = 0; i < 6; i++) a += u01(); return (a - 3.0) * 1.41421356; };
+        auto unit = [&]() { double ux = gauss(), uy = gauss(), uz = gauss(); const double l = std::sqrt(ux * ux + uy * uy + uz * uz) + 1e-30; return mk3((float)(ux / l), (float)(uy / l), (float)(uz / l)); };
+        const float dist = (float)(0.05 * std::pow(200.0 / 0.05, u01()));
+        const f3 cen = xyz(Q.pos_a);
+        const f3 o0 = cen + unit() * dist;
+        f3 aim = cen + mk3((float)gauss(), (float)gauss(), (float)gauss()) * (extent * 0.8f) - o0;
+        const f3 d0 = aim * (1.0f / (length3(aim) + 1e-30f));
+        float th = 0.0f;
+        bool rr = false;
+        if (!surface_literal(Q, o0, d0, RT_FLT_MAX, th, rr) || !(th < 1.0e4f)) continue;
+        f3 ro = d0 * th + o0;
+        if (u01() < 0.5) ro = ro + unit() * (float)(u01() < 0.5 ? 1e-7 * std::pow(1e3, u01()) : 1e-4 * std::pow(10.0, u01()));
+        f3 rd = unit();
+        if (u01() < 0.3) { const f3 g = rd - d0 * dot3(rd, d0) + d0 * (float)(0.02 * (2.0 * u01() - 1.0)); rd = g * (1.0f / (length3(g) + 1e-30f)); }
+        const float tmin = u01() < 0.5 ? RT_FLT_MAX : (float)std::pow(10.0, -3.0 + 4.7 * u01());
+        float t_lit = 0.0f, t_prod = 0.0f;
+        const bool hit = surface_literal(Q, ro, rd, tmin, t_lit, rr);
+        const bool hit_p = intersect_surface(Q, ro, rd, tmin, t_prod);   // host build: every early exit on the ray's own condition
+        c_rays++; c_hit += hit;
+        const float fmax = RT_FLT_MAX;
+        c_exit += !hit_p && rr && std::memcmp(&t_prod, &fmax, 4) == 0;
+        if (hit != hit_p || (hit && std::memcmp(&t_lit, &t_prod, 4) != 0)) {
+            c_bad++;
+#pragma omp critical
+            if (n_bad < max_bad) { float* o = bad + 7 * n_bad++; o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = tmin; }
+        }
+    }
+    counts[0] = c_rays; counts[1] = c_hit; counts[2] = c_exit; counts[3] = c_bad;
+    return n_bad;
+}
+
 // The candidate tables (ray pencils, slab tables) primitive by primitive: n random rays of three kinds -- from the camera (pencil 0), from
 // random points towards every light with a pencil, and arbitrary rays (slab tables) -- and for each ray every quadric and torus:
 // if the un-culled intersector reports a hit, the primitive's bit must be set in the ray's candidate mask.

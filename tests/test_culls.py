@@ -328,6 +328,28 @@ def test_quadric_cull_premise_in_bulk(built, clip):
         assert (culled > 50000) if (hi <= 50 or len(clip) == 3) else (culled == 0), (clip, lo, culled)
 
 
+@pytest.mark.parametrize("clip", [(1,), (0, 1, 2), ()])
+def test_quadric_intersector_on_rays_that_start_on_the_quadric(built, clip):
+    """The product's intersect_surface (with its early exit for rays without a real root, taken per ray in the host build) against the
+    shader's sequence written out (rt.frag:513-572), on the rays where the two are most likely to part: rays that START on the quadric --
+    its own shadow and mirror rays, where F(origin) is rounding noise of either sign and one root sits at t ~ 0 +- 1e-6 next to the
+    `t > 1e-4` test -- hit points as the shader forms them, half of them pushed off by 1e-7 ... 1e-3, any direction, a third grazing:
+    same hit flag, same t bits."""
+    import ctypes
+    L = _premise_lib()
+    L.harness_quadric_self_rays.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    rng = np.random.default_rng(3)
+    rays = exits = 0
+    for k in range(6):
+        rec = _clipped_quadric(rng, _QUADRICS[k], clip)
+        cnt, bad = (ctypes.c_int64 * 4)(), (ctypes.c_float * 28)()
+        L.harness_quadric_self_rays(ctypes.create_string_buffer(rec, len(rec)), 300000, k + 1, 3.0, cnt, bad, 4)
+        assert cnt[3] == 0, (k, clip, list(cnt), list(bad[:7]))
+        rays += cnt[0]
+        exits += cnt[2]
+    assert rays > 300000, rays
+
+
 def test_open_clip_box_far_origin_regression(built):
     """The pencil-scene fuzz case (seed 966): an elliptic cylinder of radius 0.5 clipped in world y only, its axis 1.4e-3 rad off the
     slab, seen from 3000 units away. The reference's float arithmetic reports a hit 1400 units along the axis -- 300 beyond the end of the

@@ -346,9 +346,10 @@ __device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, uns
 // quadrics: surface_cull (segment test, tight / far bound, degenerate-branch margin), group sphere + quadric_may_degenerate, and the product's
 // intersect_surface (wave-level exit for waves without a real root) against the literal rt.frag:513-572
 // counters: 0 rays, 1 culled by surface_cull, 2 culled by the group test, 3 literal hits, 4 literal hits on the degenerate branch,
+//           5 rays the product's intersector leaves early (no real root),
 //           10 VIOLATIONS surface_cull, 11 group, 12 product intersector != literal (hit flag, or t on a hit)
 // ================================================================================================================================
-__device__ bool intersect_surface_literal(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t, bool& degenerate)
+__device__ bool intersect_surface_literal(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t, bool& degenerate, bool* real_roots = nullptr)
 {
     const f3 ro = quat_rotate(Q.quat, ro_w - xyz(Q.pos_a));
     const f3 rd = quat_rotate(Q.quat, rd_w);
@@ -358,7 +359,9 @@ __device__ bool intersect_surface_literal(const DevSurface& Q, f3 ro_w, f3 rd_w,
     const float p2 = a * d1 * d1 + b * d2 * d2 + c * d3 * d3;
     const float p3 = a * o1 * o1 + b * o2 * o2 + c * o3 * o3 + d * o3 + e * o2 + f;
     degenerate = fabsf(p2) < 1e-6f;
+    if (real_roots) *real_roots = false;
     if (degenerate) { t = -p3 / p1; return t > tmin; }
+    if (real_roots) *real_roots = !(p1 * p1 - 4.0f * p2 * p3 < 0.0f);
     const float p4 = sqrtf(p1 * p1 - 4.0f * p2 * p3);
     float mn = RT_FLT_MAX, mx = RT_FLT_MAX;
     const float t1 = (-p1 - p4) / (2.0f * p2), t2 = (-p1 + p4) / (2.0f * p2);
@@ -424,9 +427,26 @@ __device__ void quadric_ray(Rng& R, const DevSurface& Q, const DevSurfaceCull& C
         const f3 d = grazing_dir(R, n);
         ro = pb - d * (far ? R.logu(60.0f, 3000.0f) : R.logu(0.01f, 60.0f));
         rd = d;
-    } else {                                  // origins around the switch between the two bounds (RT_QUADRIC_FAR +- 10)
+    } else if (mode == 7) {                   // origins around the switch between the two bounds (RT_QUADRIC_FAR +- 10)
         ro = c + R.unit() * ((float)RT_QUADRIC_FAR + 10.0f * R.sym());
         rd = normalize3(c + mk3(R.gauss(), R.gauss(), R.gauss()) * (ext * 1.5f) - ro);
+    } else {                                  // rays that START on the quadric (shadow / mirror rays of its own hits: F(origin) is rounding noise of
+                                              // either sign -- what the sign-based exit of intersect_surface judges): a hit point of the literal
+                                              // intersector, as the shader forms it, left where it is or pushed off by up to 1e-3; any direction
+        f3 o0 = c + R.unit() * R.logu(0.05f, 200.0f);
+        f3 d0 = normalize3(c + mk3(R.gauss(), R.gauss(), R.gauss()) * (ext * 0.8f) - o0);
+        float th = 0.0f;
+        bool dg = false;
+        if (intersect_surface_literal(Q, o0, d0, RT_FLT_MAX, th, dg) && th < 1.0e4f) {
+            ro = d0 * th + o0;
+            if (R.u01() < 0.5f) ro = ro + R.unit() * (R.u01() < 0.5f ? R.logu(1.0e-7f, 1.0e-4f) : R.logu(1.0e-4f, 1.0e-3f));
+            rd = R.unit();
+            if (R.u01() < 0.3f) rd = normalize3(rd - d0 * dot3(rd, d0) + d0 * (0.02f * R.sym()));   // grazing the incoming ray's normal plane, roughly
+            if (R.u01() < 0.5f) tmin = R.logu(1.0e-3f, 50.0f);
+        } else {
+            ro = o0;
+            rd = d0;
+        }
     }
 }
 __device__ void audit_quadric(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
@@ -442,14 +462,15 @@ __device__ void audit_quadric(const AuditParams& p, const SceneView& S, unsigned
         const DevSurfaceCull C = S.surf_cull()[i];
         f3 ro, rd;
         float tmin;
-        quadric_ray(R, Q, C, (int)(R.next() & 7ull), ro, rd, tmin);
+        quadric_ray(R, Q, C, (int)(R.next() % 10ull), ro, rd, tmin);
         const bool c_cull = surface_cull(C, ro, rd, tmin);
         const bool c_group = grouped && surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd) && !quadric_may_degenerate(C, rd);
         float t_lit = 0.0f, t_prod = 0.0f;
-        bool deg = false;
-        const bool hit = intersect_surface_literal(Q, ro, rd, tmin, t_lit, deg);
-        const bool hit_p = intersect_surface(Q, ro, rd, tmin, t_prod);
+        bool deg = false, real_roots = false;
+        const bool hit = intersect_surface_literal(Q, ro, rd, tmin, t_lit, deg, &real_roots);
+        const bool hit_p = intersect_surface<false>(Q, ro, rd, tmin, t_prod);   // every lane takes the early exits on its own condition
         c[0]++; c[1] += c_cull; c[2] += c_group; c[3] += hit; c[4] += hit && deg;
+        c[5] += !hit_p && !real_roots && !deg;   // left by the product's exit for lanes without a real root
         if (c_cull && hit) { c[10]++; record_bad(p, 10, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
         if (c_group && hit) { c[11]++; record_bad(p, 11, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
         if (hit != hit_p || (hit && __builtin_bit_cast(unsigned, t_lit) != __builtin_bit_cast(unsigned, t_prod))) { c[12]++; record_bad(p, 12, i, ro, rd, tmin, t_lit, t_prod); }
