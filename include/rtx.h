@@ -80,9 +80,10 @@ typedef enum rtx_option {
     RTX_OPT_XCD_REMAP = 4,   /* 1: workgroups are dealt to the 8 XCDs in 128x32-pixel super-tiles (texture lines stay in
                                 one XCD's L2); 0 (default): plain row-major order. Measured on the 4K default scene:
                                 FETCH_SIZE 96.3 vs 97.5 MB, kernel 0.939 vs 0.902 ms -- no reuse to win, so it is off. */
-    RTX_OPT_HOT_ROWS_FIRST = 6, /* 1 (default): in rtx_draw_bands launches that cover a quarter of the frame or less (band_stride >= 4)
-                                the workgroup rows that show a torus -- tiles that run ~20x the median -- are dispatched first, so
-                                that they do not form the tail of the launch; 0: plain row order. Same results either way. */
+    RTX_OPT_HOT_ROWS_FIRST = 6, /* 1 (default): in launches of at most 24 000 workgroups (frames up to about 3200 x 1800) and in
+                                rtx_draw_bands launches that cover a quarter of the frame or less (band_stride >= 4) the workgroup
+                                rows that show a torus -- tiles that run ~20x the median -- are dispatched first, so that they do
+                                not form the tail of the launch; 0: plain row order. Same results either way. */
     RTX_OPT_GATHER_TARGETS = 7, /* multi-device contexts: which colour targets travel to the root each draw: 1 = RGBA32F only, 2 = RGBA8
                                 only (what the reference's framebuffer holds: a quarter of the bytes), 3 (default) = both */
     RTX_OPT_RAY_PENCILS = 8,  /* 1 (default): scenes with a long quadric / torus table (16 .. 128 entries) get per-pencil candidate masks --

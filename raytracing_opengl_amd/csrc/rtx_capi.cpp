@@ -383,7 +383,13 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     p.band_stride = band_stride;
     p.rows_local = rows_local;
     p.xcd_remap = ctx->opt_xcd;
-    if (ctx->opt_hot && !ctx->opt_xcd && band_stride >= 4) hot_rows(ctx, p);   // small launches only, see rt_kernel.hip
+    // Rows that show a torus first: for a rank's share of a frame (band_stride >= 4) and, round 4, for any launch of at most HOT_MAX_WG
+    // workgroups -- a small frame ends with its longest workgroups however few the others are (default scene, kernel us without / with:
+    // 1280x720 197 / 166, 1920x1080 230 / 202, 2560x1440 318 / 287, 3200x1800 372 / 363; 3840x2160 469 / 489: there plain row order wins,
+    // neighbouring rows run the same code). profiles/r04_hot_rows_small_frames.txt
+    constexpr int HOT_MAX_WG = 24000;
+    const int launch_wg = ((ctx->width + 31) / 32) * ((rows_local + 7) / 8);
+    if (ctx->opt_hot && !ctx->opt_xcd && (band_stride >= 4 || launch_wg <= HOT_MAX_WG)) hot_rows(ctx, p);
     p.out_f32 = out_f32;
     p.out_u8 = out_u8;
     p.counters = ctx->d_counters;
