@@ -275,7 +275,7 @@ def test_bench_multi_gpu_forms_run_through_the_c_boundary():
     assert len(cfg["trace_ms_per_rank"]) == 1 and cfg["rows_per_rank"] == [360] and cfg["gather_GB_s_into_rank0"] > 0 and cfg["clock_ramp"]["ms"] >= 100
     also = cfg["also_measured"]
     assert also["rgba8"]["ms_per_step"] > 0 and also["bands_balanced"]["ms_per_step"] > 0 and sum(also["bands_balanced"]["rows_per_rank"]) == 360
-    r, line = _run_bench(["--gpus", "1", "--transport", "loopback", "--bands", "balanced", "--target", "rgba8"])
+    r, line = _run_bench(["--gpus", "1", "--transport", "loopback", "--bands", "balanced", "--target", "rgba8", "--also-bands"])
     assert r.returncode == 0 and line and "weighted by kernel time" in line["config"]["parallelism"], r.stderr[-2000:]
     assert line["parity"]["vs_one_device_tracing_the_whole_frame"] == "bit-identical" and "bands_interleaved" in line["config"]["also_measured"]
     r, line = _run_bench(["--gpus", "1", "--transport", "loopback"], torchrun=True)
