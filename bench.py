@@ -184,6 +184,7 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     elapsed, trace_ms_max, gather_ms = timed(args.steps)
     ranks_trace_ms = rank_ms()
     layout_name = {"interleaved": "interleaved 8-row bands", "contiguous": "contiguous equal ranges", "balanced": "contiguous ranges weighted by kernel time"}[args.bands]
+    gather_rgb = bool(gl.get_option(wrapper.RTX_OPT_GATHER_RGB))
     split_used = gl.band_split()
     st_end = gl.stats()
 
@@ -245,7 +246,9 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
     ms_per_step = elapsed / args.steps * 1e3
     rows0 = split_used[0]
     achieved = rows0 * W * px_bytes / (trace_ms_max * 1e-3) / 1e9
-    moved = sum(split_used[r] for r in range(0 if args.transport == "loopback" else 1, n_ranks)) * W * px_bytes
+    # what travels per pixel: the float target of the interleaved layout goes without its alpha (RTX_OPT_GATHER_RGB, default on: 12 bytes)
+    link_px_bytes = 12 if (target == "rgba32f" and args.bands == "interleaved" and gather_rgb) else px_bytes
+    moved = sum(split_used[r] for r in range(0 if args.transport == "loopback" else 1, n_ranks)) * W * link_px_bytes
     links = max(1, n_ranks - 1)
     out = {
         "metric": f"Mray/s at {W}x{H} depth-{args.depth} {args.scene} scene (reference-defined rays: closest-hit + shadow scans)",
@@ -271,7 +274,7 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
                                  "loopback": "RCCL incl. rank 0 -> rank 0 (diagnostic)",
                                  "peer": "hipMemcpyPeerAsync issued by rank 0 (librtx_hip.so)"}[args.transport],
                    "trace_ms_max_rank": round(trace_ms_max, 4), "trace_ms_per_rank": [round(v, 4) for v in ranks_trace_ms], "rows_per_rank": split_used,
-                   "gather_ms": round(gather_ms, 4), "gather_bytes_per_frame": int(moved),
+                   "gather_ms": round(gather_ms, 4), "gather_bytes_per_frame": int(moved), "gather_bytes_per_pixel": link_px_bytes,
                    "gather_GB_s_into_rank0": round(moved / max(gather_ms, 1e-6) / 1e6, 1), "gather_GB_s_per_link": round(moved / links / max(gather_ms, 1e-6) / 1e6, 1),
                    "also_measured": extras,
                    "cull": args.cull, "scene_in_lds": args.lds, "texture_lod": args.lod, "xcd_remap": args.xcd,

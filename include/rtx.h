@@ -97,6 +97,11 @@ typedef enum rtx_option {
                                 straight into place -- no landing buffers, no placement pass. 2: as 1, and the library moves the boundaries
                                 towards equal kernel times (rates of two frames back; single-process contexts only). Same pixels in every
                                 layout. A per-process group (rtx_create_rank) must set the same value on every rank. */
+    RTX_OPT_GATHER_RGB = 10,  /* multi-device contexts, interleaved layout: 1 (default): the RGBA32F bands travel to the root WITHOUT their alpha
+                                channel -- 12 bytes per pixel instead of 16; the traced frame's alpha is the constant 1.0f (rt.frag:902) and the
+                                root writes it back while it places the bands, so the assembled frame is bit-identical; 0: 16 bytes per
+                                pixel. At N = 2 ... 4 the frame rate of the float target is the rate of the root's links.
+                                The contiguous layouts receive in place and always move whole pixels. */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which build of the trace kernel runs: 0 = the default one, 1 = the many-primitive one (group culls, ray
                                 pencils and slab tables compiled in; its own register budget -- 7 waves/SIMD in round 1, hence the
                                 name, 6 now), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */

@@ -15,7 +15,7 @@ RTX_OK = 0
 RTX_RGBA32F, RTX_RGBA8, RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_WEIGHTS_RGBA8 = 0, 1, 2, 3, 4
 RTX_SMAA_OFF, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_HIGH, RTX_SMAA_ULTRA = -1, 0, 1, 2, 3
 RTX_WRAP_REPEAT, RTX_WRAP_CLAMP_TO_EDGE = 0, 1
-RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_GATHER_TARGETS, RTX_OPT_RAY_PENCILS, RTX_OPT_BAND_LAYOUT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+RTX_OPT_CULL, RTX_OPT_COUNT_RAYS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_GATHER_TARGETS, RTX_OPT_RAY_PENCILS, RTX_OPT_BAND_LAYOUT, RTX_OPT_GATHER_RGB = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 RTX_GATHER_RCCL, RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL_LOOPBACK = 0, 1, 2
 RTX_RCCL_ID_BYTES = 128
 

@@ -20,7 +20,49 @@ __global__ __launch_bounds__(256) void unpack_kernel(const Unit* __restrict__ pa
     }
 }
 
+// The RGBA32F target without its alpha channel (round 4). The tracer writes vec4(colour, 1.0) (rt.frag:902, rt_device.h trace_pixel), so a
+// rank's float bands travel as 12 bytes per pixel and the root writes the 1.0f back while it places them: a quarter less on the link that
+// bounds the frame rate at N = 2 ... 4. One pixel per thread: a wave reads 1 KiB and writes 768 contiguous bytes (pack),
+// or the reverse (place).
+__global__ __launch_bounds__(256) void pack_rgb_kernel(const float4* __restrict__ rgba, float* __restrict__ rgb, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = rgba[i];
+        rgb[3 * i] = v.x;
+        rgb[3 * i + 1] = v.y;
+        rgb[3 * i + 2] = v.z;
+    }
+}
+__global__ __launch_bounds__(256) void unpack_rgb_kernel(const float* __restrict__ rgb, float4* __restrict__ frame, int fb_w, int fb_h, int band_rows,
+                                                         int band_first, int band_stride, int rows_local)
+{
+    const size_t n = (size_t)rows_local * (size_t)fb_w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int lr = (int)(i / (size_t)fb_w), x = (int)(i - (size_t)lr * (size_t)fb_w);
+        const int j = lr / band_rows;
+        const int y = (band_first + j * band_stride) * band_rows + (lr - j * band_rows);
+        if (y < fb_h) frame[(size_t)y * (size_t)fb_w + (size_t)x] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.0f);
+    }
+}
+
 }  // namespace
+
+hipError_t bands_pack_rgb(const void* rgba32f, void* rgb32f, size_t n_pixels, hipStream_t stream)
+{
+    if (n_pixels == 0) return hipSuccess;
+    const int blocks = (int)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_rgb_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const float4*>(rgba32f), static_cast<float*>(rgb32f), n_pixels);
+    return hipGetLastError();
+}
+hipError_t bands_unpack_rgb(const void* rgb32f, void* frame_rgba32f, int fb_w, int fb_h, int band_rows, int band_first, int band_stride, int rows_local, hipStream_t stream)
+{
+    if (rows_local <= 0) return hipSuccess;
+    const size_t n = (size_t)rows_local * (size_t)fb_w;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(unpack_rgb_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const float*>(rgb32f), static_cast<float4*>(frame_rgba32f), fb_w, fb_h, band_rows,
+                       band_first, band_stride, rows_local);
+    return hipGetLastError();
+}
 
 hipError_t bands_unpack(const void* packed, void* frame, int fb_w, int fb_h, int px_bytes, int band_rows, int band_first, int band_stride, int rows_local,
                         hipStream_t stream)

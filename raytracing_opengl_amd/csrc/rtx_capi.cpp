@@ -161,6 +161,9 @@ struct rtx_context {
     bool loopback = false;             // RTX_GATHER_RCCL_LOOPBACK: rank 0's own bands travel through the transport too
     int gather_kind = RTX_GATHER_RCCL;
     int gather_targets = 3;            // bit 0: RGBA32F, bit 1: RGBA8 travel to the root (RTX_OPT_GATHER_TARGETS)
+    int gather_rgb = 1;                // RTX_OPT_GATHER_RGB: the RGBA32F bands of the interleaved layout travel without their alpha (the constant 1.0f)
+    void* d_rgb[2] = {nullptr, nullptr};   // [frame parity] this rank's float bands at 12 bytes per pixel, what is sent then (lazily allocated)
+    hipEvent_t rgb_packed[2] = {nullptr, nullptr};   // recorded on the rank's transfer stream behind the pack kernel (peer-copy transport: the root waits for it)
     int band_rows = 8;                 // rows per band of the interleaved split: the kernel's tile height, the finest interleave
     // RTX_OPT_BAND_LAYOUT: 0 = interleaved bands (above); 1 = ONE contiguous range of rows per rank (split_start / split_rows, multiples of
     // 8), the root traces its range straight into the colour targets and the peers' ranges are received straight into place -- no landing
@@ -670,6 +673,8 @@ int ensure_packed(rtx_context* c, const rtx_context* frame)
             c->d_packed[t][q] = nullptr;
             HIP_TRY(hipMalloc(&c->d_packed[t][q], need * frame->width * target_bytes(t)));
         }
+    for (int q = 0; q < 2; q++)
+        if (c->d_rgb[q]) { HIP_TRY(hipFree(c->d_rgb[q])); c->d_rgb[q] = nullptr; HIP_TRY(hipEventDestroy(c->rgb_packed[q])); c->rgb_packed[q] = nullptr; }   // re-made at the new size
     c->packed_cap_rows = need;
     return RTX_OK;
 }
@@ -834,6 +839,24 @@ int multi_draw(rtx_context* me)
         if ((st = use_device(me)) != RTX_OK) return st;
         HIP_TRY(hipEventRecord(me->gather_start, me->xfer_stream));
     }
+    // The float target without its alpha: every rank whose bands travel packs them to 12 bytes per pixel on its transfer stream (behind its
+    // trace, beside the next one), and that is what is sent; the root writes the 1.0f back while it places the bands.
+    const bool rgb = me->gather_rgb != 0 && (me->gather_targets & 1) != 0;
+    auto bytes_moved = [&](int t, size_t rows) { return rows * me->width * (t == 0 && rgb ? size_t(12) : target_bytes(t)); };
+    if (rgb)
+        for (rtx_context* c : local) {
+            if (c->rank < first_moved) continue;
+            if ((st = use_device(c)) != RTX_OK) return st;
+            const size_t rows = static_cast<size_t>(rows_of_rank(me, c->rank));
+            for (int q = 0; q < 2; q++)
+                if (!c->d_rgb[q]) {
+                    HIP_TRY(hipMalloc(&c->d_rgb[q], (c->packed_cap_rows ? c->packed_cap_rows : rows + 8) * me->width * 12));
+                    HIP_TRY(hipEventCreateWithFlags(&c->rgb_packed[q], hipEventDisableTiming));
+                }
+            HIP_TRY(bands_pack_rgb(c->d_packed[0][par], c->d_rgb[par], rows * me->width, c->xfer_stream));
+            HIP_TRY(hipEventRecord(c->rgb_packed[par], c->xfer_stream));
+        }
+    auto send_buffer = [&](rtx_context* c, int t) { return t == 0 && rgb ? c->d_rgb[par] : c->d_packed[t][par]; };
     if (uses_rccl(me)) {
         if (N > first_moved) {
             NCCL_TRY(g_rccl.GroupStart());
@@ -842,25 +865,25 @@ int multi_draw(rtx_context* me)
                 const size_t rows = static_cast<size_t>(rows_of_rank(me, c->rank));
                 for (int t = 0; t < 2; t++)
                     if ((me->gather_targets >> t) & 1)
-                        NCCL_TRY_IN_GROUP(g_rccl.Send(c->d_packed[t][par], rows * me->width * target_bytes(t), ncclUint8, 0, c->comm, c->xfer_stream));
+                        NCCL_TRY_IN_GROUP(g_rccl.Send(send_buffer(c, t), bytes_moved(t, rows), ncclUint8, 0, c->comm, c->xfer_stream));
             }
             if (root_here)
                 for (int r = first_moved; r < N; r++) {
                     const size_t rows = static_cast<size_t>(rows_of_rank(me, r));
                     for (int t = 0; t < 2; t++)
                         if ((me->gather_targets >> t) & 1)
-                            NCCL_TRY_IN_GROUP(g_rccl.Recv(me->d_stage[t][par][r], rows * me->width * target_bytes(t), ncclUint8, r, me->comm, me->xfer_stream));
+                            NCCL_TRY_IN_GROUP(g_rccl.Recv(me->d_stage[t][par][r], bytes_moved(t, rows), ncclUint8, r, me->comm, me->xfer_stream));
                 }
             NCCL_TRY(g_rccl.GroupEnd());
         }
     } else {
         for (int r = 1; r < N; r++) {
             rtx_context* c = rank_ctx(me, r);
-            HIP_TRY(hipStreamWaitEvent(me->xfer_stream, c->traced[par], 0));
+            HIP_TRY(hipStreamWaitEvent(me->xfer_stream, rgb ? c->rgb_packed[par] : c->traced[par], 0));
             const size_t rows = static_cast<size_t>(rows_of_rank(me, r));
             for (int t = 0; t < 2; t++) {
                 if (!((me->gather_targets >> t) & 1)) continue;
-                HIP_TRY(hipMemcpyPeerAsync(me->d_stage[t][par][r], me->device, c->d_packed[t][par], c->device, rows * me->width * target_bytes(t), me->xfer_stream));
+                HIP_TRY(hipMemcpyPeerAsync(me->d_stage[t][par][r], me->device, send_buffer(c, t), c->device, bytes_moved(t, rows), me->xfer_stream));
             }
         }
     }
@@ -870,7 +893,8 @@ int multi_draw(rtx_context* me)
                 if (!((me->gather_targets >> t) & 1)) continue;
                 const void* src = r < first_moved ? me->d_packed[t][par] : me->d_stage[t][par][r];
                 void* dst = t == 0 ? static_cast<void*>(me->d_fb_f32) : static_cast<void*>(me->d_fb_u8);
-                HIP_TRY(bands_unpack(src, dst, me->width, me->height, static_cast<int>(target_bytes(t)), me->band_rows, r, N, rows_of_rank(me, r), me->xfer_stream));
+                if (t == 0 && rgb && r >= first_moved) HIP_TRY(bands_unpack_rgb(src, dst, me->width, me->height, me->band_rows, r, N, rows_of_rank(me, r), me->xfer_stream));
+                else HIP_TRY(bands_unpack(src, dst, me->width, me->height, static_cast<int>(target_bytes(t)), me->band_rows, r, N, rows_of_rank(me, r), me->xfer_stream));
             }
         HIP_TRY(hipEventRecord(me->gather_stop, me->xfer_stream));
         me->gather_timed = true;
@@ -1223,6 +1247,8 @@ void rtx_destroy(rtx_context* ctx)
                 if (q) (void)hipFree(q);
         }
     for (int p = 0; p < 2; p++) {
+        if (ctx->d_rgb[p]) (void)hipFree(ctx->d_rgb[p]);
+        if (ctx->rgb_packed[p]) (void)hipEventDestroy(ctx->rgb_packed[p]);
         if (ctx->traced[p]) (void)hipEventDestroy(ctx->traced[p]);
         if (ctx->moved[p]) (void)hipEventDestroy(ctx->moved[p]);
     }
@@ -1442,6 +1468,10 @@ int rtx_set_option(rtx_context* ctx, int option, int value)
         case RTX_OPT_HOT_ROWS_FIRST: ctx->opt_hot = value != 0; break;
         case RTX_OPT_RAY_PENCILS: if (ctx->opt_pencils != (value != 0)) ctx->scene_dirty = true; ctx->opt_pencils = value != 0; break;   // masks are (re)built with the scene
         case RTX_OPT_GATHER_TARGETS: if (value < 1 || value > 3) return fail(RTX_ERR_INVALID, "RTX_OPT_GATHER_TARGETS: 1, 2 or 3"); ctx->gather_targets = value; break;
+        case RTX_OPT_GATHER_RGB:
+            if (ctx->gather_rgb != (value != 0) && ctx->banded && !ctx->owner) { int st = multi_sync(ctx); if (st) return st; }   // frames in flight finish as they started
+            ctx->gather_rgb = value != 0;
+            break;
         case RTX_OPT_BAND_LAYOUT:
             if (value < 0 || value > 2) return fail(RTX_ERR_INVALID, "RTX_OPT_BAND_LAYOUT: 0 (interleaved), 1 (contiguous) or 2 (contiguous, re-balanced)");
             if (value == 2 && ctx->per_process) return fail(RTX_ERR_INVALID, "RTX_OPT_BAND_LAYOUT 2 needs all ranks in one process (rtx_create_multi): a per-process group "
@@ -1472,6 +1502,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_HOT_ROWS_FIRST: *value = ctx->opt_hot; break;
         case RTX_OPT_RAY_PENCILS: *value = ctx->opt_pencils; break;
         case RTX_OPT_GATHER_TARGETS: *value = ctx->gather_targets; break;
+        case RTX_OPT_GATHER_RGB: *value = ctx->gather_rgb; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;

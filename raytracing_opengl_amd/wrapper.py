@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from ._capi import (RTX_OPT_BAND_LAYOUT, RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL, RTX_GATHER_RCCL_LOOPBACK, RTX_OPT_GATHER_TARGETS, RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_RAY_PENCILS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
+from ._capi import (RTX_OPT_BAND_LAYOUT, RTX_OPT_GATHER_RGB, RTX_GATHER_PEER_COPY, RTX_GATHER_RCCL, RTX_GATHER_RCCL_LOOPBACK, RTX_OPT_GATHER_TARGETS, RTX_OPT_COUNT_RAYS, RTX_OPT_CULL, RTX_OPT_HIGH_OCCUPANCY, RTX_OPT_HOT_ROWS_FIRST, RTX_OPT_RAY_PENCILS, RTX_OPT_SCENE_LDS, RTX_OPT_TEXTURE_LOD, RTX_OPT_XCD_REMAP, RTX_RGBA8, RTX_RGBA32F,
                     RTX_SCREEN_RGBA8, RTX_SMAA_EDGES_RG8, RTX_SMAA_HIGH, RTX_SMAA_LOW, RTX_SMAA_MEDIUM, RTX_SMAA_OFF, RTX_SMAA_ULTRA, RTX_SMAA_WEIGHTS_RGBA8,
                     RTX_WRAP_CLAMP_TO_EDGE, RTX_WRAP_REPEAT)
 
@@ -171,6 +171,11 @@ class GLWrapper:
     # --- draw / read back -----------------------------------------------------------------
     def set_option(self, option: int, value: int):
         _check(self._lib.rtx_set_option(self._ctx, option, value), "set_option")
+
+    def get_option(self, option: int) -> int:
+        v = ctypes.c_int(0)
+        _check(self._lib.rtx_get_option(self._ctx, option, ctypes.byref(v)), "get_option")
+        return v.value
 
     def draw(self):
         """GLWrapper::draw (GLWrapper.cpp:155-165), asynchronous on the context's stream."""

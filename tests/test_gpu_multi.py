@@ -47,6 +47,31 @@ def test_peer_copy_group_reproduces_the_single_device_frame(small_textures, rank
         assert gst["last_gather_ms"] > 0.0
 
 
+@pytest.mark.parametrize("gather,devices", [(wrapper.RTX_GATHER_PEER_COPY, [0, 0, 0]), (wrapper.RTX_GATHER_RCCL_LOOPBACK, [0])])
+def test_float_bands_travel_without_their_alpha_or_with_it(small_textures, gather, devices):
+    """RTX_OPT_GATHER_RGB (default 1): the RGBA32F bands go to the root at 12 bytes per pixel -- a pack kernel on every sending rank's transfer
+    stream, the 1.0f written back by the placement on the root -- or, switched off between two frames, as whole pixels. Either way the
+    assembled frame is the single-device frame bit for bit, alpha included, at an odd width (rows of 333 x 12 bytes are not 16-byte units)."""
+    w, h, depth = 333, 207, 4
+    seq = [None, scenes.build_scene("default", w, h, depth, time=2.0, delta=0.1, yaw=10.0), None]
+    sc0 = scenes.build_scene("default", w, h, depth)
+    single = wrapper.make_renderer(sc0, w, h, small_textures["textures"], small_textures["cubemap"])
+    want = _frames(single, seq)
+    single.stop()
+    assert all(np.all(f32[..., 3] == 1.0) for f32, _, _ in want)          # what the option rests on (rt.frag:902)
+    group = wrapper.make_renderer(sc0, w, h, small_textures["textures"], small_textures["cubemap"], devices=devices, gather=gather)
+    assert group.get_option(wrapper.RTX_OPT_GATHER_RGB) == 1
+    for value in (1, 0, 1):
+        group.set_option(wrapper.RTX_OPT_GATHER_RGB, value)
+        assert group.get_option(wrapper.RTX_OPT_GATHER_RGB) == value
+        group.uploader.update(sc0)
+        got = _frames(group, seq)
+        for k, ((f32, u8, _), (g32, g8, _)) in enumerate(zip(want, got)):
+            assert np.array_equal(f32.view(np.uint32), g32.view(np.uint32)), (value, k, int((f32.view(np.uint32) != g32.view(np.uint32)).sum()))
+            assert np.array_equal(u8, g8), (value, k)
+    group.stop()
+
+
 @pytest.mark.parametrize("kind,w,h,depth,ranks", [("default", 640, 360, 4, 4), ("torus", 333, 207, 6, 3), ("quadric", 320, 100, 4, 2)])
 def test_contiguous_bands_reproduce_the_single_device_frame(small_textures, kind, w, h, depth, ranks):
     """RTX_OPT_BAND_LAYOUT 1 / 2 (round 4): one contiguous range of rows per rank, the root's range traced straight into the colour targets,
