@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
             const v4f v = {px.x, px.y, px.z, px.w};
             __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p.out_f32) + idx);
         }
-        if (p.out_u8) __builtin_nontemporal_store(pack_rgba8(px), p.out_u8 + idx);
+        // The 8-bit target is what the SMAA resolve reads right behind this kernel (33 MB at 4K): an ordinary store leaves it in the last-level
+        // cache for that reader -- resolve inside rtx_draw 56.6 -> 51.2 us, the trace itself unchanged (profiles/r04_u8_plain_store.txt); the
+        // float target above (133 MB, no reader on this device) stays non-temporal.
+        if (p.out_u8) p.out_u8[idx] = pack_rgba8(px);
     }
 #ifdef RT_PHASE_TIMERS
     if (lane == 0) {
