@@ -22,7 +22,9 @@ struct RtLaunchParams {
     rtdev::TexTable tex;
 };
 
-hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream);
+// ev_start / ev_stop (both or neither): receive the launch's own begin / end timestamps; ev_stop is also what to wait on for its completion
+hipError_t rt_launch_trace(const RtLaunchParams& p, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr);
 // Fills the ray-pencil masks of the scene at d_scene (host copy of its header and pencil records: n_pencil, cells). One thread per cell.
 hipError_t rt_launch_pencil_build(const char* d_scene, const rtdev::DevSceneHeader& hdr, const rtdev::DevPencil* pencils, uint32_t* d_masks, hipStream_t stream);
 hipError_t rt_launch_selftest(int* d_result, hipStream_t stream);

@@ -14,6 +14,8 @@
 #include "rt_device.h"
 #include "rt_kernel.h"
 
+#include <hip/hip_ext.h>
+
 using namespace rtdev;
 
 #ifdef RT_DK_STATS
@@ -257,7 +259,7 @@ __global__ void rt_selftest_kernel(int* result)
 }  // namespace
 
 template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU, bool HEAVY = false>
-static hipError_t launch_variant(const RtLaunchParams& p_in, dim3 grid, size_t shmem, hipStream_t stream)
+static hipError_t launch_variant(const RtLaunchParams& p_in, dim3 grid, size_t shmem, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     RtLaunchParams p = p_in;
     p.ps_fence_slot = rtdev::path_slots(ps_wide(WPE));   // the pad column behind this variant's path-state slots
@@ -266,11 +268,14 @@ static hipError_t launch_variant(const RtLaunchParams& p_in, dim3 grid, size_t s
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>), grid, dim3(256), shmem, stream, p);
+    // With events: the launch's own begin / end timestamps land in them (hipExtLaunchKernel) -- no marker packets in front of and behind the
+    // kernel, which cost the queue ~2.5 us each and keep consecutive launches from overlapping their ramp-down and ramp-up.
+    if (ev_start && ev_stop) hipExtLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>), grid, dim3(256), (uint32_t)shmem, stream, ev_start, ev_stop, 0, p);
+    else hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>), grid, dim3(256), shmem, stream, p);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream)
+hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bool lds, bool high_occupancy, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     RtLaunchParams p = p_in;
     dim3 grid((p.fb_w + 31) / 32, (p.rows_local + 7) / 8);
@@ -285,16 +290,16 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
     }
     const size_t shmem = lds ? (size_t)((p.scene_bytes + 15) & ~15) : 0;
     const int sel = (cull ? 4 : 0) | (count ? 2 : 0) | (lds ? 1 : 0);
-    if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY, true>(p, grid, shmem, stream);  // the product path only
+    if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY, true>(p, grid, shmem, stream, ev_start, ev_stop);  // the product path only
     switch (sel) {
-        case 0: return launch_variant<false, false, false>(p, grid, shmem, stream);
-        case 1: return launch_variant<false, false, true>(p, grid, shmem, stream);
-        case 2: return launch_variant<false, true, false>(p, grid, shmem, stream);
-        case 3: return launch_variant<false, true, true>(p, grid, shmem, stream);
-        case 4: return launch_variant<true, false, false>(p, grid, shmem, stream);
-        case 5: return launch_variant<true, false, true>(p, grid, shmem, stream);
-        case 6: return launch_variant<true, true, false>(p, grid, shmem, stream);
-        default: return launch_variant<true, true, true>(p, grid, shmem, stream);
+        case 0: return launch_variant<false, false, false>(p, grid, shmem, stream, ev_start, ev_stop);
+        case 1: return launch_variant<false, false, true>(p, grid, shmem, stream, ev_start, ev_stop);
+        case 2: return launch_variant<false, true, false>(p, grid, shmem, stream, ev_start, ev_stop);
+        case 3: return launch_variant<false, true, true>(p, grid, shmem, stream, ev_start, ev_stop);
+        case 4: return launch_variant<true, false, false>(p, grid, shmem, stream, ev_start, ev_stop);
+        case 5: return launch_variant<true, false, true>(p, grid, shmem, stream, ev_start, ev_stop);
+        case 6: return launch_variant<true, true, false>(p, grid, shmem, stream, ev_start, ev_stop);
+        default: return launch_variant<true, true, true>(p, grid, shmem, stream, ev_start, ev_stop);
     }
 }
 

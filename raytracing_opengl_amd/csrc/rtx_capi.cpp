@@ -405,7 +405,8 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
         ctx->ev_pending--;
     }
     const int e = ctx->ev_head;
-    HIP_TRY(hipEventRecord(ctx->ev_start[e], stream));
+    static const bool marker_events = getenv("RTX_MARKER_EVENTS") != nullptr;   // A/B: hipEventRecord around the launch, as until round 4
+    if (marker_events) HIP_TRY(hipEventRecord(ctx->ev_start[e], stream));
     // long primitive tables (quadric-/torus-heavy scenes): the 7-waves-per-SIMD build of the kernel hides the table walks
     const rtpack::Defines& df = ctx->defines;
     const int n_prims = df.sphere_size + df.plane_size + df.surface_size + df.box_size + df.torus_size + df.ring_size;
@@ -425,8 +426,12 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
         std::fprintf(stderr, "rtx: %d quadrics / %d tori: more than the %d of a kind the ray-pencil and slab tables hold -- two-level scans with group culls only "
                              "(same pixels, slower; rtx_stats.candidate_tables)\n", df.surface_size, df.torus_size, (int)RT_PENCIL_MAX_PRIMS);
     }
-    HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream));
-    HIP_TRY(hipEventRecord(ctx->ev_stop[e], stream));
+    if (marker_events) {
+        HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream));
+        HIP_TRY(hipEventRecord(ctx->ev_stop[e], stream));
+    } else {
+        HIP_TRY(rt_launch_trace(p, ctx->opt_cull != 0, ctx->opt_count != 0, ctx->opt_lds != 0, high_occ, stream, ctx->ev_start[e], ctx->ev_stop[e]));
+    }
     // "The last launch on this stream has finished", for whoever overwrites the scene from another stream (upload_scene): the launch's own
     // stop event, not a third event per draw (round 4: an event record costs the queue ~4 us per draw -- ms_per_step 0.4788 -> 0.4745). The
     // ring re-records an event only EVENT_RING launches later and waits for its old recording first (above), so a stream's entry never
