@@ -545,9 +545,7 @@ int smaa_resolve(rtx_context* ctx, hipStream_t stream)
     }
     if (stream != ctx->stream) return fail(RTX_ERR_INVALID, "the SMAA resolve runs on the context's own stream");
     const SmaaBuffers b = smaa_buffers(ctx, ctx->smaa_frame);
-    HIP_TRY(hipEventRecord(ctx->smaa_start, stream));
-    HIP_TRY(smaa_launch(b, ctx->smaa_preset, ctx->smaa_frame, stream));
-    HIP_TRY(hipEventRecord(ctx->smaa_stop, stream));
+    HIP_TRY(smaa_launch(b, ctx->smaa_preset, ctx->smaa_frame, stream, ctx->smaa_start, ctx->smaa_stop));   // the kernels' own timestamps
     ctx->smaa_frame++;
     ctx->smaa_timed = true;
     ctx->screen_valid = true;

@@ -35,6 +35,8 @@ struct SmaaBuffers {
 size_t smaa_segment_capacity(int w, int h);
 size_t smaa_plane_bytes(int w, int h);        // size of the row bit plane
 size_t smaa_col_plane_bytes(int w, int h);    // size of the column bit plane
-hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream);
+// ev_start / ev_stop (optional): the begin timestamp of the resolve's first kernel and the end timestamp of its last one land in them
+// (hipExtLaunchKernel: no marker packets between the tracer and the resolve); ev_stop is also what to wait on for the resolve.
+hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // For read-backs of RTX_SMAA_EDGES_RG8 / RTX_SMAA_WEIGHTS_RGBA8: fills `edges` from the bit plane and zeroes the weight texels of pixels without an edge.
 hipError_t smaa_expand(const SmaaBuffers& b, hipStream_t stream);

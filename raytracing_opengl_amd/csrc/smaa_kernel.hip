@@ -42,6 +42,8 @@
 
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #ifdef SMAA_PHASE_TIMES
 // diagnostic build (tools/smaa_phase_times.py): per wave of the last smaa_weights_kernel launch, s_memrealtime (10 ns ticks) at [0] kernel
 // entry, [5] list prefix done, [6] list entry read, [1..4] the convergent points of smaa::BlendT::weights, [7] exit; [8] = 1 if the wave had a pixel
@@ -600,7 +602,7 @@ hipError_t smaa_expand(const SmaaBuffers& b, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream)
+hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const unsigned cur = frame & 1u;
     const dim3 sparse(1024);                                                    // grid-stride over the device-side total of the segment counts
@@ -615,13 +617,13 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
 #endif
     const float thr = smaa::preset_of(preset).threshold;
-    if (strip_h == 8) hipLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
-    else hipLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, b, thr, cur);
+    if (strip_h == 8) hipExtLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, ev_start, nullptr, 0, b, thr, cur);
+    else hipExtLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, ev_start, nullptr, 0, b, thr, cur);
 #if SMAA_ROLE_WAVES
     hipLaunchKernelGGL(smaa_weights_roles_kernel, dim3(SMAA_ROLE_GRID), dim3(256), 0, stream, b, preset, cur);
 #else
     hipLaunchKernelGGL(smaa_weights_kernel, sparse, dim3(256), 0, stream, b, preset, cur);
 #endif
-    hipLaunchKernelGGL(smaa_blend_kernel, sparse, dim3(256), 0, stream, b, cur);
+    hipExtLaunchKernelGGL(smaa_blend_kernel, sparse, dim3(256), 0, stream, nullptr, ev_stop, 0, b, cur);
     return hipGetLastError();
 }
