@@ -279,7 +279,11 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
 {
     RtLaunchParams p = p_in;
     dim3 grid((p.fb_w + 31) / 32, (p.rows_local + 7) / 8);
-    if (grid.x == 0 || grid.y == 0) return hipSuccess;
+    if (grid.x == 0 || grid.y == 0) {   // nothing to trace (a rank without rows): the events still have to be recorded, their readers wait on them
+        if (ev_start && hipEventRecord(ev_start, stream) != hipSuccess) return hipGetLastError();
+        if (ev_stop && hipEventRecord(ev_stop, stream) != hipSuccess) return hipGetLastError();
+        return hipSuccess;
+    }
     p.grid_x = (int)grid.x;
     p.grid_y = (int)grid.y;
     if (p.xcd_remap) {

@@ -695,17 +695,27 @@ void rebalance(rtx_context* root)
 {
     const int N = n_ranks(root);
     if (root->per_process || N < 2 || root->frame_no < 4 || root->frame_no - root->resplit_frame < 3) return;
-    std::vector<double> rate(N);
+    std::vector<double> rate(N, 0.0);
     double sum = 0.0, tmin = 1e30, tmax = 0.0;
+    int measured = 0, starved = 0;
     for (int r = 0; r < N; r++) {
+        if (root->split_rows[r] <= 0) { starved++; continue; }   // a rank a caller's split left without rows: no rate of its own (below)
         float ms = 0.0f;
-        if (!launch_ms_ago(rank_ctx(root, r), 2, &ms) || !(ms > 0.0f) || root->split_rows[r] <= 0) return;
+        if (!launch_ms_ago(rank_ctx(root, r), 2, &ms) || !(ms > 0.0f)) return;
         rate[r] = root->split_rows[r] / static_cast<double>(ms);
         sum += rate[r];
+        measured++;
         tmin = ms < tmin ? ms : tmin;
         tmax = ms > tmax ? ms : tmax;
     }
-    if (tmax <= 1.04 * tmin) return;                        // balanced within the noise of the timers
+    if (measured == 0) return;
+    if (starved > 0) {                                      // it is as fast as the others on average, until it has rows and says otherwise
+        const double mean = sum / measured;
+        for (int r = 0; r < N; r++)
+            if (root->split_rows[r] <= 0) { rate[r] = mean; sum += mean; }
+    } else if (tmax <= 1.04 * tmin) {
+        return;                                             // balanced within the noise of the timers
+    }
     const int units = (root->height + 7) / 8;
     std::vector<int> u(N);
     int used = 0;

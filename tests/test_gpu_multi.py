@@ -107,6 +107,13 @@ def test_contiguous_bands_reproduce_the_single_device_frame(small_textures, kind
     group.set_band_split(rows)
     assert group.band_split() == rows
     check(group, "weighted split")
+    # a rank without any rows (a split may starve one): its launch is empty, its events still complete, nothing travels for it
+    if ranks >= 3:
+        starved = [8, 0] + [8] * (ranks - 3) + [h - 8 * (ranks - 2)]
+        group.set_band_split(starved)
+        assert group.band_split() == starved
+        check(group, "a rank without rows")
+        assert group.rank_draw_ms()[1] >= 0.0
     with pytest.raises(wrapper.RtxError, match="multiple of 8|cover"):
         group.set_band_split([5] + [h - 5] + [0] * (ranks - 2))
     with pytest.raises(wrapper.RtxError, match="cover"):
