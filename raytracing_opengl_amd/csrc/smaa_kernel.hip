@@ -88,6 +88,9 @@ constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels
 #ifndef SMAA_ABL
 #define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
 #endif
+#ifndef SMAA_EARLY_ATOMIC
+#define SMAA_EARLY_ATOMIC 1   /* the append's atomic is issued before the plane and texel stores (round 4: traced ULTRA edges 25.2 -> 23.9 us, other presets +-0) */
+#endif
 #ifndef SMAA_XCD_BANDS
 #define SMAA_XCD_BANDS 1
 #endif
@@ -267,6 +270,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #if SMAA_ABL & 16
     if (threshold > -1.0e30f) { if (ebits[0] == 0x123456789abcdefull) screen[0] = 1; return; }   // keep the arithmetic alive, skip the append
 #endif
+#if SMAA_EARLY_ATOMIC
+    // The strip's list entries are reserved HERE, before the plane and texel stores below: the atomic's round trip (the wave needs its
+    // return value for the very last thing it does) then runs beside those stores instead of behind them.
+    const bool has_edges = __ballot((ebits[0] | ebits[1]) != 0) != 0;
+    const unsigned long long any_e[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
+    const unsigned mine_e = (unsigned)__popcll(any_e[0]) + (unsigned)__popcll(any_e[1]);
+    unsigned incl_e = mine_e, base_e = 0;
+    if (has_edges) {
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned u = __shfl_up(incl_e, off, 64);
+            if (lane >= off) incl_e += u;
+        }
+#if SMAA_LINEAR_STRIPS
+        const unsigned strip_e = (unsigned)strip_id;
+#else
+        const unsigned strip_e = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
+#endif
+        if (lane == 63) base_e = atomicAdd(b.count + cur * SMAA_COUNT_SET + (strip_e % SMAA_SEGMENTS) * SMAA_COUNT_STRIDE, incl_e);
+    }
+#endif
     // the bit planes (dense: edge-free strips write their zeros too, so the planes need no clearing). Rows: this lane's four pixels of a
     // row are one byte, 64 lanes = 64 consecutive bytes. Columns: per 8-row block and column 16 bits, this lane's four columns = 8 bytes.
     {
@@ -339,8 +362,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #endif
     const unsigned seg = strip % SMAA_SEGMENTS;
     unsigned base = 0;
+#if SMAA_EARLY_ATOMIC
+    base = __shfl(base_e, 63, 64);
+#else
     if (lane == 63) base = atomicAdd(b.count + cur * SMAA_COUNT_SET + seg * SMAA_COUNT_STRIDE, incl);   // lane 63's inclusive sum is the total
     base = __shfl(base, 63, 64);
+#endif
     uint32_t* out = b.list + (size_t)seg * b.segment_capacity + base + (incl - mine);
     for (int half = 0; half < (STRIP_H * 4 + 31) / 32; half++) {
         unsigned long long m = any[half];
