@@ -869,6 +869,7 @@ int multi_draw(rtx_context* me)
             HIP_TRY(bands_pack_rgb(c->d_packed[0][par], c->d_rgb[par], rows * me->width, c->xfer_stream));
             HIP_TRY(hipEventRecord(c->rgb_packed[par], c->xfer_stream));
         }
+    if (rgb && root_here && (st = use_device(me)) != RTX_OK) return st;   // what follows on the root is issued with the root's device current, as before
     auto send_buffer = [&](rtx_context* c, int t) { return t == 0 && rgb ? c->d_rgb[par] : c->d_packed[t][par]; };
     if (uses_rccl(me)) {
         if (N > first_moved) {
