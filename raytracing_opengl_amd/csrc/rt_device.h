@@ -1048,8 +1048,11 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
 // hit so far / distance to the light) at a point inside the clip box, so a bound that lies behind the origin, or that the ray enters
 // beyond the limit, settles the quadric like a line that misses it (the closest-hit scan passes the tmin of the moment, which is the very
 // value intersect_surface would compare with).
-RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
+// safe (out): the degenerate branch is ruled out for this direction (fact (1) below holds), i.e. a hit needs a point of the ray strictly
+// inside the clip box -- what surface_box_miss may then use.
+RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit, bool& safe)
 {
+    safe = false;
     if (!(Q.bound.w >= 0.0f)) return false;
     // p2 ~ d^T M d from the six direction products (ray-invariant) and the symmetric M of this quadric
     const float dxx = rd.x * rd.x, dyy = rd.y * rd.y, dzz = rd.z * rd.z;
@@ -1058,6 +1061,7 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
     if (!(fabsf(p2) > Q.sym1.z)) return false;  // too close to the degenerate branch: run the full test
     const float a = dot3_fma(rd, rd);
     if (!(a > 0.25f && a < 4.0f)) return false;  // degenerate direction: never cull
+    safe = true;
     const f3 oc = ro - xyz(Q.bound);
     const float b = dot3_fma(oc, rd);
     const float d2 = dot3_fma(oc, oc);
@@ -1069,6 +1073,35 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
     if (!(cc > 0.0f)) return false;             // origin inside the bound
     if (b >= 0.0f) return true;                 // the bound lies behind the origin
     return sphere_entry_beyond(a, b, h + err, d2, tlimit);
+}
+RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
+{
+    bool safe;
+    return surface_cull(Q, ro, rd, tlimit, safe);
+}
+// Second conservative pre-test, for lanes the sphere test lets through and whose direction rules the degenerate branch out (`safe`): the
+// reference accepts a root only at a point STRICTLY inside the world-space clip box (checkSurfaceEdges, rt.frag:500-512, on pt = rd t + ro in
+// float) with 1e-4 < t < tlimit. true = the ray's part [0, tlimit] misses the box inflated by more than pt's rounding can move a point
+// (relative 1e-5 of |origin| + |box|, absolute 1e-5), so there is no such point. Slab test with approximate reciprocals (the margins
+// cover them); NaNs from 0 x inf drop out of fminf / fmaxf, i.e. that axis says nothing. Unbounded box axes are +-FLT_MAX and never cull.
+RT_HD bool surface_box_miss(const DevSurface& Q, f3 ro, f3 rd, float tlimit)
+{
+    const f3 lo = mk3(Q.f_vmin.y, Q.f_vmin.z, Q.f_vmin.w), hi = xyz(Q.vmax);
+    float t0 = 0.0f, t1 = tlimit;
+    const float o[3] = {ro.x, ro.y, ro.z}, d[3] = {rd.x, rd.y, rd.z}, l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float pad = fmaf(1.0e-5f, fabsf(o[k]) + fabsf(l[k]) + fabsf(h[k]), 1.0e-5f);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float inv = __builtin_amdgcn_rcpf(d[k]);
+#else
+        const float inv = 1.0f / d[k];
+#endif
+        const float ta = ((l[k] - pad) - o[k]) * inv, tb = ((h[k] + pad) - o[k]) * inv;
+        t0 = fmaxf(t0, fminf(ta, tb));
+        t1 = fminf(t1, fmaxf(ta, tb));
+    }
+    return t0 > fmaf(1.0e-5f, fabsf(t1), t1) + 1.0e-6f;   // (NaN -> false -> not culled)
 }
 
 // ---- second-level culls for long tables (RT_GROUP consecutive primitives under one sphere, built by the packer) ----
@@ -1505,7 +1538,10 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
                 const DevSurfaceCull c0 = cullrec[i];
-                const bool need = !surface_cull(c0, ro, rd, tmin);
+                // (round 4) behind the sphere: the clip box itself, for the lanes it governs -- quadric-heavy 4K frame 1 015 -> 981 us
+                bool safe;
+                bool need = !surface_cull(c0, ro, rd, tmin, safe);
+                if (RT_ANY(need)) need = need && !(safe && surface_box_miss(S.surfaces()[i], ro, rd, tmin));
                 if (RT_ANY(need)) {
                     scan_stats_level2(ps.mem ? 0 : 1, need);
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; scan_stats_hit(ps.mem ? 0 : 1); }
@@ -1678,7 +1714,9 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
                 const DevSurfaceCull c0 = cullrec[i];
-                const bool need = on && !surface_cull(c0, ro, rd, dist);
+                bool safe;
+                bool need = on && !surface_cull(c0, ro, rd, dist, safe);
+                if (RT_ANY(need)) need = need && !(safe && surface_box_miss(S.surfaces()[i], ro, rd, dist));
                 if (RT_ANY(need)) {
                     scan_stats_level2(ps.mem ? 2 : 3, need);
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; scan_stats_hit(ps.mem ? 2 : 3); }

@@ -272,7 +272,9 @@ int harness_surface_bound(const void* record, float out[5])
 
 // The same for a quadric (`record`: one std140 rt_surface): rays around its position from distances [dist_lo, dist_hi].
 // extent: the size of the region the rays are aimed at. counts / bad as above.
-int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float dist_lo, float dist_hi, float extent, int64_t counts[4], float* bad, int max_bad)
+// counts: [0] rays, [1] culled by surface_cull (the sphere tests), [2] hits, [3] VIOLATIONS (culled by either test and hit), [4] culled by the
+// clip-box test behind it
+int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float dist_lo, float dist_hi, float extent, int64_t counts[5], float* bad, int max_bad)
 {
     rtpack::Defines d;
     std::memset(&d, 0, sizeof d);
@@ -289,9 +291,9 @@ int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float 
     const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()));
     const DevSurface Q = S.surfaces()[0];
     const DevSurfaceCull C = S.surf_cull()[0];
-    int64_t c_cull = 0, c_hit = 0, c_bad = 0;
+    int64_t c_cull = 0, c_hit = 0, c_bad = 0, c_box = 0;
     int n_bad = 0;
-#pragma omp parallel for schedule(static, 4096) reduction(+ : c_cull, c_hit, c_bad)
+#pragma omp parallel for schedule(static, 4096) reduction(+ : c_cull, c_hit, c_bad, c_box)
     for (int64_t k = 0; k < n; k++) {
         uint64_t x = seed * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(k) * 0xbf58476d1ce4e5b9ull + 1;
         auto u01 = [&]() { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return (x >> 11) * (1.0 / 9007199254740992.0); };
@@ -309,16 +311,19 @@ int harness_quadric_premise(const void* record, int64_t n, uint64_t seed, float 
         if (u01() < 0.1) rd = -rd;
         const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
         float t = 0.0f;
-        const bool cull = surface_cull(C, ro, rd, tmin);
+        bool safe = false;
+        const bool sphere = surface_cull(C, ro, rd, tmin, safe);
+        const bool box = !sphere && safe && surface_box_miss(Q, ro, rd, tmin);   // the clip-box test behind the sphere, as the candidate scans compose it
+        const bool cull = sphere || box;
         const bool hit = intersect_surface(Q, ro, rd, tmin, t);
-        c_cull += cull; c_hit += hit;
+        c_cull += sphere; c_box += box; c_hit += hit;
         if (cull && hit) {
             c_bad++;
 #pragma omp critical
             if (n_bad < max_bad) { float* o = bad + 7 * n_bad++; o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = tmin; }
         }
     }
-    counts[0] = n; counts[1] = c_cull; counts[2] = c_hit; counts[3] = c_bad;
+    counts[0] = n; counts[1] = c_cull; counts[2] = c_hit; counts[3] = c_bad; counts[4] = c_box;
     return n_bad;
 }
 

@@ -312,20 +312,26 @@ _QUADRICS = [dict(a=1, b=1, c=1, f=-0.6), dict(a=4, b=4, c=-1), dict(a=4, b=4, f
 
 @pytest.mark.parametrize("clip", [(1,), (0, 1), (0, 1, 2)])
 def test_quadric_cull_premise_in_bulk(built, clip):
-    """'The reference reports no hit for a ray the quadric cull rejects' on random rays from 0.1 to 1e4 units, for clip boxes open along
-    two axes, one axis, none. With an open axis the bound only holds near the quadric, so beyond that distance nothing may be culled."""
+    """'The reference reports no hit for a ray the quadric culls reject' on random rays from 0.1 to 1e4 units, for clip boxes open along
+    two axes, one axis, none: the sphere tests of surface_cull and, behind them, the clip-box test (round 4). With an open axis the SPHERE
+    bound only holds near the quadric, so beyond that distance it must stand aside; the clip box is a statement about the hit point alone
+    and keeps culling from anywhere -- along its closed axes."""
     import ctypes
     L = _premise_lib()
     rng = np.random.default_rng(7)
     for lo, hi in ((0.1, 10), (10, 50), (100, 1000), (1000, 1e4)):
-        culled = 0
+        sphere = box = 0
         for k in range(6):
             rec = _clipped_quadric(rng, _QUADRICS[k], clip)
-            cnt, bad = (ctypes.c_int64 * 4)(), (ctypes.c_float * 28)()
+            cnt, bad = (ctypes.c_int64 * 5)(), (ctypes.c_float * 28)()
             L.harness_quadric_premise(ctypes.create_string_buffer(rec, len(rec)), 100000, k + 1, lo, hi, 3.0, cnt, bad, 4)
             assert cnt[3] == 0, (k, clip, lo, list(bad[:7]))
-            culled += cnt[1]
-        assert (culled > 50000) if (hi <= 50 or len(clip) == 3) else (culled == 0), (clip, lo, culled)
+            sphere += cnt[1]
+            box += cnt[4]
+        assert (sphere > 50000) if (hi <= 50 or len(clip) == 3) else (sphere == 0), (clip, lo, sphere)
+        if not (hi <= 50 or len(clip) == 3):
+            assert box > 10000, (clip, lo, box)          # the only cull left out there
+        assert box > 0, (clip, lo, box)
 
 
 @pytest.mark.parametrize("clip", [(1,), (0, 1, 2), ()])

@@ -347,7 +347,8 @@ __device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, uns
 // intersect_surface (wave-level exit for waves without a real root) against the literal rt.frag:513-572
 // counters: 0 rays, 1 culled by surface_cull, 2 culled by the group test, 3 literal hits, 4 literal hits on the degenerate branch,
 //           5 rays the product's intersector leaves early (no real root),
-//           10 VIOLATIONS surface_cull, 11 group, 12 product intersector != literal (hit flag, or t on a hit)
+//           6 culled by the clip-box test behind surface_cull,
+//           10 VIOLATIONS surface_cull, 11 group, 12 product intersector != literal (hit flag, or t on a hit), 13 clip-box test
 // ================================================================================================================================
 __device__ bool intersect_surface_literal(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, float& t, bool& degenerate, bool* real_roots = nullptr)
 {
@@ -463,16 +464,19 @@ __device__ void audit_quadric(const AuditParams& p, const SceneView& S, unsigned
         f3 ro, rd;
         float tmin;
         quadric_ray(R, Q, C, (int)(R.next() % 10ull), ro, rd, tmin);
-        const bool c_cull = surface_cull(C, ro, rd, tmin);
+        bool safe = false;
+        const bool c_cull = surface_cull(C, ro, rd, tmin, safe);
+        const bool c_box = !c_cull && safe && surface_box_miss(Q, ro, rd, tmin);   // as the product composes it: behind the sphere test
         const bool c_group = grouped && surface_group_cull(S.surf_group()[i / RT_GROUP], ro, rd) && !quadric_may_degenerate(C, rd);
         float t_lit = 0.0f, t_prod = 0.0f;
         bool deg = false, real_roots = false;
         const bool hit = intersect_surface_literal(Q, ro, rd, tmin, t_lit, deg, &real_roots);
         const bool hit_p = intersect_surface<false>(Q, ro, rd, tmin, t_prod);   // every lane takes the early exits on its own condition
-        c[0]++; c[1] += c_cull; c[2] += c_group; c[3] += hit; c[4] += hit && deg;
+        c[0]++; c[1] += c_cull; c[2] += c_group; c[3] += hit; c[4] += hit && deg; c[6] += c_box;
         c[5] += !hit_p && !real_roots && !deg;   // left by the product's exit for lanes without a real root
         if (c_cull && hit) { c[10]++; record_bad(p, 10, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
         if (c_group && hit) { c[11]++; record_bad(p, 11, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
+        if (c_box && hit) { c[13]++; record_bad(p, 13, i, ro, rd, tmin, t_lit, deg ? 1.0f : 0.0f); }
         if (hit != hit_p || (hit && __builtin_bit_cast(unsigned, t_lit) != __builtin_bit_cast(unsigned, t_prod))) { c[12]++; record_bad(p, 12, i, ro, rd, tmin, t_lit, t_prod); }
     }
 }

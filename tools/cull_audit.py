@@ -36,8 +36,8 @@ LABELS = {
                      22: "hits with t < 4", 23: "4 .. 8", 24: "8 .. 16", 25: "16 .. 32", 26: "32 .. 64", 27: ">= 64",
                      28: "reported more than 1e-3 t + 0.01 before the ray enters the inflated tube: t < 4", 29: "... 4 .. 8", 30: "... 8 .. 16", 31: "... 16 .. 32",
                      32: "... 32 .. 64", 33: "... >= 64", 40: "reported more than 1e-3 t + 0.01 + 0.025 (t - 8) early, t > 8", 41: "reported more than 1 early", 42: "more than 5 early"},
-    "quadric": {0: "rays", 1: "culled by surface_cull", 2: "culled by the group test", 3: "literal hits", 4: "literal hits on the degenerate branch", 5: "left early by the product intersector (no real root)",
-                10: "VIOLATIONS surface_cull", 11: "VIOLATIONS group test", 12: "VIOLATIONS product intersector != literal rt.frag:513-572"},
+    "quadric": {0: "rays", 1: "culled by surface_cull", 2: "culled by the group test", 3: "literal hits", 4: "literal hits on the degenerate branch", 5: "left early by the product intersector (no real root)", 6: "culled by the clip-box test behind surface_cull",
+                10: "VIOLATIONS surface_cull", 11: "VIOLATIONS group test", 12: "VIOLATIONS product intersector != literal rt.frag:513-572", 13: "VIOLATIONS clip-box test"},
     "ring": {0: "rays", 1: "culled", 2: "literal hits", 10: "VIOLATIONS"},
     "tables": {0: "rays", 1: "camera-pencil rays", 2: "light-pencil rays", 3: "slab-table rays", 4: "rays whose mask has every bit set", 5: "set bits", 6: "quadric checks (clear bit)",
                7: "torus checks (clear bit)", 10: "VIOLATIONS quadric: bit clear, literal intersector hits", 11: "VIOLATIONS torus: bit clear, the ray up to its limit comes within 5 mm of the real tube"},
