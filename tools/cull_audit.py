@@ -49,8 +49,11 @@ class Defines(ctypes.Structure):
 
 
 def load():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "audit")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "audit", "libcull_audit.so"))
+    if os.environ.get("CULL_AUDIT_LIB"):      # a variant built by hand (other -D flags), e.g. to audit a candidate change before it ships
+        lib = ctypes.CDLL(os.environ["CULL_AUDIT_LIB"])
+    else:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "audit")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = ctypes.CDLL(os.path.join(ROOT, "tools", "audit", "libcull_audit.so"))
     lib.cull_audit_run.restype = ctypes.c_int
     lib.cull_audit_run.argtypes = [ctypes.POINTER(Defines), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                    ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
