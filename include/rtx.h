@@ -101,7 +101,9 @@ typedef enum rtx_option {
                                 channel -- 12 bytes per pixel instead of 16; the traced frame's alpha is the constant 1.0f (rt.frag:902) and the
                                 root writes it back while it places the bands, so the assembled frame is bit-identical; 0: 16 bytes per
                                 pixel. At N = 2 ... 4 the frame rate of the float target is the rate of the root's links.
-                                The contiguous layouts receive in place and always move whole pixels. */
+                                The contiguous layouts receive in place and always move whole pixels. A per-process group (rtx_create_rank) must
+                                set the same value on every rank, like RTX_OPT_BAND_LAYOUT and rtx_set_band_split: each process sizes its own
+                                side of the paired ncclSend / ncclRecv from them, and nothing cross-checks the ranks. */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which build of the trace kernel runs: 0 = the default one, 1 = the many-primitive one (group culls, ray
                                 pencils and slab tables compiled in; its own register budget -- 7 waves/SIMD in round 1, hence the
                                 name, 6 now), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */
@@ -224,7 +226,8 @@ RTX_API int rtx_draw(rtx_context* ctx);
 RTX_API int rtx_draw_bands(rtx_context* ctx, int band_rows, int band_first, int band_stride,
                            void* dst_device, int format, void* stream);
 /* The same for ONE contiguous range of rows -- a rank's share in the contiguous band layout (RTX_OPT_BAND_LAYOUT 1): rows
- * [row_first, row_first + n_rows), row_first a multiple of 8, stored from the start of `dst`. */
+ * [row_first, row_first + n_rows), row_first a multiple of 8 and n_rows a multiple of 8 unless the range ends the frame (the texture
+ * LOD's 2 x 2 derivative quads must not straddle two ranges; RTX_ERR_INVALID otherwise), stored from the start of `dst`. */
 RTX_API int rtx_draw_rows(rtx_context* ctx, int row_first, int n_rows, void* dst_device, int format, void* stream);
 RTX_API int rtx_finish(rtx_context* ctx);
 

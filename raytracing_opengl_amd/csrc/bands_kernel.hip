@@ -5,6 +5,8 @@
 // frame: 16 bytes per lane, rows contiguous on both sides, so every wave moves whole 1 KiB row segments.
 #include "bands_kernel.h"
 
+#include "band_math.h"
+
 namespace {
 
 template <typename Unit>
@@ -14,8 +16,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const Unit* __restrict__ pa
     const size_t n = (size_t)rows_local * (size_t)units_per_row;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int lr = (int)(i / (size_t)units_per_row), u = (int)(i - (size_t)lr * (size_t)units_per_row);
-        const int j = lr / band_rows;
-        const int y = (band_first + j * band_stride) * band_rows + (lr - j * band_rows);
+        const int y = rtbands::frame_row_of_packed(lr, band_rows, band_first, band_stride);
         if (y < fb_h) frame[(size_t)y * (size_t)units_per_row + (size_t)u] = packed[i];
     }
 }
@@ -39,8 +40,7 @@ __global__ __launch_bounds__(256) void unpack_rgb_kernel(const float* __restrict
     const size_t n = (size_t)rows_local * (size_t)fb_w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int lr = (int)(i / (size_t)fb_w), x = (int)(i - (size_t)lr * (size_t)fb_w);
-        const int j = lr / band_rows;
-        const int y = (band_first + j * band_stride) * band_rows + (lr - j * band_rows);
+        const int y = rtbands::frame_row_of_packed(lr, band_rows, band_first, band_stride);
         if (y < fb_h) frame[(size_t)y * (size_t)fb_w + (size_t)x] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.0f);
     }
 }

@@ -767,13 +767,10 @@ RT_COLD bool intersect_torus_local(const DevTorus& T, f3 ro, f3 rd, float tmin, 
 #endif
     return t > 0.0f && t < 100.0f && t < tmin;
 }
-// Conservative pre-test in WORLD space (no rotation needed): true = the solve can be skipped.
-// A root is accepted only for 0 < t < min(tmin,100) (rt.frag:486). If the ray's line misses the
-// torus' bounding sphere inflated by 1 % + 0.01, or the sphere lies behind the origin, or is
-// entered beyond that limit, the quartic has no real root in range, and Durand-Kerner -- even
-// when it runs out of its 60 sweeps, which is what happens for origins more than ~100 units
-// away -- reports none (checked exhaustively against the un-culled oracle on every bench scene
-// and on random rays: tests/test_culls.py). Skipping is therefore result-preserving.
+// Conservative pre-tests in WORLD space (no rotation needed): true = the exact test can be skipped.
+// Rings and quadrics (geometric intersectors): a hit needs 0 < t < tlimit, so a bounding sphere that the ray's line misses, that lies
+// behind the origin or that is entered beyond the limit rules the primitive out. Tori: see torus_cull below -- their solver is an
+// iteration whose reported root need not be where the ray enters the tube, so they get no length limit.
 // true = PROVABLY no point of the ray with 0 < t <= tlimit (plus slack) lies inside the sphere
 // (centre c, squared radius r2, already inflated by the caller).
 // The discriminant b*b - a*cc cancels catastrophically when the origin is far from the sphere
@@ -816,21 +813,35 @@ RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
 // degenerate-scene fuzz: a ray refracted with a non-unit normal, |rd| = 1.29, going away from a torus 2 units to its side,
 // "hit" it at t = 1.18). Such directions are never culled: the solver has to run to reproduce its own garbage.
 RT_HD bool unit_direction(float dd) { return fabsf(dd - 1.0f) <= 1e-3f; }   // false for NaN
-// The length limit of the torus culls ("entered beyond the limit": a root is accepted for t < min(tmin, 100) only, rt.frag:486). The limit
-// tests assume that the solver reports a hit no earlier than the ray really enters the inflated torus. Measured (round 4, tools/cull_audit.py
-// torus_margin: 2.7e10 solved rays, 5.5e9 hits): true up to 1e-3 t + 0.01 for every hit below t = 8 but two; beyond, where the iteration
-// runs out of sweeps more and more often, 1 481 hits were reported earlier than that -- the accepted iterate is simply inaccurate, by
-// 0.5 ... 1 at t = 45 ... 55 in the cases the audit of the culls met. Widening the limit by 2.5 % of what exceeds 8 covers nine in ten of
-// them (153 remain: iterates that are garbage with a small imaginary part, up to 46 early; DESIGN.md section 3 has the table).
-RT_HD float torus_limit(float tlimit)
-{
-    const float tl = gl_min(tlimit, 100.0f);
-    return tl + 0.025f * gl_max(tl - 8.0f, 0.0f);
-}
-RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd, float tlimit)
+// THE RAY'S OWN LENGTH LIMIT IS NOT USED by any torus cull (round 5). A root is accepted for t < min(tmin, 100) only (rt.frag:486), and rounds
+// 2-4 culled a torus whose inflated bound the ray enters beyond min(tmin, 100). That assumed that the solver reports a hit no earlier than the
+// ray really enters the tube -- a statement about the reference's Durand-Kerner iteration that does not hold: a solve that runs out of its 60
+// sweeps reports whatever iterate looks real, and on a ray that does cross the tube such an iterate can lie anywhere along it. Measured
+// (tools/cull_audit.py family torus_lead, 2.9e10 reported hits, profiles/r05a_torus_lead_by_origin_distance_4e10.txt): reported more than
+// 1e-3 t + 0.01 BEFORE the entry into the inflated tube -- 0 of 2.2e9 hits for origins within 2 units of the torus' centre, 4 of 5.5e9 at 2..4
+// (one of them by 1.04), 52 of 3.2e9 at 4..6 (up to 4.8), 1 117 of 1.4e9 at 10..12 (up to 10.5), 281 037 of 5.4e9 at 24..48 (up to 46): rarer
+// near the torus, where the quartic's coefficients are small and the iteration converges, but there is no distance from which on it is never.
+// Round 4's audit met four such rays in 2.7e11 that its culls dropped (tests/golden/torus_far_rays.json; tests/test_culls.py,
+// tests/test_gpu_culls.py). The reference never culls (rt.frag:462-487): whatever the solver reports below tmin is a hit. What is left:
+//   * LATERAL: a torus is culled when the ray's forward half-line misses its inflated bound. Of another kind than the length premise -- a ray
+//     that never comes near the tube has four complex roots, and an iterate would have to sit within 1e-3 of the real axis by chance: of 3.6e10
+//     reported hits at every distance none belongs to a ray that stays outside the tube inflated by 1 % + 0.01 (the farthest phantom passes
+//     3.8 mm from the real tube), and 1.3e11 laterally culled, solved rays of the torus family had no hit (profiles/r05b_*).
+//   * THE REFERENCE'S OWN t < 100: a torus that the ray enters beyond RT_TORUS_REACH = 102.5 is culled whatever tmin is. An accepted root would
+//     have to be reported more than 2.4 before the entry by a solve whose origin is more than 100 units out -- every such solve runs all 60
+//     sweeps. Dropping this limit as well is exact by construction and was built and measured: the torus-heavy 4K frame takes 9.7 ms instead of
+//     1.8 and the default frame 0.67 instead of 0.47 (the far floor and the planets: millions of rays from hundreds to 1e5 units out whose line
+//     crosses a torus, each 60 sweeps), with bit-identical frames -- not one of those solves reported a root below 100
+//     (profiles/r05b_torus_no_limit_at_all_cost_ab.txt). The premise is measured, not proven: tools/cull_audit.py family torus_far solves
+//     rays that enter beyond the reach (DESIGN.md section 3 has the count).
+// Cost of dropping the ray's own limit: torus-heavy 4K frame +3 %, default frame +0.3 % (profiles/r05a_torus_limit_rule_cost_ab.txt, `near0`).
+#ifndef RT_TORUS_REACH
+#define RT_TORUS_REACH 102.5f      /* 100 + 2.5 % (round 4's widening at t = 100); sphere_cull and the puck test add their own slack */
+#endif
+RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd)
 {
     if (!unit_direction(dot3_fma(rd, rd))) return false;
-    return sphere_cull(xyz(bound), bound.w, ro, rd, torus_limit(tlimit));
+    return sphere_cull(xyz(bound), bound.w, ro, rd, RT_TORUS_REACH);
 }
 // A ring hit lies within sqrt(r2) of the ring centre (p < r2, rt.frag:384) and needs 0 < t < tmin;
 // intersect_ring has no NaN-accepting path (all four comparisons must hold), so missing the
@@ -841,7 +852,7 @@ RT_HD bool ring_cull(f4 bound, f3 ro, f3 rd, float tlimit)
 }
 // Second, tighter pre-test in the torus' own frame (axis = local z), after the rotation the solver
 // needs anyway. The torus lies inside the "puck" |z| <= r, x^2+y^2 <= (R+r)^2 and outside the
-// hole x^2+y^2 < (R-r)^2. true = the part of the ray with 0 < t <= tlimit never meets the
+// hole x^2+y^2 < (R-r)^2. true = the part of the ray with 0 < t <= RT_TORUS_REACH never meets the
 // (1 %-inflated) puck, or crosses the puck's slab entirely inside the (deflated) hole. Margins as
 // in sphere_cull. Same premise as torus_cull: Durand-Kerner reports no root for a geometric miss.
 RT_HD float rt_sqrt_approx(float x)   // conservative predicates only: 1 ulp is as good as correctly rounded there
@@ -905,11 +916,11 @@ RT_HD bool torus_tube_cull(const DevTorus& T, f3 o, f3 d, float t0, float t1)
     const float mid = 0.5f * (l3 + r1);
     return l1 > eps && l2 > eps && l3 > eps && mid > eps && r1 > eps && r2 > eps && r3 > eps;
 }
-// (t0, t1: on a `false` return, the part of the ray inside the inflated puck and the limit -- what torus_tube_cull then looks at)
-RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float tlimit, float& t0, float& t1)
+// (t0, t1: on a `false` return, the part of the ray inside the inflated puck and the reach -- what torus_tube_cull then looks at)
+RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float& t0, float& t1)
 {
     t0 = 0.0f;
-    t1 = torus_limit(tlimit) * 1.001f + 0.01f;
+    t1 = RT_TORUS_REACH * 1.001f + 0.01f;     // the reference's own t < 100, never the ray's limit (see torus_cull)
     // slab |z| <= hz
     const float hz = T.cull.x;
     if (d.z != 0.0f) {
@@ -948,22 +959,22 @@ RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float tlimit, float& t
     }
     return false;
 }
-RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
+RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d)
 {
     float t0, t1;
-    return torus_puck_cull(T, o, d, tlimit, t0, t1);
+    return torus_puck_cull(T, o, d, t0, t1);
 }
 // TUBE: the Bernstein test of the inflated tube behind the puck test (round 4). Compiled into the many-primitive kernel variant (and the host
 // build): 64 tori, 4K, depth 6: 5.25 M -> 4.47 M solves, 141 k -> 128 k solver runs, 1 904 -> 1 794 us; in the default variant its one torus gains
 // a tenth fewer runs and loses as much to the 90 instructions per candidate pass (472 -> 477 us: not compiled in there).
 template <bool TUBE = true>
-RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d, float tlimit)
+RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
 {
     const float dd = dot3(d, d);
     if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
     if (torus_hull_cull(T, o, d)) return true;
     float t0, t1;
-    if (torus_puck_cull(T, o, d, tlimit, t0, t1)) return true;
+    if (torus_puck_cull(T, o, d, t0, t1)) return true;
     // Ring tori only (hole radius T.k.w > 0, i.e. R - r > 0.01): F = (D-^2 - r^2)(D+^2 - r^2) with D-, D+ the distances to the nearest and the
     // farthest point of the centre circle. With r' < R the second factor is positive everywhere and F' > 0 means "outside the inflated tube".
     // A horn or spindle torus (r >= R) has a second sheet { D+ = r } around its centre, INSIDE which F > 0 again: a ray that starts in there and
@@ -979,7 +990,7 @@ RT_HD bool intersect_torus_c(const DevTorus& T, f3 ro, f3 rd, float tmin, float&
     const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos));
     const f3 d = quat_rotate_id(T.quat, ident, rd);
     solved = false;
-    if (CULL && torus_local_cull<TUBE>(T, o, d, tmin)) return false;
+    if (CULL && torus_local_cull<TUBE>(T, o, d)) return false;
     solved = true;
     return intersect_torus_local(T, o, d, tmin, t);
 }
@@ -1114,11 +1125,11 @@ RT_HD bool surface_box_miss(const DevSurface& Q, f3 ro, f3 rd, float tlimit)
 //  * quadrics: missing the bounds does not settle a quadric -- its degenerate branch (trap T4, |p2| < 1e-6) ignores the clip box --
 //    so a skipped group still evaluates the p2 pre-check of every member (quadric_may_degenerate: the first third of surface_cull) and
 //    runs the exact test for a lane whose direction is that close to a member's asymptotic cone.
-RT_HD bool torus_group_cull(f4 g, f3 ro, f3 rd, float tlimit)
+RT_HD bool torus_group_cull(f4 g, f3 ro, f3 rd)
 {
     if (!(g.w >= 0.0f)) return false;   // a member that is never culled (zero tube, non-unit quaternion): neither is the group
     if (!unit_direction(dot3_fma(rd, rd))) return false;
-    return sphere_cull(xyz(g), g.w, ro, rd, torus_limit(tlimit));
+    return sphere_cull(xyz(g), g.w, ro, rd, RT_TORUS_REACH);
 }
 RT_HD bool surface_group_cull(f4 g, f3 ro, f3 rd)
 {
@@ -1353,6 +1364,12 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
         if (apex) return dot3_fma(C.axis, xyz(pp.a)) < fmaf(C.ct, pp.b.x, -(C.st * pp.a.w)) - 4.0e-6f;
         return pp.a.x + pp.a.z < C.ulo || pp.a.x - pp.a.z > C.uhi || pp.a.y + pp.a.z < C.vlo || pp.a.y - pp.a.z > C.vhi;
     };
+    // A light's pencil (P.a.w != 0: its rays run TOWARDS the apex): the cell of a ray only tells where the ray comes from, so "the bound is
+    // not in the cell's cone" also drops every torus BEHIND the light -- the ray's own length limit in disguise (the ray would reach it beyond
+    // its distance to the light), which no torus cull may use (torus_cull). A torus therefore stays a candidate of the cells its bound's
+    // ANTIPODAL cone meets as well.
+    auto misses_behind = [&](const PencilPrim& pp) { return -dot3_fma(C.axis, xyz(pp.a)) < fmaf(C.ct, pp.b.x, -(C.st * pp.a.w)) - 4.0e-6f; };
+    const bool towards_apex = apex && P.a.w != 0.0f;
     uint32_t bits = 0u;
     for (int b = 0; b < 32 && b < count; b++) {
         const PencilPrim pp = prims[(quadrics ? 0 : ns) + first + b];
@@ -1363,7 +1380,7 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
                 const float p2 = apex ? fabsf(quadric_p2(S.surf_cull()[first + b], C.axis)) : pp.a.w;
                 if (p2 > 2.01f * pp.b.z * C.theta + pp.b.w) clear = misses(pp);
             } else {
-                clear = misses(pp);
+                clear = misses(pp) && (!towards_apex || misses_behind(pp));
             }
         }
         if (!clear) bits |= 1u << b;
@@ -1444,7 +1461,9 @@ RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_
     // on its degenerate branch accepts t > tmin (trap T4: the comparison is inverted), which moves the "closest" hit AWAY and makes
     // primitives behind the old limit eligible again (pencil-scene fuzz, seed 9038: a floor at t = 2992, a degenerate quadric at 22 925,
     // then a cylinder at 3018 that the reference therefore shows). A lane with such a quadric among its candidates gets the whole ray.
-    float tA = 0.0f, tB = any_deg ? 1.0e6f : gl_min(tlimit + 0.025f * gl_max(gl_min(tlimit, 100.0f) - 8.0f, 0.0f), 1.0e6f);   // torus_limit's widening (tori accept no root beyond 100 anyway)
+    // Tori: never the ray's own limit, only the reference's t < 100 (torus_cull) -- in a scene with tori the walk covers at least that.
+    const float tB_quadric = any_deg ? 1.0e6f : gl_min(tlimit + 0.025f * gl_max(gl_min(tlimit, 100.0f) - 8.0f, 0.0f), 1.0e6f);   // (the slack is rounds 2-4's, kept)
+    float tA = 0.0f, tB = S.h->n_torus > 0 ? gl_max(tB_quadric, RT_TORUS_REACH * 1.001f + 0.01f) : tB_quadric;
     bool inside = true;
     const float ov[3] = {o.x, o.y, o.z}, dv[3] = {d.x, d.y, d.z}, lov[3] = {B.lo.x, B.lo.y, B.lo.z}, hiv[3] = {B.hi.x, B.hi.y, B.hi.z};
     for (int a = 0; a < 3; a++) {
@@ -1598,15 +1617,15 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                     while (u != 0u) {
                         const int b = __builtin_ctz(u), i = (w << 5) + b;
                         u &= u - 1u;
-                        if (!torus_cull(bound[i], ro, rd, tmin)) cand |= 1ull << (i - base);
+                        if (!torus_cull(bound[i], ro, rd)) cand |= 1ull << (i - base);
                     }
                 }
             } else
             for (int i = base; i < end; i += 4) {
-                if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin));
+                if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(!torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd));
                 if (!group_live) continue;   // wave-uniform: no lane can reach any of the group's tori
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
-                RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd, tmin)) cand |= 1ull << (i + k - base);)
+                RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd)) cand |= 1ull << (i + k - base);)
             }
             dk_stats_scan(cand);
             while (RT_ANY(cand != 0ull)) {
@@ -1626,7 +1645,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
-                RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd, tmin);)
+                RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd);)
             }
             for (int k = 0; k < 4; k++) {
                 if (RT_ANY(need[k])) {
@@ -1765,15 +1784,15 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                         while (u != 0u) {
                             const int b = __builtin_ctz(u), i = (w << 5) + b;
                             u &= u - 1u;
-                            if (on && !torus_cull(bound[i], ro, rd, dist)) cand |= 1ull << (i - base);
+                            if (on && !torus_cull(bound[i], ro, rd)) cand |= 1ull << (i - base);
                         }
                     }
                 } else
                 for (int i = base; i < end; i += 4) {
-                    if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, dist));
+                    if (grouped && (i & (RT_GROUP - 1)) == 0) group_live = RT_ANY(on && !torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd));
                     if (!group_live) continue;
                     const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
-                    RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd, dist)) cand |= 1ull << (i + k - base);)
+                    RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd)) cand |= 1ull << (i + k - base);)
                 }
                 dk_stats_scan(cand);
                 while (RT_ANY(cand != 0ull)) {
@@ -1795,7 +1814,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             bool need[4] = {on, on && i + 1 < n, on && i + 2 < n, on && i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
-                RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd, dist);)
+                RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd);)
             }
             for (int k = 0; k < 4; k++) {
                 if (RT_ANY(need[k])) {

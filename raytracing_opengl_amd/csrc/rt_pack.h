@@ -682,7 +682,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
                 const f4 apex = k == 0 ? h.cam_pos : (reinterpret_cast<const DevLightPoint*>(blob.data() + h.off_light_point) + (k - 1))->pos_r2;
                 if (small3(apex)) {   // a far-away apex loses the float precision the builder's margins assume: no pencil then
                     P.kind = RT_PENCIL_APEX;
-                    P.a = mk4(apex.x, apex.y, apex.z, 0.0f);
+                    P.a = mk4(apex.x, apex.y, apex.z, k == 0 ? 0.0f : 1.0f);   // w != 0: the rays run TOWARDS the apex (a light), rt_device.h pencil_cell_word
                     P.res = RT_PENCIL_APEX_RES;
                     P.cells = 6u * RT_PENCIL_APEX_RES * RT_PENCIL_APEX_RES;
                 }

@@ -145,7 +145,7 @@ enum { RT_MAX_PENCILS = 8, RT_PENCIL_APEX_RES = 64, RT_PENCIL_PAR_RES = 128, RT_
 // quadric i" that no table over positions can answer, because a quadric on that branch ignores its clip box.
 enum { RT_PENCIL_OFF = 0, RT_PENCIL_APEX = 1, RT_PENCIL_PARALLEL = 2, RT_PENCIL_DIRECTION = 3 };
 struct alignas(16) DevPencil {
-    f4 a;          // APEX: the common point; PARALLEL: the common (unit) direction
+    f4 a;          // APEX: the common point, w = 0: the rays start there (camera), 1: they run towards it (point light); PARALLEL: the common (unit) direction
     f4 e1;         // PARALLEL: first in-plane axis xyz, w = coordinate of the low edge of cell 0
     f4 e2;         // PARALLEL: second axis, w likewise
     f4 grid;       // PARALLEL: x, y = cells per unit length along e1, e2; z, w = cell sizes

@@ -43,6 +43,7 @@ const char* ncclGetErrorString(ncclResult_t);
 #include "rt_kernel.h"
 #include "rt_pack.h"
 #include "smaa_kernel.h"
+#include "band_math.h"
 #include "bands_kernel.h"
 #include "rtx/smaa_tables.h"
 
@@ -610,19 +611,13 @@ static_assert(sizeof(ncclUniqueId) == RTX_RCCL_ID_BYTES, "rtx.h documents the si
 
 inline int n_ranks(const rtx_context* ctx) { return ctx->n_total; }
 inline rtx_context* rank_ctx(rtx_context* ctx, int r) { return r == 0 ? ctx : ctx->peers[r - 1]; }
-inline size_t target_bytes(int t) { return t == 0 ? 16 : 4; }   // target 0 = RGBA32F, 1 = RGBA8
+inline size_t target_bytes(int t) { return rtbands::target_bytes(t); }   // target 0 = RGBA32F, 1 = RGBA8 (band_math.h)
 inline bool uses_rccl(const rtx_context* ctx) { return ctx->gather_kind != RTX_GATHER_PEER_COPY; }
 
 int rows_of_rank(const rtx_context* root, int rank)
 {
     if (root->band_layout != 0 && rank < static_cast<int>(root->split_rows.size())) return root->split_rows[rank];
-    const int N = n_ranks(root), n_bands = (root->height + root->band_rows - 1) / root->band_rows;
-    int rows = 0;
-    for (int b = rank; b < n_bands; b += N) {
-        const int y0 = b * root->band_rows, y1 = y0 + root->band_rows < root->height ? y0 + root->band_rows : root->height;
-        rows += y1 - y0;
-    }
-    return rows;
+    return rtbands::rows_interleaved(root->height, root->band_rows, n_ranks(root), rank);
 }
 
 // ---- contiguous bands (RTX_OPT_BAND_LAYOUT 1 / 2) ------------------------------------------------------------------------------
@@ -631,35 +626,22 @@ int rows_of_rank(const rtx_context* root, int rank)
 // that pass re-copied 464 MB per frame on the root, VERDICT r3 weak #6d). The price is balance: sky rows cost a tenth of object rows, so
 // the split is weighted -- by the caller (rtx_set_band_split: every rank of a per-process group names the same split) or, in a
 // single-process context with layout 2, by the library from the ranks' own kernel times two frames back.
-void split_equal(rtx_context* c)
-{
-    const int N = n_ranks(c), H = c->height, units = (H + 7) / 8;
-    c->split_rows.assign(N, 0);
-    c->split_start.assign(N, 0);
-    int y = 0;
-    for (int r = 0; r < N; r++) {
-        const int u = units / N + (r < units % N ? 1 : 0);
-        const int rows = (y + u * 8 <= H) ? u * 8 : (H - y > 0 ? H - y : 0);
-        c->split_start[r] = y;
-        c->split_rows[r] = rows;
-        y += rows;
-    }
-}
+void split_equal(rtx_context* c) { rtbands::split_equal(c->height, n_ranks(c), c->split_rows, c->split_start); }
 // rows[r] rows for rank r, in rank order from row 0: every count a multiple of 8 except the last non-empty one, together the frame
 int split_set(rtx_context* c, const int* rows, int n)
 {
     const int N = n_ranks(c);
-    if (!rows || n != N) return fail(RTX_ERR_INVALID, "rtx_set_band_split: %d counts for %d ranks", n, N);
+    int bad = 0;
     long long total = 0;
-    for (int r = 0; r < N; r++) {
-        if (rows[r] < 0) return fail(RTX_ERR_INVALID, "rtx_set_band_split: negative row count");
-        total += rows[r];
-        if (total < c->height && (rows[r] % 8) != 0) return fail(RTX_ERR_INVALID, "rtx_set_band_split: rank %d gets %d rows -- ranges must start on a multiple of 8 (the kernel's tile height)", r, rows[r]);
+    switch (rtbands::split_check(c->height, rows, n, N, &bad, &total)) {
+        case 0: break;
+        case 1: return fail(RTX_ERR_INVALID, "rtx_set_band_split: %d counts for %d ranks", n, N);
+        case 2: return fail(RTX_ERR_INVALID, "rtx_set_band_split: negative row count");
+        case 3: return fail(RTX_ERR_INVALID, "rtx_set_band_split: rank %d gets %d rows -- ranges must start on a multiple of 8 (the kernel's tile height)", bad, rows[bad]);
+        default: return fail(RTX_ERR_INVALID, "rtx_set_band_split: the ranges cover %lld rows, the frame has %d", total, c->height);
     }
-    if (total != c->height) return fail(RTX_ERR_INVALID, "rtx_set_band_split: the ranges cover %lld rows, the frame has %d", total, c->height);
     c->split_rows.assign(rows, rows + N);
-    c->split_start.assign(N, 0);
-    for (int r = 1; r < N; r++) c->split_start[r] = c->split_start[r - 1] + c->split_rows[r - 1];
+    rtbands::starts_of(c->split_rows, c->split_start);
     return RTX_OK;
 }
 // a rank's packed buffers must hold whatever range a re-split may hand it: the whole frame
@@ -689,57 +671,28 @@ bool launch_ms_ago(rtx_context* c, int ago, float* ms)
     if (hipSetDevice(c->device) != hipSuccess || hipEventQuery(c->ev_stop[idx]) != hipSuccess) return false;
     return hipEventElapsedTime(ms, c->ev_start[idx], c->ev_stop[idx]) == hipSuccess;
 }
-// layout 2, single process: move the boundaries towards equal kernel times. rate_r = rows_r / ms_r two frames back (those launches have
-// finished: nothing waits); the new share of rank r is proportional to its rate, damped by a half, in units of 8 rows, at least one unit.
+// layout 2, single process: move the boundaries towards equal kernel times, from the ranks' own kernel times two frames back (those launches
+// have finished: nothing waits). The arithmetic -- and its guard against frames with fewer 8-row units than ranks -- is band_math.h rebalance.
 void rebalance(rtx_context* root)
 {
     const int N = n_ranks(root);
     if (root->per_process || N < 2 || root->frame_no < 4 || root->frame_no - root->resplit_frame < 3) return;
-    std::vector<double> rate(N, 0.0);
-    double sum = 0.0, tmin = 1e30, tmax = 0.0;
-    int measured = 0, starved = 0;
+    std::vector<double> ms(N, 0.0);
     for (int r = 0; r < N; r++) {
-        if (root->split_rows[r] <= 0) { starved++; continue; }   // a rank a caller's split left without rows: no rate of its own (below)
-        float ms = 0.0f;
-        if (!launch_ms_ago(rank_ctx(root, r), 2, &ms) || !(ms > 0.0f)) return;
-        rate[r] = root->split_rows[r] / static_cast<double>(ms);
-        sum += rate[r];
-        measured++;
-        tmin = ms < tmin ? ms : tmin;
-        tmax = ms > tmax ? ms : tmax;
+        if (root->split_rows[r] <= 0) continue;             // a rank without rows has no time of its own
+        float t = 0.0f;
+        if (!launch_ms_ago(rank_ctx(root, r), 2, &t) || !(t > 0.0f)) return;
+        ms[r] = t;
     }
-    if (measured == 0) return;
-    if (starved > 0) {                                      // it is as fast as the others on average, until it has rows and says otherwise
-        const double mean = sum / measured;
-        for (int r = 0; r < N; r++)
-            if (root->split_rows[r] <= 0) { rate[r] = mean; sum += mean; }
-    } else if (tmax <= 1.04 * tmin) {
-        return;                                             // balanced within the noise of the timers
-    }
-    const int units = (root->height + 7) / 8;
-    std::vector<int> u(N);
-    int used = 0;
-    for (int r = 0; r < N; r++) {
-        const double want = units * rate[r] / sum, have = root->split_rows[r] / 8.0;
-        u[r] = static_cast<int>(have + 0.5 * (want - have) + 0.5);
-        if (u[r] < 1) u[r] = 1;
-        used += u[r];
-    }
-    for (int r = 0; used != units; r = (r + 1) % N) {      // rounding: hand the difference round, one unit at a time
-        if (used < units) { u[r]++; used++; }
-        else if (u[r] > 1) { u[r]--; used--; }
-    }
-    int y = 0;
-    for (int r = 0; r < N; r++) {
-        root->split_start[r] = y;
-        root->split_rows[r] = (y + u[r] * 8 <= root->height) ? u[r] * 8 : root->height - y;
-        y += root->split_rows[r];
-    }
+    std::vector<int> rows, start;
+    if (!rtbands::rebalance(root->height, root->split_rows, ms, rows, start)) return;
+    root->split_rows.swap(rows);
+    root->split_start.swap(start);
     root->resplit_frame = root->frame_no;
 }
 int multi_draw_contiguous(rtx_context* me)
 {
-    const int N = n_ranks(me), par = static_cast<int>(me->frame_no & 1u);
+    const int N = n_ranks(me), par = rtbands::buffer_set(me->frame_no);
     const bool root_here = me->rank == 0;
     const int first_moved = me->loopback ? 0 : 1;
     std::vector<rtx_context*> local;
@@ -832,7 +785,7 @@ int multi_draw_contiguous(rtx_context* me)
 int multi_draw(rtx_context* me)
 {
     if (me->band_layout != 0) return multi_draw_contiguous(me);
-    const int N = n_ranks(me), par = static_cast<int>(me->frame_no & 1u);
+    const int N = n_ranks(me), par = rtbands::buffer_set(me->frame_no);
     const bool root_here = me->rank == 0;
     const int first_moved = me->loopback ? 0 : 1;   // first rank whose bands go through the transport
     std::vector<rtx_context*> local;                 // the ranks this process drives
@@ -855,7 +808,7 @@ int multi_draw(rtx_context* me)
     // The float target without its alpha: every rank whose bands travel packs them to 12 bytes per pixel on its transfer stream (behind its
     // trace, beside the next one), and that is what is sent; the root writes the 1.0f back while it places the bands.
     const bool rgb = me->gather_rgb != 0 && (me->gather_targets & 1) != 0;
-    auto bytes_moved = [&](int t, size_t rows) { return rows * me->width * (t == 0 && rgb ? size_t(12) : target_bytes(t)); };
+    auto bytes_moved = [&](int t, size_t rows) { return rtbands::bytes_moved(me->width, rows, t, rgb); };
     if (rgb)
         for (rtx_context* c : local) {
             if (c->rank < first_moved) continue;
@@ -1517,6 +1470,7 @@ int rtx_get_option(rtx_context* ctx, int option, int* value)
         case RTX_OPT_RAY_PENCILS: *value = ctx->opt_pencils; break;
         case RTX_OPT_GATHER_TARGETS: *value = ctx->gather_targets; break;
         case RTX_OPT_GATHER_RGB: *value = ctx->gather_rgb; break;
+        case RTX_OPT_BAND_LAYOUT: *value = ctx->band_layout; break;
         default: return fail(RTX_ERR_INVALID, "unknown option %d", option);
     }
     return RTX_OK;
@@ -1609,6 +1563,9 @@ int rtx_draw_rows(rtx_context* ctx, int row_first, int n_rows, void* dst_device,
     if (!ctx || !dst_device) return fail(RTX_ERR_INVALID, "rtx_draw_rows: null argument");
     if (ctx->banded) return fail(RTX_ERR_INVALID, "rtx_draw_rows on a multi-device context: it splits the frame itself (rtx_draw)");
     if (row_first < 0 || (row_first % 8) != 0 || n_rows < 0 || row_first + n_rows > ctx->height) return fail(RTX_ERR_INVALID, "rtx_draw_rows: rows [%d, %d) of a %d-row frame (the first must be a multiple of 8)", row_first, row_first + n_rows, ctx->height);
+    // a range that ends inside the frame ends on a tile boundary, like the library's own splits (rtx_set_band_split): the derivative quads of
+    // the texture LOD pair rows 2k and 2k + 1, and a range cut between them would difference its last row against a lane that is not traced
+    if ((n_rows % 8) != 0 && row_first + n_rows != ctx->height) return fail(RTX_ERR_INVALID, "rtx_draw_rows: %d rows from row %d -- a range that does not end the frame must be a multiple of 8 rows", n_rows, row_first);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     if (format == RTX_RGBA32F) return draw_impl(ctx, 8, row_first / 8, 1, static_cast<float*>(dst_device), nullptr, s, n_rows);
     if (format == RTX_RGBA8) return draw_impl(ctx, 8, row_first / 8, 1, nullptr, static_cast<uint32_t*>(dst_device), s, n_rows);

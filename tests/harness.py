@@ -117,6 +117,20 @@ def render(scene_blocks, fb_w, fb_h, textures=None, cubemap=None, cull=True, y0=
     return out, {"closest": cnt[0], "shadow_ref": cnt[1], "shadow_cast": cnt[2], "torus_solves": cnt[3]}
 
 
+def probe(scene_blocks, rays):
+    """Single rays through the product's own scans (harness_probe). rays: (n, 8) float32 -- ro, rd, limit, torus index. Returns (n, 12):
+    literal torus hit, t | product's torus composition hit, t | in_shadow culls on, off | calc_inter culls on: t, num, type | culls off."""
+    fr, _keep = _frame(scene_blocks, 64, 64, None, None, 1)
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+    out = np.zeros((rays.shape[0], 12), dtype=np.float32)
+    fn = lib().harness_probe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    if fn(ctypes.byref(fr), rays.ctypes.data, rays.shape[0], out.ctypes.data) != 0:
+        raise RuntimeError("harness_probe failed")
+    return out
+
+
 def kat(type_, record: bytes, ro, rd, tmin=1e6):
     """(hit, t, culled) from the DEVICE intersector + its cull predicate for one std140 record."""
     out = (ctypes.c_float * 3)()

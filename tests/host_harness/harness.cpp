@@ -169,7 +169,7 @@ int harness_torus_premise(const void* record, int64_t n, uint64_t seed, float di
             cull = std::isfinite(static_cast<double>(b.w)) && m2 > rr * rr && std::fabs(dl2 - 1.0) <= 1e-3;
             (void)t2; (void)solved;
         } else {
-            cull = torus_cull(S.torus_bound()[0], ro, rd, tmin);
+            cull = torus_cull(S.torus_bound()[0], ro, rd);
             if (!cull) { intersect_torus_c<true>(T, ro, rd, tmin, t2, solved); cull = !solved; }
         }
         const bool hit = intersect_torus(T, ro, rd, tmin, t);
@@ -236,7 +236,7 @@ int harness_torus_surface_premise(const void* record, int64_t n, uint64_t seed, 
         const float tmin = u01() < 0.5 ? 1.0e6f : (float)std::pow(10.0, -1.0 + 5.0 * u01());
         bool solved = false;
         float t = 0.0f, t2 = 0.0f;
-        bool cull = torus_cull(S.torus_bound()[0], ro, rd, tmin);
+        bool cull = torus_cull(S.torus_bound()[0], ro, rd);
         if (!cull) { intersect_torus_c<true>(T, ro, rd, tmin, t2, solved); cull = !solved; }
         const bool hit = intersect_torus(T, ro, rd, tmin, t);
         c_cull += cull; c_hit += hit;
@@ -506,6 +506,72 @@ int harness_table_premise(const harness_frame* fr, int64_t n, uint64_t seed, int
     return 0;
 }
 
+// Single rays through the product's own scans on the host (tests/test_culls.py; tools/audit/cull_audit.hip probe_kernel is the same on the
+// device): per ray (ro, rd, limit, torus index) out[0..1] the literal torus intersector: hit, t; out[2..3] the product's composition for that
+// torus (torus_cull, group sphere, intersect_torus_c<true>): hit, t; out[4..5] in_shadow over the whole scene with `limit` as the distance
+// to the light, culls (incl. slab tables) on / off; out[6..8] calc_inter, culls on: t, num, type; out[9..11] culls off.
+int harness_probe(const harness_frame* fr, const float* rays, int n, float* out)
+{
+    std::vector<unsigned char> blocks[rtpack::BLK_COUNT];
+    for (int b = 0; b < 9; b++) {
+        const unsigned char* p = static_cast<const unsigned char*>(fr->blocks[b]);
+        if (p && fr->block_sizes[b]) blocks[b].assign(p, p + fr->block_sizes[b]);
+    }
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!rtpack::pack_scene(fr->defines, blocks, blob, err)) return -1;
+    std::vector<f4> aligned((blob.size() + 15) / 16);
+    std::memcpy(aligned.data(), blob.data(), blob.size());
+    const DevSceneHeader* hdr = reinterpret_cast<const DevSceneHeader*>(aligned.data());
+    std::vector<uint32_t> masks(hdr->pencil_mask_words, 0u);
+    const SceneView S0 = make_view(reinterpret_cast<const char*>(aligned.data()));
+    for (uint32_t k = 0; hdr->n_pencil > 0 && k < hdr->n_pencil + (hdr->pencil_dir != 0xffffffffu ? 1u : 0u); k++) {
+        const DevPencil P = S0.pencils()[k];
+        if (P.kind == RT_PENCIL_OFF) continue;
+        std::vector<PencilPrim> prims(hdr->n_surface + hdr->n_torus);
+        for (size_t i = 0; i < prims.size(); i++) prims[i] = pencil_prim_at(S0, P, static_cast<int>(i));
+#pragma omp parallel for schedule(static, 256)
+        for (int64_t cell = 0; cell <= static_cast<int64_t>(P.cells); cell++) {
+            const PencilCell C = pencil_cell_geometry(P, static_cast<uint32_t>(cell));
+            for (uint32_t w = 0; w < hdr->pencil_stride; w++)
+                masks[P.mask_off + static_cast<size_t>(cell) * hdr->pencil_stride + w] = pencil_cell_word(S0, P, prims.data(), C, static_cast<uint32_t>(cell), static_cast<int>(w));
+        }
+    }
+    const SceneView S = make_view(reinterpret_cast<const char*>(aligned.data()), hdr, masks.empty() ? nullptr : masks.data());
+    TexTable TT;
+    std::memset(&TT, 0, sizeof TT);
+    const int nt = hdr->n_torus;
+    for (int k = 0; k < n; k++) {
+        const float* r = rays + static_cast<size_t>(k) * 8;
+        const f3 ro = mk3(r[0], r[1], r[2]), rd = mk3(r[3], r[4], r[5]);
+        const float limit = r[6];
+        int i = static_cast<int>(r[7]);
+        i = i < 0 ? 0 : (i >= nt ? nt - 1 : i);
+        float* o = out + static_cast<size_t>(k) * 12;
+        for (int j = 0; j < 12; j++) o[j] = 0.0f;
+        if (nt > 0) {
+            const DevTorus T = S.tori()[i];
+            float t = 0.0f;
+            o[0] = intersect_torus(T, ro, rd, limit, t) ? 1.0f : 0.0f; o[1] = t;
+            bool culled = torus_cull(S.torus_bound()[i], ro, rd);
+            if (nt >= RT_GROUP_MIN) culled = culled || torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd);
+            bool solved = false;
+            float t2 = 0.0f;
+            const bool h2 = !culled && intersect_torus_c<true, true>(T, ro, rd, limit, t2, solved);
+            o[2] = h2 ? 1.0f : 0.0f; o[3] = h2 ? t2 : 0.0f;
+        }
+        LaneCounters cnt;
+        std::memset(&cnt, 0, sizeof cnt);
+        o[4] = in_shadow<true, false, true>(S, TT, true, true, ro, rd, limit, cnt, -1);
+        o[5] = in_shadow<false, false, true>(S, TT, true, true, ro, rd, limit, cnt, -1);
+        int num = -1, type = -1;
+        o[6] = calc_inter<true, false, true>(S, ro, rd, num, type, cnt, -1); o[7] = (float)num; o[8] = (float)type;
+        num = -1; type = -1;
+        o[9] = calc_inter<false, false, true>(S, ro, rd, num, type, cnt, -1); o[10] = (float)num; o[11] = (float)type;
+    }
+    return 0;
+}
+
 // Pencil diagnostics for the tests: out[0] = pencils, out[1] = mask words per cell, then per pencil (kind, cells, mean set bits per cell).
 int harness_pencil_stats(const harness_frame* fr, double* out, int max_out)
 {
@@ -569,7 +635,7 @@ int harness_kat(int type, const void* record, const float ro[3], const float rd[
     f2 uv = mk2(0, 0);
     if (type == TYPE_SURFACE) { cull = surface_cull(S.surf_cull()[0], o, dd, tmin); hit = intersect_surface(S.surfaces()[0], o, dd, tmin, t); }
     if (type == TYPE_BOX) { RayBoxCtx bctx; hit = intersect_box(S.boxes()[0], o, dd, tmin, t, nor, bctx); }
-    if (type == TYPE_TORUS) { bool solved; cull = torus_cull(S.torus_bound()[0], o, dd, tmin); if (!cull) { float t2; intersect_torus_c<true>(S.tori()[0], o, dd, tmin, t2, solved); cull = !solved; } hit = intersect_torus(S.tori()[0], o, dd, tmin, t); }
+    if (type == TYPE_TORUS) { bool solved; cull = torus_cull(S.torus_bound()[0], o, dd); if (!cull) { float t2; intersect_torus_c<true>(S.tori()[0], o, dd, tmin, t2, solved); cull = !solved; } hit = intersect_torus(S.tori()[0], o, dd, tmin, t); }
     if (type == TYPE_RING) { cull = ring_cull(S.ring_bound()[0], o, dd, tmin); hit = intersect_ring(S.rings()[0], o, dd, tmin, t, uv); }
     out[0] = hit ? 1.0f : 0.0f;
     out[1] = t;

