@@ -50,6 +50,16 @@
 
 namespace rtdev {
 
+// the value lane 0 of the wave holds (wave-uniform; the host build has one lane)
+RT_HD float rt_first_lane(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+#else
+    return v;
+#endif
+}
+
 // two-wide float vector: element-wise IEEE operations (v_pk_*_f32 on the device, SSE on the host)
 #if defined(__clang__)
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -269,6 +279,7 @@ struct SceneView {
     RT_HDM const f4* torus_group() const { return at<f4>(h->off_torus_group); }
     RT_HDM const DevPencil* pencils() const { return at<DevPencil>(h->off_pencil); }
     RT_HDM const DevSlabs* slabs() const { return at<DevSlabs>(h->off_slabs); }
+    RT_HDM const f4* tile_cull() const { return at<f4>(h->off_tile); }
     const uint32_t* pen;       // pencil masks (a buffer of their own, built on the device), nullptr = none
 };
 // `hdr` normally is the blob's own first record; with the tables staged in LDS it stays in global memory.
@@ -1519,8 +1530,55 @@ RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float
     return ps;
 }
 
+// ---- camera-ray tile masks (rt_scene_dev.h; records built by rt_pack.h) ----
+#ifndef RT_TILE_MASK
+#define RT_TILE_MASK 1   /* 0: A/B builds without the masks (tools/ab_build.sh) */
+#endif
+// The mask of the wave whose tile starts at the pixel with fragment coordinates (fx0, fy0) (the tile's lowest x and y: lane 0) and spans
+// 8 x 8 pixels: bit k set = record k (sphere / box / torus / ring / light sphere, in that order) may be met by one of the wave's camera rays.
+// A camera ray is s (u, v, 1) in camera space with u = (frag.x - W/2) / H, v = (frag.y - H/2) / H (rt.frag:313-317); the tile, widened by a
+// whole pixel on every side (the rays run through pixel CENTRES, half a pixel inside: the rest is slack), is u0 <= u <= u1, v0 <= v <= v1, and
+// the pyramid's side planes are x - u0 z >= 0, u1 z - x >= 0, y - v0 z >= 0, v1 z - y >= 0 (not normalised: the normal of the first is
+// (1, 0, -u0), of length sqrt(1 + u0^2)). A sphere (p, r) lies outside the pyramid if it is on the wrong side of one plane by more than r:
+// g < 0 and g^2 > r^2 |n|^2; or behind the eye altogether (z < -r). Lane k tests record k; one ballot is the mask. NaN anywhere compares
+// false -> bit set; w = +inf (never culled) -> bit set.
+// `plain_dirs`: no lane's direction has an exact zero component -- the condition under which an UNROTATED box may be culled at all (its slab
+// test divides by the direction's components: 0 -> inf, inf - inf = NaN, and the reference reports that as a hit, trap T5); the caller passes
+// the wave's vote, and the box records are forced on without it.
+RT_HD bool tile_record_keep(const SceneView& S, int k, float fx0, float fy0, bool plain_dirs)
+{
+    const float cw = (float)S.h->canvas_w, ch = (float)S.h->canvas_h;
+    const float u0 = (fx0 - 1.0f - cw / 2.0f) / ch, u1 = (fx0 + 8.0f - cw / 2.0f) / ch;
+    const float v0 = (fy0 - 1.0f - ch / 2.0f) / ch, v1 = (fy0 + 8.0f - ch / 2.0f) / ch;
+    const float nu0 = fmaf(u0, u0, 1.0f), nu1 = fmaf(u1, u1, 1.0f), nv0 = fmaf(v0, v0, 1.0f), nv1 = fmaf(v1, v1, 1.0f);
+    const f4 rec = S.tile_cull()[k];
+    const float r2 = rec.w;
+    const float g0 = fmaf(-u0, rec.z, rec.x), g1 = fmaf(u1, rec.z, -rec.x), g2 = fmaf(-v0, rec.z, rec.y), g3 = fmaf(v1, rec.z, -rec.y);
+    const bool out = (g0 < 0.0f && g0 * g0 > r2 * nu0) || (g1 < 0.0f && g1 * g1 > r2 * nu1) || (g2 < 0.0f && g2 * g2 > r2 * nv0) ||
+                     (g3 < 0.0f && g3 * g3 > r2 * nv1) || (rec.z < 0.0f && rec.z * rec.z > r2);
+    const bool is_box = k >= S.h->n_sphere && k < S.h->n_sphere + S.h->n_box;
+    return !out || (is_box && !plain_dirs);
+}
+RT_HD unsigned long long tile_mask(const SceneView& S, float fx0, float fy0, bool plain_dirs)
+{
+    const int n = (int)S.h->n_tile;
+    if (n == 0) return ~0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool k_ok = lane < n;
+    return __ballot(!k_ok || tile_record_keep(S, k_ok ? lane : 0, fx0, fy0, plain_dirs));      // (bits >= n are never looked at)
+#else
+    unsigned long long m = ~0ull;
+    for (int k = 0; k < n; k++) if (!tile_record_keep(S, k, fx0, fy0, plain_dirs)) m &= ~(1ull << k);
+    return m;
+#endif
+}
+RT_HD bool tile_bit(unsigned long long m, int k) { return ((m >> (k & 63)) & 1ull) != 0ull; }
+
+// tmask: camera-ray tile mask of the wave (tile_mask; ~0: none -- every ray that does not start at the eye). Used by the scans of the default
+// kernel variant only (the many-primitive variant has the ray pencils).
 template <bool CULL, bool COUNT, bool GROUPS = true>
-RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1)
+RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1, unsigned long long tmask = ~0ull)
 {
     float tmin = RT_MAXDIST;
     float t = 0.0f;
@@ -1536,9 +1594,10 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         for (int i = 0; i < n; i += 4) {
             const f4 g[4] = {geom[i], geom[i + 1], geom[i + 2], geom[i + 3]};
             const uint32_t hb = S.sph_hollow()[i >> 5] >> (i & 31);
-            RT_UNROLL4(if (i + k < n && intersect_sphere(ro, rd, g[k], ((hb >> k) & 1u) != 0, tmin, t)) { num = i + k; tmin = t; type = TYPE_SPHERE; })
+            RT_UNROLL4(if (i + k < n && tile_bit(tmask, i + k) && intersect_sphere(ro, rd, g[k], ((hb >> k) & 1u) != 0, tmin, t)) { num = i + k; tmin = t; type = TYPE_SPHERE; })
         }
     }
+    int tbit = S.h->n_sphere;    // first tile-mask bit of the class being scanned
     RT_PH_LAP(cnt, PH_C_SPH);
     uint32_t slabw[RT_SLAB_MAX_WORDS];
     if (GROUPS && CULL && !ps.use && slabs_available(S)) {   // a ray of no pencil: its candidates from the slab tables, up to the closest hit so far
@@ -1599,9 +1658,10 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         RayBoxCtx bctx;
         for (int i = 0; i < S.h->n_box; i++) {
             f3 nor;
-            if (intersect_box(S.boxes()[i], ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
+            if (tile_bit(tmask, tbit + i) && intersect_box(S.boxes()[i], ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
         }
     }
+    tbit += S.h->n_box;
     RT_PH_LAP(cnt, PH_C_BOX);
     if (CULL && S.h->n_torus >= RT_LANE_DIVERGENT_MIN) {
         const int n = S.h->n_torus;
@@ -1642,7 +1702,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         const int n = S.h->n_torus;
         const f4* bound = S.torus_bound();
         for (int i = 0; i < n; i += 4) {
-            bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
+            bool need[4] = {tile_bit(tmask, tbit + i), i + 1 < n && tile_bit(tmask, tbit + i + 1), i + 2 < n && tile_bit(tmask, tbit + i + 2), i + 3 < n && tile_bit(tmask, tbit + i + 3)};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd);)
@@ -1661,12 +1721,13 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             }
         }
     }
+    tbit += S.h->n_torus;
     RT_PH_LAP(cnt, PH_C_TORUS);
     {
         const int n = S.h->n_ring;
         const f4* bound = S.ring_bound();
         for (int i = 0; i < n; i += 4) {
-            bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
+            bool need[4] = {tile_bit(tmask, tbit + i), i + 1 < n && tile_bit(tmask, tbit + i + 1), i + 2 < n && tile_bit(tmask, tbit + i + 2), i + 3 < n && tile_bit(tmask, tbit + i + 3)};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !ring_cull(b[k], ro, rd, tmin);)
@@ -1679,9 +1740,10 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             }
         }
     }
+    tbit += S.h->n_ring;
     RT_PH_LAP(cnt, PH_C_RING);
     for (int i = 0; i < S.h->n_light_point; i++) {
-        if (intersect_sphere(ro, rd, S.lights_point()[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
+        if (tile_bit(tmask, tbit + i) && intersect_sphere(ro, rd, S.lights_point()[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
     }
     RT_PH_LAP(cnt, PH_C_LIGHT);
     return tmin;
@@ -2176,6 +2238,13 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
     bool side = false;  // the NEXT trip traces getReflectedColor's ray; the refracted continuation of the main path waits
                         // in PS_CONT_RO / PS_CONT_RD while it runs
     int cam_pencil = 0; // the first trip traces the camera rays: pencil 0; every later ray starts somewhere else
+    // ... and in the default variant the wave's camera-ray tile mask (lane 0 holds the tile's lowest x and y: rt_kernel.hip's lane layout)
+    unsigned long long tmask = ~0ull;
+    if (RT_TILE_MASK && CULL && !GROUPS) {
+        const f3 d0 = P.ld3(PS_RD);
+        const bool plain = !(d0.x == 0.0f || d0.y == 0.0f || d0.z == 0.0f);
+        tmask = tile_mask(S, rt_first_lane(frag_x), rt_first_lane(frag_y), !RT_ANY(!plain));
+    }
 
     alive = alive && iterations > 0;
     RT_PH_DECL;
@@ -2189,8 +2258,9 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- one closest-hit ray per live lane ----
         int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
         float tm = RT_MAXDIST;
-        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt, cam_pencil);
+        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt, cam_pencil, tmask);
         cam_pencil = -1;
+        tmask = ~0ull;
         const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
         RT_PH_LAP(cnt, PH_SCAN);
         const f3 pt = ro + rd * tm;

@@ -26,7 +26,7 @@ using namespace rtdev;
 
 namespace {
 
-enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6 };
+enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6, F_TILE = 7 };
 enum { N_COUNTERS = 128, BAD_FLOATS = 12 };
 
 struct AuditParams {
@@ -624,6 +624,47 @@ __device__ void audit_ring(const AuditParams& p, const SceneView& S, unsigned lo
 }
 
 // ================================================================================================================================
+// camera-ray tile masks (rt_device.h tile_mask; records: rt_pack.h): a random 8 x 8 tile of the scene's canvas (origin anywhere from 8 pixels
+// outside the frame to its far edge, fractional too: the arithmetic does not care), one of its 64 pixel rays as the shader forms it, and
+// for EVERY record whose bit the tile's mask clears the literal intersector of that primitive: it must report no hit (a NaN "hit" of the
+// box test, trap T5, counts as one). plain_dirs is this ray's own: in a wave it is the AND over 64 rays, which only keeps more boxes.
+// counters: 0 rays, 1 records looked at, 2 bits clear, 3 literal hits among the set bits (the masks are not empty talk),
+//           10 VIOLATIONS sphere, 11 box, 12 torus, 13 ring, 14 light sphere; 20 rays whose direction has an exact zero component
+// ================================================================================================================================
+__device__ void audit_tile(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = (int)S.h->n_tile;
+    if (n == 0) return;
+    const int ns = S.h->n_sphere, nb = S.h->n_box, nt = S.h->n_torus, nr = S.h->n_ring;
+    const float W = (float)S.h->canvas_w, H = (float)S.h->canvas_h;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        float x0 = -8.0f + (W + 8.0f) * R.u01(), y0 = -8.0f + (H + 8.0f) * R.u01();
+        if (R.u01() < 0.7f) { x0 = floorf(x0); y0 = floorf(y0); }                      // pixel-aligned like a real tile, mostly
+        const float fx0 = x0 + 0.5f, fy0 = y0 + 0.5f;
+        const int px = (int)(R.next() & 7ull), py = (int)(R.next() & 7ull);
+        const f3 ro = xyz(S.h->cam_pos), rd = ray_dir(S, fx0 + (float)px, fy0 + (float)py);
+        const bool plain = !(rd.x == 0.0f || rd.y == 0.0f || rd.z == 0.0f);
+        c[0]++; c[20] += !plain;
+        RayBoxCtx bctx;
+        for (int k = 0; k < n; k++) {
+            const bool keep = tile_record_keep(S, k, fx0, fy0, plain);
+            float t = 0.0f;
+            bool hit;
+            int cls;
+            if (k < ns) { cls = 0; hit = intersect_sphere(ro, rd, S.sph_geom()[k], ((S.sph_hollow()[k >> 5] >> (k & 31)) & 1u) != 0, RT_MAXDIST, t); }
+            else if (k < ns + nb) { cls = 1; f3 nor; hit = intersect_box(S.boxes()[k - ns], ro, rd, RT_MAXDIST, t, nor, bctx); }
+            else if (k < ns + nb + nt) { cls = 2; hit = intersect_torus(S.tori()[k - ns - nb], ro, rd, RT_MAXDIST, t); }
+            else if (k < ns + nb + nt + nr) { cls = 3; f2 uv; hit = intersect_ring(S.rings()[k - ns - nb - nt], ro, rd, RT_MAXDIST, t, uv); }
+            else { cls = 4; hit = intersect_sphere(ro, rd, S.lights_point()[k - ns - nb - nt - nr].pos_r2, false, RT_MAXDIST, t); }
+            c[1]++; c[2] += !keep; c[3] += keep && hit;
+            if (!keep && hit) { c[10 + cls]++; record_bad(p, 10 + cls, k, ro, rd, fx0, t, fy0); }
+        }
+    }
+}
+
+// ================================================================================================================================
 // candidate tables (ray pencils + slab tables + direction table): rays built like the tracer builds them; for a sample of the primitives
 // whose bit is CLEAR in the ray's mask: a quadric must not be hit by the literal intersector; a torus must stay 5 mm clear of the ray's part
 // up to its limit in exact arithmetic (the premise the torus family audits against the solver).
@@ -720,6 +761,7 @@ __global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
         }
     }
     else if (p.family == F_TORUS_FAR) audit_torus_far(p, S, gid, c);
+    else if (p.family == F_TILE) audit_tile(p, S, gid, c);
     else audit_tables(p, S, gid, c);
     flush(p, c);
     if (p.family == F_TORUS_MARGIN && worst) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 20), worst);
