@@ -41,7 +41,7 @@ extern "C" __attribute__((visibility("default"))) int rtx_debug_scan_stats(unsig
 }
 #endif
 #ifdef RT_WG_TIMES
-// diagnostic build: per-workgroup start time and duration (s_memtime ticks) of the last launch, to see which tiles are the
+// diagnostic build: per-workgroup start time and duration (s_memrealtime: 10 ns ticks, device-wide clock) of the last launch, to see which tiles are the
 // long pole of a launch (tools/wg_times.py)
 __device__ unsigned long long g_wg_start[1 << 16], g_wg_dur[1 << 16];
 extern "C" __attribute__((visibility("default"))) int rtx_debug_wg_times(unsigned long long* start, unsigned long long* dur, int n)
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 #ifdef RT_WG_TIMES
-    const unsigned long long _wg_t0 = clock64();
+    const unsigned long long _wg_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device: start times of different XCDs compare
     const int _wg_id = (by * (int)gridDim.x + bx) & 0xffff;
     if (threadIdx.x == 0) { g_wg_start[_wg_id] = _wg_t0; g_wg_dur[_wg_id] = 0ull; }
 #endif
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     }
 #endif
 #ifdef RT_WG_TIMES
-    if ((threadIdx.x & 63) == 0) atomicMax(&g_wg_dur[_wg_id], (unsigned long long)clock64() - _wg_t0);
+    if ((threadIdx.x & 63) == 0) atomicMax(&g_wg_dur[_wg_id], (unsigned long long)__builtin_amdgcn_s_memrealtime() - _wg_t0);
 #endif
     if (COUNT) {
         uint32_t v[4] = {cnt.closest, cnt.shadow_ref, cnt.shadow_cast, cnt.torus_solves};

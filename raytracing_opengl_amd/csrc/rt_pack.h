@@ -363,6 +363,8 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     const int n_tile_all = d.sphere_size + d.box_size + d.torus_size + d.ring_size + d.light_point_size;
     h.n_tile = 0;
     h.off_tile = n_tile_all > 0 && n_tile_all <= RT_TILE_MAX ? reserve(sizeof(f4) * static_cast<size_t>(n_tile_all)) : 0u;
+    h.n_bsphere = 0;
+    h.off_bsphere = h.off_tile != 0u ? reserve(sizeof(f4) * static_cast<size_t>(n_tile_all)) : 0u;
     h.total_bytes = static_cast<int32_t>(off);
     blob.assign(off, 0);
     std::memcpy(blob.data(), &h, sizeof h);
@@ -837,47 +839,53 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const double n2 = qx * qx + qy * qy + qz * qz + qw * qw;
         const bool cam_ok = std::isfinite(n2) && std::fabs(n2 - 1.0) <= 1e-3 && std::isfinite(h.cam_pos.x) && std::isfinite(h.cam_pos.y) && std::isfinite(h.cam_pos.z) &&
                             h.canvas_w > 0 && h.canvas_h > 0;
-        if (cam_ok) {
-            const double s = 1.0 / std::sqrt(n2), x = qx * s, y = qy * s, z = qz * s, w = qw * s;
-            // rows of R (rotation of the unit quaternion); camera coordinates of a world vector are its products with R's COLUMNS
-            const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
-                                    {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
-                                    {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
-            f4* out = reinterpret_cast<f4*>(blob.data() + h.off_tile);
-            int k = 0;
-            auto put = [&](f4 centre, double rb, bool never) {
-                const double cx = static_cast<double>(centre.x) - h.cam_pos.x, cy = static_cast<double>(centre.y) - h.cam_pos.y, cz = static_cast<double>(centre.z) - h.cam_pos.z;
-                const double px = R[0][0] * cx + R[1][0] * cy + R[2][0] * cz, py = R[0][1] * cx + R[1][1] * cy + R[2][1] * cz, pz = R[0][2] * cx + R[1][2] * cy + R[2][2] * cz;
-                const double d2 = cx * cx + cy * cy + cz * cz;
-                double r2 = 1.004 * rb * rb + 4e-5 * d2 + 1e-4;
-                if (never || !std::isfinite(rb) || !std::isfinite(r2) || !std::isfinite(px) || !std::isfinite(py) || !std::isfinite(pz) || r2 > 1e30 || d2 > 1e30)
-                    r2 = std::numeric_limits<double>::infinity();
-                out[k++] = mk4(static_cast<float>(px), static_cast<float>(py), static_cast<float>(pz), static_cast<float>(r2));
-            };
-            for (int i = 0; i < d.sphere_size; i++) {
-                const DevSphere* sp = reinterpret_cast<const DevSphere*>(blob.data() + h.off_sphere) + i;
-                put(sp->geom, std::fabs(static_cast<double>(sp->radius)), false);
-            }
-            for (int i = 0; i < d.box_size; i++) {
-                const DevBox* b = reinterpret_cast<const DevBox*>(blob.data() + h.off_box) + i;
-                const double fx = b->form_tex.x, fy = b->form_tex.y, fz = b->form_tex.z;
-                const bool plain = quat_is_identity(b->quat) && fx != 0.0 && fy != 0.0 && fz != 0.0;
-                put(b->pos, std::sqrt(fx * fx + fy * fy + fz * fz), !plain);
-            }
-            for (int i = 0; i < d.torus_size; i++) {
-                const f4 tb = reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i];
-                put(tb, std::sqrt(static_cast<double>(tb.w)), !(tb.w >= 0.0f));
-            }
-            for (int i = 0; i < d.ring_size; i++) {
-                const f4 rb = reinterpret_cast<const f4*>(blob.data() + h.off_ring_bound)[i];
-                put(rb, std::sqrt(static_cast<double>(rb.w)), !(rb.w >= 0.0f));
-            }
-            for (int i = 0; i < d.light_point_size; i++) {
-                const DevLightPoint* lp = reinterpret_cast<const DevLightPoint*>(blob.data() + h.off_light_point) + i;
-                put(lp->pos_r2, std::sqrt(std::fabs(static_cast<double>(lp->pos_r2.w))), !(lp->pos_r2.w >= 0.0f));
-            }
-            reinterpret_cast<DevSceneHeader*>(blob.data())->n_tile = static_cast<uint32_t>(k);
+        const double s = cam_ok ? 1.0 / std::sqrt(n2) : 0.0, x = qx * s, y = qy * s, z = qz * s, w = cam_ok ? qw * s : 1.0;
+        // rows of R (rotation of the unit quaternion); camera coordinates of a world vector are its products with R's COLUMNS
+        const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                                {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                                {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+        f4* out = reinterpret_cast<f4*>(blob.data() + h.off_tile);
+        f4* outw = reinterpret_cast<f4*>(blob.data() + h.off_bsphere);
+        int k = 0;
+        auto put = [&](f4 centre, double rb, bool never) {
+            const double cx = static_cast<double>(centre.x) - h.cam_pos.x, cy = static_cast<double>(centre.y) - h.cam_pos.y, cz = static_cast<double>(centre.z) - h.cam_pos.z;
+            const double px = R[0][0] * cx + R[1][0] * cy + R[2][0] * cz, py = R[0][1] * cx + R[1][1] * cy + R[2][1] * cz, pz = R[0][2] * cx + R[1][2] * cy + R[2][2] * cz;
+            const double d2 = cx * cx + cy * cy + cz * cz;
+            double r2 = 1.004 * rb * rb + 4e-5 * d2 + 1e-4;
+            if (never || !std::isfinite(rb) || !std::isfinite(r2) || !std::isfinite(px) || !std::isfinite(py) || !std::isfinite(pz) || r2 > 1e30 || d2 > 1e30)
+                r2 = std::numeric_limits<double>::infinity();
+            out[k] = mk4(static_cast<float>(px), static_cast<float>(py), static_cast<float>(pz), static_cast<float>(r2));
+            // world space, for the shadow masks: the bound radius itself (rounded up); the margins that depend on the rays are added where they are known
+            const bool usable = !never && std::isfinite(rb) && rb < 1e15 && std::isfinite(centre.x) && std::isfinite(centre.y) && std::isfinite(centre.z) &&
+                                std::fabs(centre.x) < 1e15f && std::fabs(centre.y) < 1e15f && std::fabs(centre.z) < 1e15f;
+            outw[k] = mk4(centre.x, centre.y, centre.z, usable ? static_cast<float>(rb * 1.0000002 + 1e-30) : std::numeric_limits<float>::infinity());
+            k++;
+        };
+        for (int i = 0; i < d.sphere_size; i++) {
+            const DevSphere* sp = reinterpret_cast<const DevSphere*>(blob.data() + h.off_sphere) + i;
+            put(sp->geom, std::fabs(static_cast<double>(sp->radius)), false);
         }
+        for (int i = 0; i < d.box_size; i++) {
+            const DevBox* b = reinterpret_cast<const DevBox*>(blob.data() + h.off_box) + i;
+            const double fx = b->form_tex.x, fy = b->form_tex.y, fz = b->form_tex.z;
+            const bool plain = quat_is_identity(b->quat) && fx != 0.0 && fy != 0.0 && fz != 0.0;
+            put(b->pos, std::sqrt(fx * fx + fy * fy + fz * fz), !plain);
+        }
+        for (int i = 0; i < d.torus_size; i++) {
+            const f4 tb = reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i];
+            put(tb, std::sqrt(static_cast<double>(tb.w)), !(tb.w >= 0.0f));
+        }
+        for (int i = 0; i < d.ring_size; i++) {
+            const f4 rb = reinterpret_cast<const f4*>(blob.data() + h.off_ring_bound)[i];
+            put(rb, std::sqrt(static_cast<double>(rb.w)), !(rb.w >= 0.0f));
+        }
+        for (int i = 0; i < d.light_point_size; i++) {
+            const DevLightPoint* lp = reinterpret_cast<const DevLightPoint*>(blob.data() + h.off_light_point) + i;
+            put(lp->pos_r2, std::sqrt(std::fabs(static_cast<double>(lp->pos_r2.w))), !(lp->pos_r2.w >= 0.0f));
+        }
+        DevSceneHeader* hp2 = reinterpret_cast<DevSceneHeader*>(blob.data());
+        hp2->n_tile = cam_ok ? static_cast<uint32_t>(k) : 0u;
+        hp2->n_bsphere = static_cast<uint32_t>(k);
     }
     return true;
 }

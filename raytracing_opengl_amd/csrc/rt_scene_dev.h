@@ -132,6 +132,9 @@ struct alignas(16) DevSceneHeader {
     uint32_t off_slabs, pencil_dir;
     // camera-ray tile masks (DevTileCull below; n_tile = 0: none): one record per sphere, box, torus, ring and point-light sphere, in that order
     uint32_t off_tile, n_tile;
+    // the same primitives' bounding spheres in WORLD space (f4: centre, bound radius -- not squared; +inf: never culled), n_bsphere = 0: none.
+    // What a wave's shadow rays are tested against before their scan (rt_device.h shadow_mask).
+    uint32_t off_bsphere, n_bsphere, _pad2[2];
 };
 
 // ---- camera-ray tile masks: which primitives can a wave's 64 camera rays meet at all? ------------------------------------------------
