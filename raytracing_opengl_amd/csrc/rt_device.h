@@ -50,35 +50,6 @@
 
 namespace rtdev {
 
-// the value lane 0 of the wave holds (wave-uniform; the host build has one lane)
-RT_HD float rt_first_lane(float v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-#else
-    return v;
-#endif
-}
-
-// the largest v over the wave's lanes (every lane must take part: call from wave-uniform control flow; lanes without a value pass -inf)
-RT_HD float rt_wave_max(float v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-#endif
-    return v;
-}
-// the value lane `lane` holds (lane: wave-uniform)
-RT_HD float rt_read_lane(float v, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-#else
-    (void)lane;
-    return v;
-#endif
-}
-
 // two-wide float vector: element-wise IEEE operations (v_pk_*_f32 on the device, SSE on the host)
 #if defined(__clang__)
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -298,8 +269,6 @@ struct SceneView {
     RT_HDM const f4* torus_group() const { return at<f4>(h->off_torus_group); }
     RT_HDM const DevPencil* pencils() const { return at<DevPencil>(h->off_pencil); }
     RT_HDM const DevSlabs* slabs() const { return at<DevSlabs>(h->off_slabs); }
-    RT_HDM const f4* tile_cull() const { return at<f4>(h->off_tile); }
-    RT_HDM const f4* bspheres() const { return at<f4>(h->off_bsphere); }
     const uint32_t* pen;       // pencil masks (a buffer of their own, built on the device), nullptr = none
 };
 // `hdr` normally is the blob's own first record; with the tables staged in LDS it stays in global memory.
@@ -1550,103 +1519,8 @@ RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float
     return ps;
 }
 
-// ---- camera-ray tile masks (rt_scene_dev.h; records built by rt_pack.h) ----
-#ifndef RT_TILE_MASK
-#define RT_TILE_MASK 1   /* 0: A/B builds without the masks (tools/ab_build.sh) */
-#endif
-#ifndef RT_SHADOW_MASK
-#define RT_SHADOW_MASK 1   /* 0: A/B builds without the shadow-ray masks */
-#endif
-// The mask of the wave whose tile starts at the pixel with fragment coordinates (fx0, fy0) (the tile's lowest x and y: lane 0) and spans
-// 8 x 8 pixels: bit k set = record k (sphere / box / torus / ring / light sphere, in that order) may be met by one of the wave's camera rays.
-// A camera ray is s (u, v, 1) in camera space with u = (frag.x - W/2) / H, v = (frag.y - H/2) / H (rt.frag:313-317); the tile, widened by a
-// whole pixel on every side (the rays run through pixel CENTRES, half a pixel inside: the rest is slack), is u0 <= u <= u1, v0 <= v <= v1, and
-// the pyramid's side planes are x - u0 z >= 0, u1 z - x >= 0, y - v0 z >= 0, v1 z - y >= 0 (not normalised: the normal of the first is
-// (1, 0, -u0), of length sqrt(1 + u0^2)). A sphere (p, r) lies outside the pyramid if it is on the wrong side of one plane by more than r:
-// g < 0 and g^2 > r^2 |n|^2; or behind the eye altogether (z < -r). Lane k tests record k; one ballot is the mask. NaN anywhere compares
-// false -> bit set; w = +inf (never culled) -> bit set.
-// `plain_dirs`: no lane's direction has an exact zero component -- the condition under which an UNROTATED box may be culled at all (its slab
-// test divides by the direction's components: 0 -> inf, inf - inf = NaN, and the reference reports that as a hit, trap T5); the caller passes
-// the wave's vote, and the box records are forced on without it.
-RT_HD bool tile_record_keep(const SceneView& S, int k, float fx0, float fy0, bool plain_dirs)
-{
-    const float cw = (float)S.h->canvas_w, ch = (float)S.h->canvas_h;
-    const float u0 = (fx0 - 1.0f - cw / 2.0f) / ch, u1 = (fx0 + 8.0f - cw / 2.0f) / ch;
-    const float v0 = (fy0 - 1.0f - ch / 2.0f) / ch, v1 = (fy0 + 8.0f - ch / 2.0f) / ch;
-    const float nu0 = fmaf(u0, u0, 1.0f), nu1 = fmaf(u1, u1, 1.0f), nv0 = fmaf(v0, v0, 1.0f), nv1 = fmaf(v1, v1, 1.0f);
-    const f4 rec = S.tile_cull()[k];
-    const float r2 = rec.w;
-    const float g0 = fmaf(-u0, rec.z, rec.x), g1 = fmaf(u1, rec.z, -rec.x), g2 = fmaf(-v0, rec.z, rec.y), g3 = fmaf(v1, rec.z, -rec.y);
-    const bool out = (g0 < 0.0f && g0 * g0 > r2 * nu0) || (g1 < 0.0f && g1 * g1 > r2 * nu1) || (g2 < 0.0f && g2 * g2 > r2 * nv0) ||
-                     (g3 < 0.0f && g3 * g3 > r2 * nv1) || (rec.z < 0.0f && rec.z * rec.z > r2);
-    const bool is_box = k >= S.h->n_sphere && k < S.h->n_sphere + S.h->n_box;
-    return !out || (is_box && !plain_dirs);
-}
-RT_HD unsigned long long tile_mask(const SceneView& S, float fx0, float fy0, bool plain_dirs)
-{
-    const int n = (int)S.h->n_tile;
-    if (n == 0) return ~0ull;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const bool k_ok = lane < n;
-    return __ballot(!k_ok || tile_record_keep(S, k_ok ? lane : 0, fx0, fy0, plain_dirs));      // (bits >= n are never looked at)
-#else
-    unsigned long long m = ~0ull;
-    for (int k = 0; k < n; k++) if (!tile_record_keep(S, k, fx0, fy0, plain_dirs)) m &= ~(1ull << k);
-    return m;
-#endif
-}
-RT_HD bool tile_bit(unsigned long long m, int k) { return ((m >> (k & 63)) & 1ull) != 0ull; }
-// some bit of the four from k on (a batch of records: skipped BEFORE its scalar loads are issued when all four are clear)
-RT_HD bool tile_any4(unsigned long long m, int k) { return ((m >> (k & 63)) & 15ull) != 0ull || k > 59; }
-
-// ---- shadow-ray masks (round 5): which primitives can the wave's shadow rays towards ONE light meet at all? ----
-// The shadow rays of a shading site start at the wave's hit points and run to the light: from a point light they are the segments
-// pt_i -> L, from a directional light the parallel half-lines pt_i + s u. With P one of the hit points and rho >= |pt_i - P| for all of them,
-// every such segment stays within rho of the segment P -> L (a point at parameter s of pt_i -> L is (1 - s)(pt_i - P) away from the point
-// at s of P -> L), every half-line within rho of the half-line from P. So a primitive whose bounding sphere (c, rb) keeps a distance of
-// more than rb' + rho from that segment / half-line is met by none of the wave's rays: rb'^2 = 1.004 rb^2 + 4e-5 (|c - P| + rho)^2 + 1e-4
-// pads the bound for what the reference's float tests can make of a near miss (as the camera-ray records do, rt_pack.h). Lane k tests
-// world-space record k (rt_scene_dev.h off_bsphere: spheres, boxes, tori, rings, light spheres); one ballot is the mask.
-//   u, len: unit direction and length of P -> L (len = +inf for a directional light);
-//   tori: bit forced on for a point light -- a torus cull may not use the ray's own limit (torus_cull), and beyond the light the wave's
-//         rays fan out again; for a directional light the half-lines are parallel and the test is the lateral one;
-//   boxes: forced on unless `plain_dirs` (no lane's direction has an exact zero component: trap T5, see tile_mask).
-RT_HD bool shadow_record_keep(const SceneView& S, int k, f3 P, float rho, f3 u, float len, bool plain_dirs)
-{
-    const int box0 = S.h->n_sphere, box1 = box0 + S.h->n_box, tor1 = box1 + S.h->n_torus;
-    const f4 rec = S.bspheres()[k];
-    const f3 w = xyz(rec) - P;
-    const float d2c = dot3_fma(w, w);
-    const float s = gl_min(gl_max(dot3_fma(w, u), 0.0f), len);          // nearest point of the segment / half-line (len = inf: half-line)
-    const f3 q = mk3(fmaf(-s, u.x, w.x), fmaf(-s, u.y, w.y), fmaf(-s, u.z, w.z));
-    const float d2 = dot3_fma(q, q);
-    const float far = rt_sqrt_approx(d2c) + rho;
-    const float rb2 = fmaf(1.004f * rec.w, rec.w, fmaf(4.0e-5f * far, far, 1.0e-4f));
-    const float lim = rt_sqrt_approx(rb2) * 1.0001f + rho * 1.0001f;
-    const bool out = d2 > lim * lim * 1.0001f;                          // NaN / inf -> false -> kept
-    const bool forced = (k >= box0 && k < box1 && !plain_dirs) || (k >= box1 && k < tor1 && len < 3.0e38f);
-    return !out || forced;
-}
-RT_HD unsigned long long shadow_mask(const SceneView& S, f3 P, float rho, f3 u, float len, bool plain_dirs)
-{
-    const int n = (int)S.h->n_bsphere;
-    if (n == 0) return ~0ull;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const bool k_ok = lane < n;
-    return __ballot(!k_ok || shadow_record_keep(S, k_ok ? lane : 0, P, rho, u, len, plain_dirs));
-#else
-    unsigned long long m = ~0ull;
-    for (int k = 0; k < n; k++) if (!shadow_record_keep(S, k, P, rho, u, len, plain_dirs)) m &= ~(1ull << k);
-    return m;
-#endif
-}
-
-// tmask: camera-ray tile mask of the wave (tile_mask; ~0: none -- every ray that does not start at the eye). Used by the scans of the default
-// kernel variant only (the many-primitive variant has the ray pencils).
 template <bool CULL, bool COUNT, bool GROUPS = true>
-RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1, unsigned long long tmask = ~0ull)
+RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1)
 {
     float tmin = RT_MAXDIST;
     float t = 0.0f;
@@ -1660,13 +1534,11 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         const int n = S.h->n_sphere;
         const f4* geom = S.sph_geom();
         for (int i = 0; i < n; i += 4) {
-            if (!tile_any4(tmask, i)) continue;
             const f4 g[4] = {geom[i], geom[i + 1], geom[i + 2], geom[i + 3]};
             const uint32_t hb = S.sph_hollow()[i >> 5] >> (i & 31);
-            RT_UNROLL4(if (i + k < n && tile_bit(tmask, i + k) && intersect_sphere(ro, rd, g[k], ((hb >> k) & 1u) != 0, tmin, t)) { num = i + k; tmin = t; type = TYPE_SPHERE; })
+            RT_UNROLL4(if (i + k < n && intersect_sphere(ro, rd, g[k], ((hb >> k) & 1u) != 0, tmin, t)) { num = i + k; tmin = t; type = TYPE_SPHERE; })
         }
     }
-    int tbit = S.h->n_sphere;    // first tile-mask bit of the class being scanned
     RT_PH_LAP(cnt, PH_C_SPH);
     uint32_t slabw[RT_SLAB_MAX_WORDS];
     if (GROUPS && CULL && !ps.use && slabs_available(S)) {   // a ray of no pencil: its candidates from the slab tables, up to the closest hit so far
@@ -1727,10 +1599,9 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         RayBoxCtx bctx;
         for (int i = 0; i < S.h->n_box; i++) {
             f3 nor;
-            if (tile_bit(tmask, tbit + i) && intersect_box(S.boxes()[i], ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
+            if (intersect_box(S.boxes()[i], ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
         }
     }
-    tbit += S.h->n_box;
     RT_PH_LAP(cnt, PH_C_BOX);
     if (CULL && S.h->n_torus >= RT_LANE_DIVERGENT_MIN) {
         const int n = S.h->n_torus;
@@ -1771,8 +1642,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         const int n = S.h->n_torus;
         const f4* bound = S.torus_bound();
         for (int i = 0; i < n; i += 4) {
-            if (!tile_any4(tmask, tbit + i)) continue;
-            bool need[4] = {tile_bit(tmask, tbit + i), i + 1 < n && tile_bit(tmask, tbit + i + 1), i + 2 < n && tile_bit(tmask, tbit + i + 2), i + 3 < n && tile_bit(tmask, tbit + i + 3)};
+            bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd);)
@@ -1791,14 +1661,12 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             }
         }
     }
-    tbit += S.h->n_torus;
     RT_PH_LAP(cnt, PH_C_TORUS);
     {
         const int n = S.h->n_ring;
         const f4* bound = S.ring_bound();
         for (int i = 0; i < n; i += 4) {
-            if (!tile_any4(tmask, tbit + i)) continue;
-            bool need[4] = {tile_bit(tmask, tbit + i), i + 1 < n && tile_bit(tmask, tbit + i + 1), i + 2 < n && tile_bit(tmask, tbit + i + 2), i + 3 < n && tile_bit(tmask, tbit + i + 3)};
+            bool need[4] = {true, i + 1 < n, i + 2 < n, i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !ring_cull(b[k], ro, rd, tmin);)
@@ -1811,10 +1679,9 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             }
         }
     }
-    tbit += S.h->n_ring;
     RT_PH_LAP(cnt, PH_C_RING);
     for (int i = 0; i < S.h->n_light_point; i++) {
-        if (tile_bit(tmask, tbit + i) && intersect_sphere(ro, rd, S.lights_point()[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
+        if (intersect_sphere(ro, rd, S.lights_point()[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
     }
     RT_PH_LAP(cnt, PH_C_LIGHT);
     return tmin;
@@ -1825,7 +1692,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
 // early exit is exact. The any-hit scan is an OR (a float sum for textured rings only), so the
 // cheap classes go first; ring order is kept for the sum.
 template <bool CULL, bool COUNT, bool GROUPS = true>
-RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt, int pencil = -1, unsigned long long smask = ~0ull)
+RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt, int pencil = -1)
 {
     float shadow = 0.0f;
     float t = 0.0f;
@@ -1835,9 +1702,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         const int n = S.h->n_sphere;
         const f4* geom = S.sph_geom();
         for (int i = 0; i < n; i += 4) {
-            if (!tile_any4(smask, i)) continue;
             const f4 g[4] = {geom[i], geom[i + 1], geom[i + 2], geom[i + 3]};
-            RT_UNROLL4(if (on && i + k < n && tile_bit(smask, i + k) && intersect_sphere(ro, rd, g[k], false, dist, t)) { shadow = 1.0f; on = false; })
+            RT_UNROLL4(if (on && i + k < n && intersect_sphere(ro, rd, g[k], false, dist, t)) { shadow = 1.0f; on = false; })
             if (!RT_ANY(on)) break;
         }
     }
@@ -1845,7 +1711,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         RayBoxCtx bctx;
         for (int i = 0; i < S.h->n_box; i++) {
             f3 nor;
-            if (!tile_bit(smask, S.h->n_sphere + i)) continue;
             if (on && intersect_box(S.boxes()[i], ro, rd, dist, t, nor, bctx)) { shadow = 1.0f; on = false; }
             if (!RT_ANY(on)) break;
         }
@@ -1945,10 +1810,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
     } else if (RT_ANY(on)) {
         const int n = S.h->n_torus;
         const f4* bound = S.torus_bound();
-        const int tb0 = S.h->n_sphere + S.h->n_box;
         for (int i = 0; i < n; i += 4) {
-            if (!tile_any4(smask, tb0 + i)) continue;
-            bool need[4] = {on && tile_bit(smask, tb0 + i), on && i + 1 < n && tile_bit(smask, tb0 + i + 1), on && i + 2 < n && tile_bit(smask, tb0 + i + 2), on && i + 3 < n && tile_bit(smask, tb0 + i + 3)};
+            bool need[4] = {on, on && i + 1 < n, on && i + 2 < n, on && i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd);)
@@ -1977,11 +1840,9 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
     if (RT_ANY(ring_on)) {
         const int n = S.h->n_ring;
         const f4* bound = S.ring_bound();
-        const int rb0 = S.h->n_sphere + S.h->n_box + S.h->n_torus;
         for (int i = 0; i < n; i += 4) {
-            if (!tile_any4(smask, rb0 + i)) continue;
             const bool live = lod ? ref_on : on;
-            bool need[4] = {live && tile_bit(smask, rb0 + i), live && i + 1 < n && tile_bit(smask, rb0 + i + 1), live && i + 2 < n && tile_bit(smask, rb0 + i + 2), live && i + 3 < n && tile_bit(smask, rb0 + i + 3)};
+            bool need[4] = {live, live && i + 1 < n, live && i + 2 < n, live && i + 3 < n};
             if (CULL) {
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !ring_cull(b[k], ro, rd, dist);)
@@ -2026,23 +1887,6 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
     f3 specular = mk3(0.0f, 0.0f, 0.0f);
     const f3 ambient = xyz(S.h->ambient), shadow_ambient = xyz(S.h->shadow_ambient);
     const int n_lp = S.h->n_light_point, n_ld = S.h->n_light_direct;
-    // shadow-ray masks (default variant): P = the hit point of the first shading lane, rho = how far the wave's other hit points are from it
-    f3 sm_P = mk3(0.0f, 0.0f, 0.0f);
-    float sm_rho = 0.0f;
-    const bool use_smask = RT_SHADOW_MASK && CULL && !GROUPS && S.h->n_bsphere != 0u;
-    if (use_smask) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned long long onb = __ballot(on);
-        const int src = onb != 0ull ? __builtin_ctzll(onb) : 0;
-#else
-        const int src = 0;
-#endif
-        sm_P = mk3(rt_read_lane(pt.x, src), rt_read_lane(pt.y, src), rt_read_lane(pt.z, src));
-        const f3 dp0 = pt - sm_P;
-        // (a lane whose point is not finite makes rho NaN or inf: nothing is culled then)
-        sm_rho = rt_wave_max(on ? rt_sqrt_approx(dot3_fma(dp0, dp0)) * 1.0001f + 1.0e-6f * (fabsf(pt.x) + fabsf(pt.y) + fabsf(pt.z)) : -1.0f);
-        if (!(sm_rho >= 0.0f)) sm_rho = __builtin_huge_valf();
-    }
     for (int li = 0; li < n_lp + n_ld; li++) {
         f3 light_color, light_dir;
         float intensity, dist, distDiv;
@@ -2070,23 +1914,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         // (NaN dp must still take the full path so that it propagates like in the shader.)
         const bool cast = on && !(dp == 0.0f);
         RT_PH_BEGIN(_sh0);
-        unsigned long long smask = ~0ull;
-        if (use_smask) {
-            f3 u;
-            float len;
-            if (li < n_lp) {
-                const f3 v = xyz(S.lights_point()[li].pos_r2) - sm_P;
-                len = rt_sqrt_approx(dot3_fma(v, v));
-                u = v * (1.0f / len);
-                len = len * 1.0001f + sm_rho;      // (the rays end at the light; a lane's own distance differs from P's by at most rho)
-            } else {
-                u = light_dir;
-                len = __builtin_huge_valf();
-            }
-            const bool zero_dir = on && (light_dir.x == 0.0f || light_dir.y == 0.0f || light_dir.z == 0.0f);
-            smask = shadow_mask(S, sm_P, sm_rho, u, len, !RT_ANY(zero_dir));
-        }
-        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS>(S, T, cast, on, pt, light_dir, dist, cnt, 1 + li, smask);   // pencil 0 is the camera's
+        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS>(S, T, cast, on, pt, light_dir, dist, cnt, 1 + li);   // pencil 0 is the camera's
         RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
@@ -2348,13 +2176,6 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
     bool side = false;  // the NEXT trip traces getReflectedColor's ray; the refracted continuation of the main path waits
                         // in PS_CONT_RO / PS_CONT_RD while it runs
     int cam_pencil = 0; // the first trip traces the camera rays: pencil 0; every later ray starts somewhere else
-    // ... and in the default variant the wave's camera-ray tile mask (lane 0 holds the tile's lowest x and y: rt_kernel.hip's lane layout)
-    unsigned long long tmask = ~0ull;
-    if (RT_TILE_MASK && CULL && !GROUPS) {
-        const f3 d0 = P.ld3(PS_RD);
-        const bool plain = !(d0.x == 0.0f || d0.y == 0.0f || d0.z == 0.0f);
-        tmask = tile_mask(S, rt_first_lane(frag_x), rt_first_lane(frag_y), !RT_ANY(!plain));
-    }
 
     alive = alive && iterations > 0;
     RT_PH_DECL;
@@ -2368,9 +2189,8 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- one closest-hit ray per live lane ----
         int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
         float tm = RT_MAXDIST;
-        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt, cam_pencil, tmask);
+        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt, cam_pencil);
         cam_pencil = -1;
-        tmask = ~0ull;
         const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
         RT_PH_LAP(cnt, PH_SCAN);
         const f3 pt = ro + rd * tm;

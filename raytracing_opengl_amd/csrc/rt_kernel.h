@@ -13,7 +13,6 @@ struct RtLaunchParams {
     int32_t band_rows, band_first, band_stride, rows_local;
     int32_t xcd_remap;        // 1: XCD-aware super-tile order (see rt_kernel.hip)
     int32_t hot_row0, hot_rows;  // workgroup rows [hot_row0, hot_row0 + hot_rows) of this launch are dispatched first (0 rows = off)
-    int32_t hot_prio;         // > 0: waves of those rows also run at this s_setprio level (0 .. 3) for their whole life
     int32_t grid_x, grid_y, st_nx, st_ny;  // filled by rt_launch_trace
     int32_t ps_fence_slot;    // filled at launch: the variant's pad slot, deliberately a run-time value (rtdev::PathStore::fence)
     float* out_f32;           // RGBA32F, 16 B/pixel, or nullptr

@@ -130,14 +130,13 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
         if (p.hot_rows > 0) {
             const int k = by;
             by = k < p.hot_rows ? p.hot_row0 + k : (k - p.hot_rows < p.hot_row0 ? k - p.hot_rows : k);
-            // ... and, round 5, issued ahead of the other waves of their SIMD: a torus tile's wave is one serial chain of solver runs (4 bounces x 3
-            // scans), and sharing a SIMD's issue slots with five sky waves stretches exactly the chain the launch ends with
-            // (inline asm without a memory clobber, NOT __builtin_amdgcn_s_setprio: the builtin counts as a possible store, after which no load of
-            // the scene blob is "known unclobbered" any more and every scalar load of the kernel turns into a vector load -- s_load 305 -> 34,
-            // scratch 44 -> 92 B, the 4K default frame 0.46 -> 0.66 ms, measured by accident: profiles/r05d_setprio_builtin_clobbers_scalar_loads.txt)
-            // (nor a volatile asm: anything with side effects does it. The asm below is pure as far as the compiler knows -- it "computes" by, which
-            // is used -- so it stays, in place, and clobbers nothing.)
-            if (k < p.hot_rows && p.hot_prio > 0) asm("s_setprio 3" : "+s"(by));
+            // (Round 5 also ran these waves at s_setprio 3 -- a torus tile's wave is one serial chain of solver runs, and it shares its SIMD's issue
+            // slots with five sky waves: no gain at 640x480 ... 4K nor for a rank's share of a frame, profiles/r05e_hot_rows_setprio_*.txt. One
+            // thing learnt on the way: __builtin_amdgcn_s_setprio, or a volatile asm, ANYWHERE in the kernel -- even on a path never taken --
+            // counts as a possible store, after which no load of the scene blob is "known unclobbered" and every scalar load of the kernel
+            // becomes a vector load: s_load 222 -> 30, scratch 44 -> 92 B, the 4K frame 0.46 -> 0.66 ms
+            // (profiles/r05d_setprio_builtin_clobbers_scalar_loads.txt). asm("s_setprio 3" : "+s"(by)) does not. Round 4's "s_setprio at 4K:
+            // 680 us" was most likely that effect, not the priority.)
         }
     }
     const int lane = threadIdx.x & 63;

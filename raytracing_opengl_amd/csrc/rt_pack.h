@@ -359,12 +359,6 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
     const bool slabs = n_pencil > 0 && h.pencil_stride <= RT_SLAB_MAX_WORDS;
     h.off_slabs = slabs ? reserve(sizeof(DevSlabs)) : 0u;
     const uint32_t off_slab_table = slabs ? reserve(sizeof(uint32_t) * 3 * RT_SLAB_LEVELS * RT_SLABS * h.pencil_stride) : 0u;
-    // camera-ray tile masks (rt_scene_dev.h): spheres, boxes, tori, rings, point-light spheres -- filled at the end of this function
-    const int n_tile_all = d.sphere_size + d.box_size + d.torus_size + d.ring_size + d.light_point_size;
-    h.n_tile = 0;
-    h.off_tile = n_tile_all > 0 && n_tile_all <= RT_TILE_MAX ? reserve(sizeof(f4) * static_cast<size_t>(n_tile_all)) : 0u;
-    h.n_bsphere = 0;
-    h.off_bsphere = h.off_tile != 0u ? reserve(sizeof(f4) * static_cast<size_t>(n_tile_all)) : 0u;
     h.total_bytes = static_cast<int32_t>(off);
     blob.assign(off, 0);
     std::memcpy(blob.data(), &h, sizeof h);
@@ -823,69 +817,6 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             }
         }
         hp->pencil_mask_words = n_pencil > 0 ? mask_words + 4u : 0u;   // + spare words: the scans request one word ahead
-    }
-    // ---- camera-ray tile masks (rt_scene_dev.h, rt_device.h tile_mask) ----
-    // Camera rays are normalize(rotate(q, (u, v, 1))) (rt.frag:313-317); rotate is q v q* = |q|^2 R v, so up to a positive factor a ray is
-    // R (u, v, 1) and a world vector w has camera coordinates R^T w. Everything here is double arithmetic on the float inputs; the
-    // device's float rays differ from these by ~1e-7 rad, against the whole pixel (>= 2e-4 rad at 8K) the tile is widened by.
-    // A record's squared radius covers (a) the primitive's own bound, (b) what the reference's float arithmetic can make of a near miss:
-    // the sphere test's discriminant b^2 - c cancels to ~1e-6 |oc|^2 (sphere_cull: "beyond rounding doubt" = 1e-5 |oc|^2), the box slabs and the
-    // torus / ring bounds are off by ~1e-6 |oc| -- together r_eff^2 = 1.004 r^2 + 4e-5 |oc|^2 + 1e-4, several times each.
-    // Never culled (+inf): anything non-finite; a box with a rotation (its slab test divides by the ROTATED direction's components, and an
-    // exact zero there makes 0 * inf = NaN, which the reference reports as a hit -- trap T5; for an unrotated box tile_mask checks the
-    // wave's directions themselves) or with a zero half extent (the same NaN from |1/d| * 0); tori and rings whose own bound is not finite.
-    if (h.off_tile != 0u) {
-        const double qx = h.cam_quat.x, qy = h.cam_quat.y, qz = h.cam_quat.z, qw = h.cam_quat.w;
-        const double n2 = qx * qx + qy * qy + qz * qz + qw * qw;
-        const bool cam_ok = std::isfinite(n2) && std::fabs(n2 - 1.0) <= 1e-3 && std::isfinite(h.cam_pos.x) && std::isfinite(h.cam_pos.y) && std::isfinite(h.cam_pos.z) &&
-                            h.canvas_w > 0 && h.canvas_h > 0;
-        const double s = cam_ok ? 1.0 / std::sqrt(n2) : 0.0, x = qx * s, y = qy * s, z = qz * s, w = cam_ok ? qw * s : 1.0;
-        // rows of R (rotation of the unit quaternion); camera coordinates of a world vector are its products with R's COLUMNS
-        const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
-                                {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
-                                {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
-        f4* out = reinterpret_cast<f4*>(blob.data() + h.off_tile);
-        f4* outw = reinterpret_cast<f4*>(blob.data() + h.off_bsphere);
-        int k = 0;
-        auto put = [&](f4 centre, double rb, bool never) {
-            const double cx = static_cast<double>(centre.x) - h.cam_pos.x, cy = static_cast<double>(centre.y) - h.cam_pos.y, cz = static_cast<double>(centre.z) - h.cam_pos.z;
-            const double px = R[0][0] * cx + R[1][0] * cy + R[2][0] * cz, py = R[0][1] * cx + R[1][1] * cy + R[2][1] * cz, pz = R[0][2] * cx + R[1][2] * cy + R[2][2] * cz;
-            const double d2 = cx * cx + cy * cy + cz * cz;
-            double r2 = 1.004 * rb * rb + 4e-5 * d2 + 1e-4;
-            if (never || !std::isfinite(rb) || !std::isfinite(r2) || !std::isfinite(px) || !std::isfinite(py) || !std::isfinite(pz) || r2 > 1e30 || d2 > 1e30)
-                r2 = std::numeric_limits<double>::infinity();
-            out[k] = mk4(static_cast<float>(px), static_cast<float>(py), static_cast<float>(pz), static_cast<float>(r2));
-            // world space, for the shadow masks: the bound radius itself (rounded up); the margins that depend on the rays are added where they are known
-            const bool usable = !never && std::isfinite(rb) && rb < 1e15 && std::isfinite(centre.x) && std::isfinite(centre.y) && std::isfinite(centre.z) &&
-                                std::fabs(centre.x) < 1e15f && std::fabs(centre.y) < 1e15f && std::fabs(centre.z) < 1e15f;
-            outw[k] = mk4(centre.x, centre.y, centre.z, usable ? static_cast<float>(rb * 1.0000002 + 1e-30) : std::numeric_limits<float>::infinity());
-            k++;
-        };
-        for (int i = 0; i < d.sphere_size; i++) {
-            const DevSphere* sp = reinterpret_cast<const DevSphere*>(blob.data() + h.off_sphere) + i;
-            put(sp->geom, std::fabs(static_cast<double>(sp->radius)), false);
-        }
-        for (int i = 0; i < d.box_size; i++) {
-            const DevBox* b = reinterpret_cast<const DevBox*>(blob.data() + h.off_box) + i;
-            const double fx = b->form_tex.x, fy = b->form_tex.y, fz = b->form_tex.z;
-            const bool plain = quat_is_identity(b->quat) && fx != 0.0 && fy != 0.0 && fz != 0.0;
-            put(b->pos, std::sqrt(fx * fx + fy * fy + fz * fz), !plain);
-        }
-        for (int i = 0; i < d.torus_size; i++) {
-            const f4 tb = reinterpret_cast<const f4*>(blob.data() + h.off_torus_bound)[i];
-            put(tb, std::sqrt(static_cast<double>(tb.w)), !(tb.w >= 0.0f));
-        }
-        for (int i = 0; i < d.ring_size; i++) {
-            const f4 rb = reinterpret_cast<const f4*>(blob.data() + h.off_ring_bound)[i];
-            put(rb, std::sqrt(static_cast<double>(rb.w)), !(rb.w >= 0.0f));
-        }
-        for (int i = 0; i < d.light_point_size; i++) {
-            const DevLightPoint* lp = reinterpret_cast<const DevLightPoint*>(blob.data() + h.off_light_point) + i;
-            put(lp->pos_r2, std::sqrt(std::fabs(static_cast<double>(lp->pos_r2.w))), !(lp->pos_r2.w >= 0.0f));
-        }
-        DevSceneHeader* hp2 = reinterpret_cast<DevSceneHeader*>(blob.data());
-        hp2->n_tile = cam_ok ? static_cast<uint32_t>(k) : 0u;
-        hp2->n_bsphere = static_cast<uint32_t>(k);
     }
     return true;
 }

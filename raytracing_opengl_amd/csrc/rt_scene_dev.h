@@ -129,22 +129,8 @@ struct alignas(16) DevSceneHeader {
     uint32_t n_pencil, off_pencil, pencil_stride, pencil_mask_words;
     // rays outside every pencil (mirror / refracted rays, shadow rays of lights without one): slab tables (DevSlabs below; 0 = none) and
     // the direction table of the quadrics' degenerate branch (record n_pencil of the pencil array; 0xffffffff = none)
-    uint32_t off_slabs, pencil_dir;
-    // camera-ray tile masks (DevTileCull below; n_tile = 0: none): one record per sphere, box, torus, ring and point-light sphere, in that order
-    uint32_t off_tile, n_tile;
-    // the same primitives' bounding spheres in WORLD space (f4: centre, bound radius -- not squared; +inf: never culled), n_bsphere = 0: none.
-    // What a wave's shadow rays are tested against before their scan (rt_device.h shadow_mask).
-    uint32_t off_bsphere, n_bsphere, _pad2[2];
+    uint32_t off_slabs, pencil_dir, _pad[2];
 };
-
-// ---- camera-ray tile masks: which primitives can a wave's 64 camera rays meet at all? ------------------------------------------------
-// A wave traces an 8 x 8 pixel tile, and its camera rays lie inside the pyramid from the eye through that tile. Per primitive with a bounding
-// sphere the packer stores the sphere's centre in CAMERA space (x, y along the image axes, z along the view direction: a camera ray is
-// s (u, v, 1), s > 0, with u, v the shader's own screen coordinates, rt.frag:313-317) and its padded squared radius (w; +inf: never
-// culled). At the start of a pixel program lane k tests record k against the four side planes of the tile's pyramid, one ballot makes
-// the wave's mask, and the first closest-hit scan -- the only one that traces camera rays -- skips every primitive whose bit is clear
-// without a single vector instruction (rt_device.h tile_mask). At most 64 records; scenes with more have n_tile = 0.
-enum { RT_TILE_MAX = 64 };
 
 // ---- ray pencils: third-level cull for long tables ---------------------------------------------
 // Most rays of a frame belong to one of a few PENCILS: camera rays all start at the eye, shadow rays towards a point light all end at

@@ -394,10 +394,6 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     constexpr int HOT_MAX_WG = 24000;
     const int launch_wg = ((ctx->width + 31) / 32) * ((rows_local + 7) / 8);
     if (ctx->opt_hot && !ctx->opt_xcd && (band_stride >= 4 || launch_wg <= HOT_MAX_WG)) hot_rows(ctx, p);
-    {   // experiment knob (tools/runs/r05_hot_prio.sh): RTX_HOT_PRIO=1 raises the hot rows' waves to s_setprio 3
-        static const int hot_prio = std::getenv("RTX_HOT_PRIO") ? std::atoi(std::getenv("RTX_HOT_PRIO")) : 0;
-        p.hot_prio = hot_prio;
-    }
     p.out_f32 = out_f32;
     p.out_u8 = out_u8;
     p.counters = ctx->d_counters;

@@ -45,7 +45,7 @@ def test_recorded_far_origin_torus_rays_on_the_gpu(audit):
 
 # rays per family: every torus ray of the `torus` family that some cull rejects is also SOLVED (that is the check), the margin and lead
 # families solve every ray
-@pytest.mark.parametrize("family,rays", [("torus", 3e9), ("torus_margin", 4e8), ("torus_lead", 4e8), ("torus_far", 4e8), ("quadric", 3e9), ("ring", 3e9), ("tables", 2e9), ("tile", 2e9)])
+@pytest.mark.parametrize("family,rays", [("torus", 3e9), ("torus_margin", 4e8), ("torus_lead", 4e8), ("torus_far", 4e8), ("quadric", 3e9), ("ring", 3e9), ("tables", 2e9)])
 def test_cull_audit(audit, family, rays):
     ca, lib = audit
     scs = ca.scene_list(3)          # the bench scenes + 3 seeds of each generator of tests/random_scenes.py
@@ -62,5 +62,3 @@ def test_cull_audit(audit, family, rays):
         assert c[1] > 0.1 * c[0] and c[3] > 0
     if family == "tables":
         assert c[6] + c[7] > 0
-    if family == "tile":
-        assert c[2] > 0.3 * c[1] and c[3] > 0, "the tile masks should clear a good share of the bits, and set bits should hold real hits"

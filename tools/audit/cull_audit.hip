@@ -26,7 +26,7 @@ using namespace rtdev;
 
 namespace {
 
-enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6, F_TILE = 7, F_SHADOW = 8 };
+enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6 };
 enum { N_COUNTERS = 128, BAD_FLOATS = 12 };
 
 struct AuditParams {
@@ -624,107 +624,6 @@ __device__ void audit_ring(const AuditParams& p, const SceneView& S, unsigned lo
 }
 
 // ================================================================================================================================
-// camera-ray tile masks (rt_device.h tile_mask; records: rt_pack.h): a random 8 x 8 tile of the scene's canvas (origin anywhere from 8 pixels
-// outside the frame to its far edge, fractional too: the arithmetic does not care), one of its 64 pixel rays as the shader forms it, and
-// for EVERY record whose bit the tile's mask clears the literal intersector of that primitive: it must report no hit (a NaN "hit" of the
-// box test, trap T5, counts as one). plain_dirs is this ray's own: in a wave it is the AND over 64 rays, which only keeps more boxes.
-// counters: 0 rays, 1 records looked at, 2 bits clear, 3 literal hits among the set bits (the masks are not empty talk),
-//           10 VIOLATIONS sphere, 11 box, 12 torus, 13 ring, 14 light sphere; 20 rays whose direction has an exact zero component
-// ================================================================================================================================
-__device__ void audit_tile(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
-{
-    const int n = (int)S.h->n_tile;
-    if (n == 0) return;
-    const int ns = S.h->n_sphere, nb = S.h->n_box, nt = S.h->n_torus, nr = S.h->n_ring;
-    const float W = (float)S.h->canvas_w, H = (float)S.h->canvas_h;
-    for (int it = 0; it < p.iters; it++) {
-        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
-        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
-        float x0 = -8.0f + (W + 8.0f) * R.u01(), y0 = -8.0f + (H + 8.0f) * R.u01();
-        if (R.u01() < 0.7f) { x0 = floorf(x0); y0 = floorf(y0); }                      // pixel-aligned like a real tile, mostly
-        const float fx0 = x0 + 0.5f, fy0 = y0 + 0.5f;
-        const int px = (int)(R.next() & 7ull), py = (int)(R.next() & 7ull);
-        const f3 ro = xyz(S.h->cam_pos), rd = ray_dir(S, fx0 + (float)px, fy0 + (float)py);
-        const bool plain = !(rd.x == 0.0f || rd.y == 0.0f || rd.z == 0.0f);
-        c[0]++; c[20] += !plain;
-        RayBoxCtx bctx;
-        for (int k = 0; k < n; k++) {
-            const bool keep = tile_record_keep(S, k, fx0, fy0, plain);
-            float t = 0.0f;
-            bool hit;
-            int cls;
-            if (k < ns) { cls = 0; hit = intersect_sphere(ro, rd, S.sph_geom()[k], ((S.sph_hollow()[k >> 5] >> (k & 31)) & 1u) != 0, RT_MAXDIST, t); }
-            else if (k < ns + nb) { cls = 1; f3 nor; hit = intersect_box(S.boxes()[k - ns], ro, rd, RT_MAXDIST, t, nor, bctx); }
-            else if (k < ns + nb + nt) { cls = 2; hit = intersect_torus(S.tori()[k - ns - nb], ro, rd, RT_MAXDIST, t); }
-            else if (k < ns + nb + nt + nr) { cls = 3; f2 uv; hit = intersect_ring(S.rings()[k - ns - nb - nt], ro, rd, RT_MAXDIST, t, uv); }
-            else { cls = 4; hit = intersect_sphere(ro, rd, S.lights_point()[k - ns - nb - nt - nr].pos_r2, false, RT_MAXDIST, t); }
-            c[1]++; c[2] += !keep; c[3] += keep && hit;
-            if (!keep && hit) { c[10 + cls]++; record_bad(p, 10 + cls, k, ro, rd, fx0, t, fy0); }
-        }
-    }
-}
-
-// ================================================================================================================================
-// shadow-ray masks (rt_device.h shadow_mask): a wave's hit points as a ball (P, rho) somewhere in or around the scene -- rho from a
-// millimetre to a few units, as the tiles of a frame have them, sometimes huge (a tile that straddles a near object and a far planet) --,
-// one point pt of that ball, one of the scene's lights, the shadow ray exactly as calc_shade builds it (rt.frag:693-703), and for EVERY
-// record the mask of (P, rho) clears the literal intersector on that ray: no hit may be reported (NaN "hits" of the box test included).
-// counters: 0 rays, 1 records judged, 2 bits clear, 3 literal hits among the set bits, 4 rays towards a point light,
-//           10 VIOLATIONS sphere, 11 box, 12 torus, 13 ring
-// ================================================================================================================================
-__device__ f3 crowd_point(Rng& R, f3 c, f3 half);
-__device__ void audit_shadow_mask(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
-{
-    const int n = (int)S.h->n_bsphere, n_lp = S.h->n_light_point, n_ld = S.h->n_light_direct;
-    if (n == 0 || n_lp + n_ld == 0) return;
-    const int ns = S.h->n_sphere, nb = S.h->n_box, nt = S.h->n_torus, nr = S.h->n_ring;
-    for (int it = 0; it < p.iters; it++) {
-        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
-        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
-        // P: on or near a primitive's bound (where hit points are), or anywhere around the scene
-        f3 P;
-        const f4 anchor = S.bspheres()[(int)(R.next() % (unsigned long long)n)];
-        if (R.u01() < 0.7f && isfinite(anchor.w) && anchor.w < 1.0e6f) P = xyz(anchor) + R.unit() * (anchor.w * (R.u01() < 0.7f ? 1.0f : 3.0f * R.u01()));
-        else P = crowd_point(R, mk3(0.0f, 0.0f, 12.0f), mk3(12.0f, 10.0f, 10.0f));
-        const float rho_true = R.u01() < 0.05f ? R.logu(3.0f, 1.0e4f) : R.logu(1.0e-4f, 3.0f);
-        const f3 pt = P + R.unit() * (rho_true * R.u01());
-        const f3 dp0 = pt - P;
-        const float rho = rt_sqrt_approx(dot3_fma(dp0, dp0)) * 1.0001f + 1.0e-6f * (fabsf(pt.x) + fabsf(pt.y) + fabsf(pt.z));   // as calc_shade forms it (>= this lane's own)
-        const float rho_wave = fmaxf(rho, rho_true);       // some other lane of the wave may be farther out
-        const int li = (int)(R.next() % (unsigned long long)(n_lp + n_ld));
-        f3 light_dir, u;
-        float dist, len;
-        if (li < n_lp) {
-            const f3 Lp = xyz(S.lights_point()[li].pos_r2);
-            light_dir = Lp - pt; dist = length3(light_dir); light_dir = normalize3(light_dir);
-            const f3 v = Lp - P;
-            len = rt_sqrt_approx(dot3_fma(v, v));
-            u = v * (1.0f / len);
-            len = len * 1.0001f + rho_wave;
-            c[4]++;
-        } else {
-            light_dir = xyz(S.lights_direct()[li - n_lp].dir_n); dist = RT_MAXDIST;
-            u = light_dir; len = __builtin_huge_valf();
-        }
-        const bool plain = !(light_dir.x == 0.0f || light_dir.y == 0.0f || light_dir.z == 0.0f);
-        c[0]++;
-        RayBoxCtx bctx;
-        for (int k = 0; k < ns + nb + nt + nr; k++) {
-            const bool keep = shadow_record_keep(S, k, P, rho_wave, u, len, plain);
-            float t = 0.0f;
-            bool hit;
-            int cls;
-            if (k < ns) { cls = 0; hit = intersect_sphere(pt, light_dir, S.sph_geom()[k], false, dist, t); }
-            else if (k < ns + nb) { cls = 1; f3 nor; hit = intersect_box(S.boxes()[k - ns], pt, light_dir, dist, t, nor, bctx); }
-            else if (k < ns + nb + nt) { cls = 2; hit = intersect_torus(S.tori()[k - ns - nb], pt, light_dir, dist, t); }
-            else { cls = 3; f2 uv; hit = intersect_ring(S.rings()[k - ns - nb - nt], pt, light_dir, dist, t, uv); }
-            c[1]++; c[2] += !keep; c[3] += keep && hit;
-            if (!keep && hit) { c[10 + cls]++; record_bad(p, 10 + cls, k, pt, light_dir, dist, t, rho_wave); }
-        }
-    }
-}
-
-// ================================================================================================================================
 // candidate tables (ray pencils + slab tables + direction table): rays built like the tracer builds them; for a sample of the primitives
 // whose bit is CLEAR in the ray's mask: a quadric must not be hit by the literal intersector; a torus must stay 5 mm clear of the ray's part
 // up to its limit in exact arithmetic (the premise the torus family audits against the solver).
@@ -821,8 +720,6 @@ __global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
         }
     }
     else if (p.family == F_TORUS_FAR) audit_torus_far(p, S, gid, c);
-    else if (p.family == F_TILE) audit_tile(p, S, gid, c);
-    else if (p.family == F_SHADOW) audit_shadow_mask(p, S, gid, c);
     else audit_tables(p, S, gid, c);
     flush(p, c);
     if (p.family == F_TORUS_MARGIN && worst) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 20), worst);

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BLOCKS = ("scene_buf", "spheres_buf", "planes_buf", "surfaces_buf", "boxes_buf", "toruses_buf", "rings_buf", "lights_point_buf", "lights_direct_buf")
-FAMILIES = {"torus": 0, "torus_margin": 1, "quadric": 2, "ring": 3, "tables": 4, "torus_lead": 5, "torus_far": 6, "tile": 7, "shadow_mask": 8}
+FAMILIES = {"torus": 0, "torus_margin": 1, "quadric": 2, "ring": 3, "tables": 4, "torus_lead": 5, "torus_far": 6}
 N_COUNTERS = 128
 LEAD_BINS = ("<2", "2..4", "4..6", "6..8", "8..10", "10..12", "12..16", "16..24", "24..48", ">=48")      # |o|: origin to torus centre
 NEEDS = {"torus": 4, "torus_margin": 4, "torus_lead": 4, "torus_far": 4, "quadric": 2, "ring": 5}      # index into defines of the count that must be > 0
@@ -45,10 +45,6 @@ LABELS = {
                        (10, "VIOLATIONS a root below the ray's limit is reported")] +
                       [(20 + b, f"rays from {n} units out") for b, n in enumerate(("< 120", "120..150", "150..200", "200..400", "400..1000", ">= 1000"))] +
                       [(30 + b, f"hits reported from {n} units out") for b, n in enumerate(("< 120", "120..150", "150..200", "200..400", "400..1000", ">= 1000"))]),
-    "tile": {0: "camera rays (one pixel of a random 8 x 8 tile each)", 1: "records judged", 2: "bits the tile's mask clears", 3: "literal hits among the set bits", 20: "rays with an exact zero direction component",
-             10: "VIOLATIONS sphere: bit clear, the literal test hits", 11: "VIOLATIONS box", 12: "VIOLATIONS torus", 13: "VIOLATIONS ring", 14: "VIOLATIONS light sphere"},
-    "shadow_mask": {0: "shadow rays (one hit point of a ball (P, rho) each, towards one of the scene's lights)", 1: "records judged", 2: "bits the ball's mask clears", 3: "literal hits among the set bits", 4: "rays towards a point light",
-                    10: "VIOLATIONS sphere: bit clear, the literal test hits", 11: "VIOLATIONS box", 12: "VIOLATIONS torus", 13: "VIOLATIONS ring"},
     "quadric": {0: "rays", 1: "culled by surface_cull", 2: "culled by the group test", 3: "literal hits", 4: "literal hits on the degenerate branch", 5: "left early by the product intersector (no real root)", 6: "culled by the clip-box test behind surface_cull",
                 10: "VIOLATIONS surface_cull", 11: "VIOLATIONS group test", 12: "VIOLATIONS product intersector != literal rt.frag:513-572", 13: "VIOLATIONS clip-box test"},
     "ring": {0: "rays", 1: "culled", 2: "literal hits", 10: "VIOLATIONS"},
@@ -126,7 +122,7 @@ def run(lib, sc, family, rays, seed, counters, bad_rows, max_bad=16):
 def run_family(lib, scs, fam, want, seed0=1000):
     """`want` rays of family `fam`, split evenly over the scenes of `scs` (name, scene) that have primitives of that family. Returns the
     report entry; violation rows carry the scene's name in front (a recorded ray can be replayed: tests/golden/torus_far_rays.json)."""
-    use = [(n, s) for n, s in scs if (fam == "tables" and (s.defines[2] >= 16 or s.defines[4] >= 16)) or (fam in ("tile", "shadow_mask")) or (fam not in ("tables", "tile", "shadow_mask") and s.defines[NEEDS[fam]] > 0)]
+    use = [(n, s) for n, s in scs if (fam == "tables" and (s.defines[2] >= 16 or s.defines[4] >= 16)) or (fam != "tables" and s.defines[NEEDS[fam]] > 0)]
     counters = (ctypes.c_uint64 * N_COUNTERS)()
     bad_rows, t0, gpu_s = [], time.time(), 0.0
     per = max(1, int(want / max(1, len(use))))
