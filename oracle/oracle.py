@@ -163,7 +163,7 @@ class OracleScene:
     def drop_mips():
         lib().orc_kat_drop_mips()
 
-    def primary_hits(self, threads: int = 0, torus_t=None):
+    def primary_hits(self, threads: int = 0, torus_t=None, y0: int = 0, y1: int | None = None):
         """Diagnostic (orc_set_primary_buffers): -> (frame, hits) where hits[y, x] = (t, type, num, 0) of the pixel's FIRST calcInter
         (type = num = -1 on a miss). torus_t: optional (H, W) float32 -- where the camera ray hits a torus and the entry is > 0, that
         distance replaces the solver's own root (the reference's root substituted)."""
@@ -174,16 +174,17 @@ class OracleScene:
         assert tin is None or tin.shape == (self.height, self.width)
         l.orc_set_primary_buffers(hits.ctypes.data, None if tin is None else tin.ctypes.data)
         try:
-            frame, _ = self.render(threads=threads)
+            frame, _ = self.render(y0, y1, threads=threads)     # (a row range renders those rows only; the buffers stay whole-frame)
         finally:
             l.orc_set_primary_buffers(None, None)
         return frame, hits
 
-    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0, jitter=(0.0, 0.0), tags=None, lod_force: float = -1.0):
+    def render(self, y0: int = 0, y1: int | None = None, threads: int = 0, jitter=(0.0, 0.0), tags=None, lod_force: float = -1.0, lod_force_site=None):
         """Returns (float32 array (rows, W, 4), counters dict). Row 0 = bottom (gl_FragCoord).
         jitter: diagnostic displacement of every primary ray (orc_set_ray_jitter), in units of the un-normalised view vector.
         tags: optional (rows, W) uint32 array that receives the per-pixel ORC_TAG_* event bits (TAG_* below).
-        lod_force: diagnostic, >= 0: every mip-mapped fetch is sampled at this level of detail (orc_set_lod_force)."""
+        lod_force: diagnostic, >= 0: every mip-mapped fetch is sampled at this level of detail (orc_set_lod_force).
+        lod_force_site: diagnostic, up to two (sampler uniform, site 0 = hit / 1 = shadow, level): the fetches of those sites at levels of their own."""
         y1 = self.height if y1 is None else y1
         out = np.empty((y1 - y0, self.width, 4), dtype=np.float32)
         cnt = Counters()
@@ -193,6 +194,9 @@ class OracleScene:
         l.orc_set_ray_jitter(float(jitter[0]), float(jitter[1]))
         l.orc_set_lod_force.argtypes = [ctypes.c_float]
         l.orc_set_lod_force(float(lod_force))
+        l.orc_set_lod_force_site.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        for idx, f in enumerate(lod_force_site or ()):
+            l.orc_set_lod_force_site(idx, TEX_SLOTS.index(f[0]), int(f[1]), float(f[2]))
         if tags is not None:
             assert tags.shape == (y1 - y0, self.width) and tags.dtype == np.uint32 and tags.flags.c_contiguous
             l.orc_set_tag_buffer(tags.ctypes.data)
@@ -201,6 +205,8 @@ class OracleScene:
         finally:
             l.orc_set_ray_jitter(0.0, 0.0)
             l.orc_set_lod_force(-1.0)
+            l.orc_set_lod_force_site(0, -1, -1, -1.0)
+            l.orc_set_lod_force_site(1, -1, -1, -1.0)
             l.orc_set_tag_buffer(None)
         if rc != 0:
             raise RuntimeError("orc_render failed")

@@ -251,6 +251,12 @@ void orc_set_lod_bias(float b) { g_lod_bias = b; }
  * (tests/reference_classify.py: the `divergent` and `quad_neighbour` classes demand the reference's pixel inside that bracket). */
 static float g_lod_force = -1.0f;
 void orc_set_lod_force(float level) { g_lod_force = level; }
+/* diagnostic: the fetches of ONE site -- sampler slot `slot` at site `site` (SITE_HIT 0 / SITE_SHADOW 1) -- at a level of their own, whatever
+ * orc_set_lod_force says for the rest; level < 0: off; two such overrides (idx 0, 1). tests/reference_classify.py brackets pixels whose PATH depends on one fetch's value
+ * (the ring's alpha decides the pass-through, rt.frag:884) with the levels of that fetch and of all others chosen independently. */
+static int g_lod_force2_slot[2] = {-1, -1}, g_lod_force2_site[2] = {-1, -1};
+static float g_lod_force2_level[2] = {-1.0f, -1.0f};
+void orc_set_lod_force_site(int idx, int slot, int site, float level) { if (idx >= 0 && idx < 2) { g_lod_force2_slot[idx] = slot; g_lod_force2_site[idx] = site; g_lod_force2_level[idx] = level; } }
 static int g_nan_minmax = 0;
 void orc_set_nan_minmax(int mode) { g_nan_minmax = mode; }
 static inline float gl_min(float a, float b) { return g_nan_minmax ? (a < b ? a : b) : (b < a ? b : a); }
@@ -630,6 +636,8 @@ static void quad_resolve(quad_t* q, const orc_frame* fr)
         }
         if (g_lod_bias != 0.0f) lambda += g_lod_bias;   /* diagnostic, see orc_set_lod_bias */
         if (g_lod_force >= 0.0f) lambda = g_lod_force;  /* diagnostic, see orc_set_lod_force */
+        for (int f = 0; f < 2; f++)
+            if (g_lod_force2_level[f] >= 0.0f && key.slot == g_lod_force2_slot[f] && key.site == g_lod_force2_site[f]) lambda = g_lod_force2_level[f];
         res[k] = sample2d_lod(t, q->lane[k].uv, lambda);
     }
     for (int k = 0; k < 4; k++)

@@ -44,41 +44,54 @@ def _to_u8(img: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8))
 
 
-def planet(seed: int, w: int, h: int, tint=(1.0, 0.85, 0.7)) -> np.ndarray:
-    """RGB8 equirect 'gas giant': latitude bands + three octaves of smooth noise + fine grain."""
+def planet(seed: int, w: int, h: int, tint=(1.0, 0.85, 0.7), smooth: bool = False) -> np.ndarray:
+    """RGB8 equirect 'gas giant': latitude bands + three octaves of smooth noise + fine grain. smooth: band-limited -- no per-texel grain,
+    no finest octave, gentler bands (a texel differs from its neighbours by a fraction of a grey level, so that a sample barely depends on
+    WHICH mip level an implementation picks: the fixtures that hold the oracle to the reference at 5e-3, tests/reference_frames.py)."""
     rng = np.random.default_rng(seed)
     lat = np.linspace(0, np.pi, h, dtype=np.float32)[:, None]
-    bands = 0.5 + 0.25 * np.sin(lat * 14.0) + 0.1 * np.sin(lat * 37.0 + 1.3)
-    n = 0.5 * _upsampled_noise(rng, h, w, max(1, h // 8)) + 0.3 * _upsampled_noise(rng, h, w, max(1, h // 32)) \
-        + 0.2 * _upsampled_noise(rng, h, w, max(1, h // 128))
-    grain = rng.random((h, w), dtype=np.float32) * 0.06 - 0.03
+    bands = 0.5 + 0.25 * np.sin(lat * (5.0 if smooth else 14.0)) + (0.0 if smooth else 0.1 * np.sin(lat * 37.0 + 1.3))
+    n = 0.5 * _upsampled_noise(rng, h, w, max(1, h // 8)) + 0.3 * _upsampled_noise(rng, h, w, max(1, h // (12 if smooth else 32))) \
+        + (0.0 if smooth else 0.2 * _upsampled_noise(rng, h, w, max(1, h // 128)))
+    grain = np.float32(0.0) if smooth else rng.random((h, w), dtype=np.float32) * 0.06 - 0.03
     base = np.clip(0.65 * bands + 0.45 * (n - 0.5) + grain, 0, 1)
     img = np.stack([base * tint[0], base * tint[1], np.clip(base * tint[2] + 0.1 * (n - 0.5), 0, 1)], axis=-1)
     return _to_u8(img)
 
 
-def ring(seed: int, w: int, h: int) -> np.ndarray:
-    """RGBA8 ring strip: radial (u) bands; alpha has fully transparent gaps and fully opaque bands."""
+def ring(seed: int, w: int, h: int, smooth: bool = False) -> np.ndarray:
+    """RGBA8 ring strip: radial (u) bands; alpha has fully transparent gaps and fully opaque bands. smooth: band-limited (24 / 60 knots
+    instead of 48 / 700, ramps into the gap and the opaque band instead of steps, no per-texel noise)."""
     rng = np.random.default_rng(seed)
     u = np.linspace(0, 1, w, dtype=np.float32)
-    coarse = np.interp(u, np.linspace(0, 1, 48), rng.random(48)).astype(np.float32)
-    fine = np.interp(u, np.linspace(0, 1, 700), rng.random(700)).astype(np.float32)
+    coarse = np.interp(u, np.linspace(0, 1, 24 if smooth else 48), rng.random(24 if smooth else 48)).astype(np.float32)
+    fine = np.interp(u, np.linspace(0, 1, 60 if smooth else 700), rng.random(60 if smooth else 700)).astype(np.float32)
     dens = np.clip(1.6 * coarse + 0.5 * fine - 0.6, 0, 1)
-    dens[(u > 0.58) & (u < 0.64)] = 0.0  # a "Cassini division": exact alpha 0
-    dens[(u > 0.2) & (u < 0.3)] = 1.0    # an opaque band: exact alpha 255
+    if smooth:
+        dens = dens * np.clip(np.abs(u - 0.61) / 0.06 - 0.5, 0, 1)                      # the gap: alpha 0 in its middle, ramps at its edges
+        dens = np.maximum(dens, np.clip(1.5 - np.abs(u - 0.25) / 0.05, 0, 1))           # the opaque band likewise
+    else:
+        dens[(u > 0.58) & (u < 0.64)] = 0.0  # a "Cassini division": exact alpha 0
+        dens[(u > 0.2) & (u < 0.3)] = 1.0    # an opaque band: exact alpha 255
     rgb = np.stack([0.85 * (0.6 + 0.4 * fine), 0.78 * (0.6 + 0.4 * fine), 0.62 * (0.6 + 0.4 * coarse)], axis=-1)
     img = np.concatenate([rgb, dens[:, None]], axis=-1)[None, :, :].repeat(h, axis=0)
-    img = img + (rng.random((h, w, 1), dtype=np.float32) * 0.02 - 0.01) * (img > 0) * (img < 1)
+    if not smooth:
+        img = img + (rng.random((h, w, 1), dtype=np.float32) * 0.02 - 0.01) * (img > 0) * (img < 1)
     return _to_u8(img)
 
 
-def crate(seed: int, w: int, h: int) -> np.ndarray:
-    """RGBA8 'container': planks with dark seams and a frame, alpha 255."""
+def crate(seed: int, w: int, h: int, smooth: bool = False) -> np.ndarray:
+    """RGBA8 'container': planks with dark seams and a frame, alpha 255. smooth: the planks and the frame as sine ramps instead of steps,
+    no one-texel seams."""
     rng = np.random.default_rng(seed)
     y, x = np.mgrid[0:h, 0:w].astype(np.float32)
     plank = ((x / max(1, w // 8)).astype(np.int32) % 2).astype(np.float32)
     seam = (np.minimum(x % max(1, w // 8), max(1, w // 8) - (x % max(1, w // 8))) < max(1, w // 128)).astype(np.float32)
     frame = ((x < w // 16) | (x >= w - w // 16) | (y < h // 16) | (y >= h - h // 16)).astype(np.float32)
+    if smooth:
+        plank = 0.5 + 0.5 * np.sin(x * (np.pi / max(1, w // 8)))
+        seam = np.zeros_like(x)
+        frame = np.clip(1.0 - np.minimum(np.minimum(x, w - 1 - x), np.minimum(y, h - 1 - y)) / max(1.0, w / 8.0), 0, 1)
     wood = 0.55 + 0.1 * plank + 0.15 * (_upsampled_noise(rng, h, w, max(1, h // 64)) - 0.5) + 0.06 * np.sin(y * 0.4)
     wood = wood * (1 - 0.6 * seam) * (1 - 0.35 * frame)
     img = np.stack([wood, wood * 0.72, wood * 0.45, np.ones_like(wood)], axis=-1)
@@ -97,19 +110,20 @@ def nebula_face(seed: int, n: int) -> np.ndarray:
     return _to_u8(img)
 
 
-def default_texture_set(scale: int = 1, seed: int = 2024) -> dict:
-    """Returns {'textures': [(uniform, unit, array HxWxC uint8)], 'cubemap': [6 arrays NxNx3 uint8]}."""
+def default_texture_set(scale: int = 1, seed: int = 2024, smooth: bool = False) -> dict:
+    """Returns {'textures': [(uniform, unit, array HxWxC uint8)], 'cubemap': [6 arrays NxNx3 uint8]}. smooth: the band-limited variants of
+    the planets, the ring and the crate (see planet)."""
     s = max(1, int(scale))
     out = []
     for i, (_name, uniform, unit, w, h, c) in enumerate(REFERENCE_TEXTURES):
         w, h = max(4, w // s), max(4, h // s)
         if uniform == "texture_ring":
-            img = ring(seed + i, w, h)
+            img = ring(seed + i, w, h, smooth)
         elif uniform == "texture_box":
-            img = crate(seed + i, w, h)
+            img = crate(seed + i, w, h, smooth)
         else:
             tint = ((1.0, 0.85, 0.7), (0.95, 0.9, 0.65), (1.0, 0.55, 0.4))[i]
-            img = planet(seed + i, w, h, tint)
+            img = planet(seed + i, w, h, tint, smooth)
         assert img.shape == (h, w, c) and img.dtype == np.uint8
         out.append((uniform, unit, img))
     n = max(4, CUBEMAP_FACE // s)

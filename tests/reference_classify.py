@@ -31,6 +31,14 @@ result to the implementation; a pixel claimed by none fails the test.
             the committed fixtures needs this class (it exists for tools/fuzz_reference.py's degenerate scenes).
  quad_neighbour  A mip-mapped fetch whose 2x2 quad holds an unstable or divergent pixel: its derivatives difference that pixel's uv.
             BOUNDED like `divergent`: inside the forced-level envelope.
+ divergent_alpha (round 5) A divergent / quad-neighbour pixel OUTSIDE that envelope whose path went through an alpha-textured ring
+            (rt.frag:884: `alpha < 1` passes the ray through and weights what follows by 1 - alpha): the sampled alpha steers the PATH, so
+            the level llvmpipe took for that ONE fetch and the levels of all other fetches enter the colour independently, and renders that
+            force every fetch to the same level do not bracket it. BOUNDED: inside the envelope of the oracle's renders with the ring's
+            hit-site fetch forced to level i, its shadow-site fetches (inShadow adds the ring's alpha, rt.frag:647) to level k and every other fetch
+            to level j, for all triples (i, k, j) (orc_set_lod_force_site; only the quad
+            rows of the pixels in question are rendered), widened by LOD_PAD. This is the class of round 4's one LEFTOVER pixel per
+            full-size fixture.
  approx_math (last) A stable pixel within APPROX_TOL = 5e-4: llvmpipe's pow / exp / log2 are polynomial approximations (measured: pow 1e-5
             relative at small exponents; a specular pow(x, 200) amplifies that 200-fold). Counted and bounded.
  unstable_between (last resort, counted) unstable, inside the envelope of the 41 renders, but not within NEAR_TOL of any: <= 8 pixels per frame.
@@ -126,6 +134,34 @@ def _build_probe(ref, texture_lod, gl_mips, threads):
         _PROBES[key] = (base, tags, unstable, ref["frame"], lo, hi, nan_seen, lod_lo, lod_hi)     # (the frame is kept so that its id stays unique)
 
 
+def _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img):
+    """For the pixels of `cand`: are the reference's and the candidate's values inside the envelope of the oracle's renders with the ring's
+    hit-site fetch at level i, its shadow-site fetches at level k and every other mip-mapped fetch at level j, over all (i, k, j)? Renders only the quad rows involved."""
+    w, h = ref["width"], ref["height"]
+    top = max(int(np.ceil(np.log2(max(im.shape[0], im.shape[1])))) for _u, _n, im in ref["textures"])
+    oracle.OracleScene.drop_mips()
+    O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod)
+    if gl_mips:
+        for uniform, levels in ref["gl_mips"].items():
+            O.set_mip_levels(uniform, levels)
+    ok = np.zeros((h, w), bool)
+    try:
+        for y0 in sorted({int(y) & ~1 for y in np.argwhere(cand)[:, 0]}):
+            y1 = min(y0 + 2, h)
+            lo = np.full((y1 - y0, w, 3), np.inf); hi = np.full((y1 - y0, w, 3), -np.inf)
+            for i in range(top + 1):
+                for k in range(top + 1):
+                    for j in range(top + 1):
+                        v = O.render(y0, y1, threads=threads, lod_force=float(j), lod_force_site=(("texture_ring", 0, float(i)), ("texture_ring", 1, float(k))))[0][..., :3].astype(np.float64)
+                        lo, hi = np.fmin(lo, v), np.fmax(hi, v)
+            r = ref["frame"][y0:y1, :, :3].astype(np.float64); c = img[y0:y1, :, :3].astype(np.float64)
+            ok[y0:y1] = ((r >= lo - LOD_PAD) & (r <= hi + LOD_PAD)).all(-1) & ((c >= lo - LOD_PAD) & (c <= hi + LOD_PAD)).all(-1)
+    finally:
+        if gl_mips:
+            oracle.OracleScene.drop_mips()
+    return ok
+
+
 def classify(ref: dict, candidate: np.ndarray | None = None, texture_lod: int = 1, tex_tol: float = 0.0, threads: int = 8, gl_mips: bool = False,
              tex_level_envelope: bool = False) -> dict:
     """ref: tests/reference_frames.load(name). candidate: the frame under test (default: the oracle's own render).
@@ -180,6 +216,13 @@ def classify(ref: dict, candidate: np.ndarray | None = None, texture_lod: int = 
     q = flagged[:hq, :wq].reshape(hq // 2, 2, wq // 2, 2).any(axis=(1, 3))
     quad_any[:hq, :wq] = np.repeat(np.repeat(q, 2, axis=0), 2, axis=1)
     claim("quad_neighbour", ((tags & oracle.TAG_TEXTURE) != 0) & quad_any & lod_ok)
+    # divergent_alpha: what the two classes above could not bracket, against the envelope over independent levels for the ring's alpha fetch
+    # and for everything else -- rendered on demand, only the quad rows that hold such a pixel
+    cand = left & ((tags & oracle.TAG_TEXTURE) != 0) & (((tags & oracle.TAG_QUAD_DIVERGENT) != 0) | quad_any)
+    out["divergent_alpha"] = 0
+    if cand.any() and lod_lo is not None and any(u == "texture_ring" for u, _n, _i in ref["textures"]):
+        pair_ok = _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img)
+        claim("divergent_alpha", cand & pair_ok)
     claim("texture", ((tags & oracle.TAG_TEXTURE) != 0) & (d <= tex_tol))
     if tex_level_envelope and lod_lo is not None:
         # texture_level: a mip-mapped fetch whose value differs by more than tex_tol although every quad neighbour was present: the two

@@ -58,6 +58,10 @@ CASES = {
     # depth 1, at half the configuration's 640 x 480; with the textures off and as the reference runs it
     "config0_untextured": (lambda: _strip_textures(scenes.build_scene("default", 320, 240, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0)), False, (0.004, 0.0006)),
     "config0": (lambda: scenes.build_scene("default", 320, 240, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0), True, (0.10, 0.012)),
+    # ---- round 5: the two textured plain runs again with BAND-LIMITED textures (textures.default_texture_set(smooth=True): no per-texel grain,
+    # no steps): which mip level an implementation takes then hardly matters, and the `texture` class is held at 5e-3 instead of 0.1
+    "default_smooth": (lambda: scenes.build_scene("default", W, H, 4), True, (0.10, 0.004)),
+    "config0_smooth": (lambda: scenes.build_scene("default", 320, 240, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0), True, (0.10, 0.004)),
     # the reference's own default run (main.cpp:7-8: 1280 x 720; SceneManager.cpp:233: reflect_depth 5; main.cpp:197-246: animated) at a
     # quarter of its size, two animation times
     "app_default_t3": (lambda: _strip_textures(scenes.build_scene("default", 320, 180, 5, time=3.0, delta=0.016)), False, (0.004, 0.0006)),
@@ -82,7 +86,7 @@ def _fuzz(seed):
 
 for _s in FUZZ_SEEDS:
     CASES[f"fuzz_{_s}"] = ((lambda s=_s: _fuzz(s)), False, (0.02, 0.004))
-SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180),
+SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "config0_smooth": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180),
          "config0_full": (640, 480), "app_default_full": (1280, 720)}
 SIZES.update({f"fuzz_{_s}": FUZZ_SIZE for _s in FUZZ_SEEDS})
 
@@ -102,6 +106,7 @@ SAME_MIPS = ("default_same_mips", 0.025, 0.008)   # name, max fraction > 1e-4, >
 #   <case>_level0    : GL was given level 0 only (GL_TEXTURE_MAX_LEVEL = 0) -> compared with the oracle at texture_lod = 0
 TEXTURED = ("default", "trap_degenerate_rings")     # pinned three ways (variants below)
 TEXTURED_PLAIN_ONLY = ("config0",)                  # textured, plain run only (with llvmpipe's generated mip levels stored)
+SMOOTH = ("default_smooth", "config0_smooth")       # textured with the band-limited set, plain run only, llvmpipe's mip levels stored
 FULL_SIZE = ("config0_full", "app_default_full")    # textured, plain run only, at the configuration's own size: the pixel-by-pixel accounting of
                                                     # these runs on the GPU box (GPU_PLAN; its host has the cores for the oracle's probes), the
                                                     # CPU suite holds the oracle to their limits only
@@ -110,8 +115,9 @@ PRIMARY_HITS = ("torus", "default_untextured")
 VARIANTS = {f"{c}_{v}": (c, v) for c in TEXTURED for v in ("same_mips", "level0")}
 
 
-def texture_set():
-    return textures.default_texture_set(scale=TEX_SCALE)
+def texture_set(name: str = ""):
+    """The texture set of a case: the band-limited one for the *_smooth cases."""
+    return textures.default_texture_set(scale=TEX_SCALE, smooth=name.endswith("_smooth"))
 
 
 def input_digest(sc, ts) -> str:
@@ -143,7 +149,7 @@ def load(name):
     defines = tuple(int(v) for v in d[:9]) + tuple(float(np.float32(v)) for v in d[9:15])
     blocks = {n: z["block_" + n].tobytes() if ("block_" + n) in z.files else b"" for n in BLOCK_NAMES}
     sc = SceneBlocks(defines=defines, blocks=blocks)
-    ts = texture_set()
+    ts = texture_set(name)
     if input_digest(sc, ts) != str(z["digest"]):
         raise RuntimeError(f"inputs of reference frame '{name}' no longer reproduce (textures.py changed?)")
     # llvmpipe's own mip levels (plain textured runs only), stored as differences from the oracle's integer-mean levels

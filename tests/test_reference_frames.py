@@ -31,15 +31,17 @@ TEXTURED_PLAN = ([(c + "_level0", 0, 0.01, False, False) for c in rf.TEXTURED] +
 PLAN_IDS = [p[0] + ("_gl_mips" if p[3] else "") + ("_product_rule" if p[4] else "") for p in TEXTURED_PLAN]
 
 
-# The two full-size fixtures (round 4: 307 200 and 921 600 pixels against 36 864 ... 76 800 of the others) each leave ONE pixel that no class
-# claims and, in the 1280 x 720 frame, one pixel of the box_nan class -- named here, not waved through:
-#   config0_full      (281, 151): 0.12 off, a mip-mapped ring fetch in a divergent quad (tags TEXTURE | QUAD_DIVERGENT) whose reference value lies
-#                     outside the envelope of the oracle's forced-level renders: the sampled alpha decides the `alpha < 1` pass-through
-#                     (rt.frag:884), so the pixel's PATH depends on the level llvmpipe took for that one fetch, and the forced-level renders
-#                     force every fetch of the pixel to the same level;
-#   app_default_full  (144, 382): 0.011 off, a torus pixel (TORUS_TOL is 5e-3: the root's 1e-3 reaches the colour through a mirror bounce);
-#                     one pixel where a ray runs parallel to a face of the glass box (0 * inf in intersectBox, trap T5: min / max of a NaN).
-LEFTOVER = {"config0_full": dict(unexplained=1, box_nan=0), "app_default_full": dict(unexplained=1, box_nan=1)}
+# The two full-size fixtures (round 4: 307 200 and 921 600 pixels against 36 864 ... 76 800 of the others) each left ONE pixel that no class
+# claimed and, in the 1280 x 720 frame, one pixel of the box_nan class. Round 5:
+#   config0_full      (281, 151), 0.12 off: a mip-mapped ring fetch in a divergent quad whose sampled alpha decides the `alpha < 1` pass-through
+#                     (rt.frag:884), so the pixel's PATH depends on the level llvmpipe took for that one fetch. Claimed now by the class
+#                     divergent_alpha (tests/reference_classify.py: levels of the ring's hit-site fetch, of its shadow-site fetches and of
+#                     everything else forced independently) -- nothing is left over in this frame;
+#   app_default_full  (144, 382), 0.011 off, a torus pixel (TORUS_TOL is 5e-3): the accepted root's 1e-3 reaches the colour through a mirror
+#                     bounce. Kept as the one named exception, with its mechanism TESTED: test_the_leftover_torus_pixel_is_the_solvers_tolerance
+#                     moves the camera ray's root by the solver's own tolerance and the reference's colour lies between the oracle's answers;
+#                     and one pixel where a ray runs parallel to a face of the glass box (0 * inf in intersectBox, trap T5: min / max of a NaN).
+LEFTOVER = {"app_default_full": dict(unexplained=1, box_nan=1)}
 
 
 def _accept(name, r, textured):
@@ -75,6 +77,26 @@ def test_oracle_matches_reference_shader_textured(built, name, lod, tex_tol, gl_
     if name.endswith("_same_mips"):    # same texels + llvmpipe's LOD formula: well under the plain run
         plain = rc._diff(oracle.OracleScene(*_scene_args(rf.load(name[:-10])), texture_lod=1).render(threads=8)[0], rf.load(name[:-10])["frame"])
         assert r["over"] < 0.8 * int((plain > rc.TOL).sum()), (name, r)
+
+
+# Round 5: the two textured plain runs again with BAND-LIMITED textures (no per-texel grain, no steps:
+# textures.default_texture_set(smooth=True)). Which mip level an implementation takes then hardly matters, so the `texture` class is held
+# at 5e-3 -- twenty times tighter than the grainy fixtures' 0.1, which was mostly the textures' own 0.03 of per-texel noise seen through a
+# different level. (plan: fixture, oracle LOD mode, llvmpipe's own mip levels read back?)
+SMOOTH_TEX_TOL = 5e-3
+SMOOTH_PLAN = [(n, 2, True) for n in rf.SMOOTH]      # (the product's own rule against these runs: GPU_PLAN below, on the HIP kernel's frame)
+
+
+@pytest.mark.parametrize("name,lod,gl_mips", SMOOTH_PLAN, ids=[p[0] + ("_gl_mips" if p[2] else "_product_rule") for p in SMOOTH_PLAN])
+def test_oracle_matches_reference_shader_with_band_limited_textures(built, name, lod, gl_mips):
+    r = _accept(name, rc.classify(rf.load(name), texture_lod=lod, tex_tol=SMOOTH_TEX_TOL, gl_mips=gl_mips, tex_level_envelope=True), True)
+    assert r["texture"] > 100, (name, r)                       # (there are mip-mapped pixels to judge)
+    if gl_mips:     # llvmpipe's texels and llvmpipe's level formula: all but a handful of the mip-mapped pixels within 5e-3 (measured: 122 of 122
+                    # and 561 of 568; the rest up to 1e-2 -- seen through the glass sphere -- and one pixel on a planet's u = 0 / 1 seam)
+        assert r["texture_level"] <= 8, (name, r)
+    else:           # the product's own rule (integer-mean mips, exact log2) against the plain run: a few more choose another level
+        assert r["texture_level"] <= 0.001 * r["pixels"], (name, r)
+    assert r["divergent_alpha"] <= 8, (name, r)                # the ring-alpha class stays a handful of pixels
 
 
 def _scene_args(ref):
@@ -182,6 +204,33 @@ def test_accepted_torus_roots_equal_the_reference_shaders(built):
             assert (before > 1e-4).sum() > 20       # (there WAS something to explain)
 
 
+def test_the_leftover_torus_pixel_is_the_solvers_tolerance(built):
+    """app_default_full (144, 382) is 0.011 from the reference, above the torus class' 5e-3, and no other class claims it (LEFTOVER). Its camera
+    ray hits the torus, whose mirror term (reflect 0.2) carries a steep gradient there. Durand-Kerner stops when the roots move by less than
+    1e-3 (rt.frag:475-481), so the accepted root is good to about that: with the oracle's own root displaced by -2e-3 ... +2e-3 (substituted
+    through orc_set_primary_buffers, the mechanism of test_accepted_torus_roots_equal_the_reference_shaders) the pixel's colour sweeps a range
+    that holds the reference's value -- i.e. the difference is the solver's tolerance and nothing else."""
+    ref = rf.load("app_default_full")
+    x, y = 144, 382
+    O = oracle.OracleScene(*_scene_args(ref), texture_lod=1)
+    y0 = y & ~1
+    frame, hits = O.primary_hits(threads=2, y0=y0, y1=y0 + 2)
+    t0, ty = float(hits[y, x, 0]), int(hits[y, x, 1])
+    assert ty == 4, "the camera ray of the leftover pixel hits the torus"
+    base = frame[y - y0, x, :3].astype(np.float64)
+    want = ref["frame"][y, x].astype(np.float64)
+    assert 5e-3 < np.abs(base - want).max() < 2e-2
+    lo, hi = base.copy(), base.copy()
+    for dt in (-2e-3, -1e-3, -5e-4, 5e-4, 1e-3, 2e-3):
+        sub = np.zeros((ref["height"], ref["width"]), np.float32)
+        sub[y, x] = np.float32(t0 + dt)
+        f, _ = O.primary_hits(threads=2, torus_t=sub, y0=y0, y1=y0 + 2)
+        v = f[y - y0, x, :3].astype(np.float64)
+        lo, hi = np.minimum(lo, v), np.maximum(hi, v)
+    assert ((want >= lo - 1e-4) & (want <= hi + 1e-4)).all(), (lo, hi, want)
+    assert (hi - lo).max() > 5e-3          # the pixel really is that sensitive to the root
+
+
 @pytest.mark.parametrize("name", rf.FULL_SIZE)
 def test_oracle_is_within_the_limits_of_the_full_size_reference_frames(built, name):
     """The two configurations the reference is run at, at their own size and as it runs them (640 x 480 depth 1; 1280 x 720 depth 5 at t = 3;
@@ -217,7 +266,8 @@ def test_reference_run_is_reproducible(built):
 # the kernel has one texture rule (the product's: lod 1) and its level-0 mode: the level-0 fixtures at 0.01, the *_same_mips fixtures (GL had
 # the very mip texels the kernel builds; only the level formula differs) and the plain runs at 0.1 or a sample of another level
 GPU_PLAN = ([(n, 1, 0.0, False) for n in UNTEXTURED] + [(c + "_level0", 0, 0.01, False) for c in rf.TEXTURED]
-            + [(c + "_same_mips", 1, 0.1, True) for c in rf.TEXTURED] + [(c, 1, 0.1, True) for c in rf.TEXTURED + rf.TEXTURED_PLAIN_ONLY + rf.FULL_SIZE])
+            + [(c + "_same_mips", 1, 0.1, True) for c in rf.TEXTURED] + [(c, 1, 0.1, True) for c in rf.TEXTURED + rf.TEXTURED_PLAIN_ONLY + rf.FULL_SIZE]
+            + [(c, 1, SMOOTH_TEX_TOL, True) for c in rf.SMOOTH])
 
 
 @pytest.mark.gpu

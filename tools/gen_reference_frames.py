@@ -25,7 +25,6 @@ def main():
     if not ref_gl.available():
         sys.exit("needs /root/reference and Mesa's swrast_dri.so (build container only)")
     print("GL:", ref_gl.renderer())
-    ts = rf.texture_set()
     only = sys.argv[1:]
     cases = dict(rf.CASES)
     for vname, (case, _variant) in rf.VARIANTS.items():
@@ -34,6 +33,7 @@ def main():
         if only and name not in only:
             continue
         sc = build()
+        ts = rf.texture_set(name)
         same_mips = name.endswith("_same_mips")
         level0 = name.endswith("_level0")
         W, H = rf.size(name)
