@@ -86,10 +86,13 @@ namespace {
 
 constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels = one 1 KiB row segment per load
 #ifndef SMAA_ABL
-#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = no strip-border loads, 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
+#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = (round 4's strip-border loads; gone), 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
 #endif
 #ifndef SMAA_EARLY_ATOMIC
 #define SMAA_EARLY_ATOMIC 1   /* the append's atomic is issued before the plane and texel stores (round 4: traced ULTRA edges 25.2 -> 23.9 us, other presets +-0) */
+#endif
+#ifndef SMAA_ROW_DIST
+#define SMAA_ROW_DIST 1       /* a row is requested this many iterations of the strip walk before the one that needs it */
 #endif
 #ifndef SMAA_XCD_BANDS
 #define SMAA_XCD_BANDS 1
@@ -117,7 +120,11 @@ struct Row4 { float l[4]; };   // lumas of one lane's four pixels in one row
 // needs come from the adjacent lanes by cross-lane moves, the strip's outermost columns by two extra loads. Every row is copied to the
 // screen as it passes. Edge bits are kept in two registers per lane for the whole strip; at the end the wave reserves its list slots with
 // ONE atomic (none at all for the strips without an edge -- most of a frame), ranks its pixels with a scan of the lanes' counts and writes list + edge texels.
-template <int STRIP_H>
+// VEC (frame widths that are multiples of four, chosen by smaa_launch): a lane's four pixels are ONE 16-byte load and one 16-byte store, and a
+// lane is either wholly inside the frame or wholly outside. The two forms are separate instantiations on purpose: as two branches of one
+// kernel the compiler merged their tails into four 4-byte loads per lane and row for BOTH (round 5: the ISA of round 4's kernel held no
+// 16-byte load at all -- four times the cache look-ups per row).
+template <int STRIP_H, bool VEC>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffers b, float threshold, unsigned cur)
 {
     static_assert(STRIP_H * 4 * 2 <= 128, "edge bits of a strip live in two 64-bit registers per lane");
@@ -158,27 +165,44 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     const bool no_strip = x0 >= w;
 #endif
     const int px = x0 + lane * 4;
-    const bool vec_ok = ((w & 3) == 0) && (px + 3 < w);
-    // what the RG8 edge texture still holds for this lane's pixels: the previous resolve's row plane (requested first, needed last)
+    const bool vec_ok = VEC && px < w;                                         // (w % 4 == 0: px < w <=> px + 3 < w)
+    const int pxl = VEC ? (px < w ? px : w - 4) : px;                          // lanes right of the frame load its last four pixels and keep nothing
+    // what the RG8 edge texture still holds for this lane's pixels: the previous resolve's row plane (requested first, needed last). All
+    // STRIP_H loads are issued back to back from clamped addresses and masked afterwards: guarded one by one, each was followed by a wait
+    // for itself -- eight cache round trips in a row before the strip's first row was asked for (round 5, seen in the ISA).
     const int pw8 = smaa::SearchPlanes::plane_words(w) * 8;                    // bytes per row-plane row
     const int byte_x = px >> 2;
     unsigned long long pbits[2] = {0, 0};
-    if (byte_x < pw8) {
+    {
         const uint8_t* const pplane = reinterpret_cast<const uint8_t*>(b.bits_prev);
+        const int bxc = byte_x < pw8 ? byte_x : pw8 - 1;
+        uint8_t pb[STRIP_H];
+#pragma unroll
+        for (int r = 0; r < STRIP_H; r++) pb[r] = pplane[(size_t)(y0 + r < h ? y0 + r : h - 1) * pw8 + bxc];
 #pragma unroll
         for (int r = 0; r < STRIP_H; r++)
-            if (y0 + r < h) pbits[r >> 3] |= (unsigned long long)pplane[(size_t)(y0 + r) * pw8 + byte_x] << ((r & 7) * 8);
+            if (y0 + r < h && byte_x < pw8) pbits[r >> 3] |= (unsigned long long)pb[r] << ((r & 7) * 8);
     }
 
     auto load_row = [&](int y, uint32_t c[4]) {                               // clamped in y; x clamped per pixel on the scalar path
         const int yc = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        if (vec_ok) {
-            const uint4 v = *reinterpret_cast<const uint4*>(color + (size_t)yc * w + px);
+        if constexpr (VEC) {
+            const uint4 v = *reinterpret_cast<const uint4*>(color + (size_t)yc * w + pxl);
             c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) c[k] = load_px(color, w, h, px + k, yc);
         }
+    };
+    // The strip's outermost columns of a row -- what lane 0 needs to its left (x0 - 2, x0 - 1) and the strip's last lane to its right
+    // (min(x0 + 256, w - 1): CLAMP_TO_EDGE) -- are ONE more load per row, issued with the row: lane 0 fetches x0 - 1, lane 1 x0 - 2, every other lane
+    // the right-hand texel; the row's iteration takes their lumas from lanes 0, 1 and 2 (v_readlane). Round 4 fetched them inside
+    // `if (lane == 0)` / `if (last lane)` in the iteration that needed them: three dependent cache round trips per row.
+    const bool right_lane = lane == 63 || px + 4 >= w;
+    const int border_x = lane == 0 ? x0 - 1 : (lane == 1 ? x0 - 2 : x0 + STRIP_W);
+    auto load_border = [&](int y) {
+        const int yc = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        return load_px(color, w, h, border_x, yc);
     };
     auto lumas = [&](const uint32_t c[4]) {
         Row4 r;
@@ -188,21 +212,35 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     };
 
     // window: lumas of rows y-1 (Lt) and y (Lc), vertical deltas |row - row below| of rows y-1 (dyt) and y (dyc)
-    uint32_t c0[4], c1[4], cc[4], cb[4], cn[4];
+    // The strip's rows travel through a ring of SMAA_ROW_DIST + 2 register rows: while row y is worked on, rows y + 1 ... y + 1 + SMAA_ROW_DIST are
+    // held or in flight (the loop below is unrolled, every ring index is a constant).
+    constexpr int RING = SMAA_ROW_DIST + 2;
+    uint32_t c0[4], c1[4], ring[RING][4];
+    uint32_t ering[RING];                                                      // the border texels travel with their rows
+#pragma unroll
+    for (int j = 0; j < RING; j++) ering[j] = 0;
     load_row(y0 - 2, c0);
     load_row(y0 - 1, c1);
-    load_row(y0, cc);
-    load_row(y0 + 1, cb);                                                      // two rows are always in flight ahead of the one being worked on
+#pragma unroll
+    for (int j = 0; j <= SMAA_ROW_DIST; j++) {
+        load_row(y0 + j, ring[j]);
+        if (j < STRIP_H) ering[j] = load_border(y0 + j);
+    }
     {
-        const float wgt[3] = {0.2126f, 0.7152f, 0.0722f};
-        for (int i = threadIdx.x; i < 768; i += 64 * WAVES_PER_WG) lut[i >> 8][i & 255] = smaa::unorm8((uint32_t)(i & 255)) * wgt[i >> 8];
+        // one entry of each table per thread, the weights as immediates: indexed from an array they were three loads from constant memory in a
+        // loop, each followed by a wait for EVERY load in flight -- the strip's first rows included (round 5, seen in the ISA)
+        static_assert(64 * WAVES_PER_WG == 256, "one table entry per thread");
+        const float u = smaa::unorm8((uint32_t)threadIdx.x);
+        lut[0][threadIdx.x] = u * 0.2126f;
+        lut[1][threadIdx.x] = u * 0.7152f;
+        lut[2][threadIdx.x] = u * 0.0722f;
     }
     __syncthreads();
     SMAA_EP(1);
     if (no_strip) return;
     const Row4 Ltt = lumas(c0);
     Row4 Lt = lumas(c1);
-    Row4 Lc = lumas(cc);
+    Row4 Lc = lumas(ring[0]);
     Row4 dyt, dyc;
 #pragma unroll
     for (int k = 0; k < 4; k++) { dyt.l[k] = fabsf(Lt.l[k] - Ltt.l[k]); dyc.l[k] = fabsf(Lc.l[k] - Lt.l[k]); }
@@ -215,17 +253,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     for (int r = 0; r < STRIP_H; r++) {
         const int y = y0 + r;
         if (y >= h) break;                                                     // wave-uniform
+        uint32_t* const cc = ring[r % RING];
+        uint32_t* const cb = ring[(r + 1) % RING];
+        const uint32_t ec = ering[r % RING];
+        if (r + 1 + SMAA_ROW_DIST <= STRIP_H) {
+            uint32_t* const cn = ring[(r + 1 + SMAA_ROW_DIST) % RING];
 #if SMAA_ABL & 32
-        if (r + 1 < STRIP_H) { for (int k = 0; k < 4; k++) cn[k] = cb[k] ^ (uint32_t)r; }
+            for (int k = 0; k < 4; k++) cn[k] = cb[k] ^ (uint32_t)r;
 #else
-        if (r + 1 < STRIP_H) load_row(y + 2, cn);
+            load_row(y + 1 + SMAA_ROW_DIST, cn);
+            if (r + 1 + SMAA_ROW_DIST < STRIP_H) ering[(r + 1 + SMAA_ROW_DIST) % RING] = load_border(y + 1 + SMAA_ROW_DIST);
 #endif
+        }
         const Row4 Lb = lumas(cb);
         // the dense copy: pass 3 for every pixel without weights (streamed: nothing reads these lines again before the sparse passes)
-        if (vec_ok) {
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            const v4u v = {cc[0], cc[1], cc[2], cc[3]};
-            __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(screen + (size_t)y * w + px));
+        if constexpr (VEC) {
+            if (vec_ok) {
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v4u v = {cc[0], cc[1], cc[2], cc[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(screen + (size_t)y * w + px));
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -235,14 +282,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #if SMAA_ABL & 4
         float left1 = Lc.l[3], left2 = Lc.l[2], right = Lc.l[0];
 #else
-        float left1 = __shfl_up(Lc.l[3], 1, 64), left2 = __shfl_up(Lc.l[2], 1, 64), right = __shfl_down(Lc.l[0], 1, 64);
-#endif
-#if !(SMAA_ABL & 2)
-        if (lane == 0) {
-            left1 = luma(load_px(color, w, h, px - 1, y));
-            left2 = luma(load_px(color, w, h, px - 2, y));
-        }
-        if (lane == 63 || px + 4 >= w) right = luma(load_px(color, w, h, px + 4, y));
+        // lumas of the strip's border texels: lane 0 holds x0 - 1, lane 1 x0 - 2, lane 2 the right-hand one (wave-uniform after the read)
+        const float le = luma(ec);
+        const int sl1 = __builtin_amdgcn_readlane(__float_as_int(le), 0), sl2 = __builtin_amdgcn_readlane(__float_as_int(le), 1);
+        const float sr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(le), 2));
+        // the neighbouring lanes' pixels by whole-wave DPP shifts (one VALU move each; __shfl_up / __shfl_down are ds_bpermute: an LDS round
+        // trip). wave_shr:1 = lane i reads lane i - 1 and lane 0 keeps `old` -- which is the border texel it needs.
+        const float left1 = __int_as_float(__builtin_amdgcn_update_dpp(sl1, __float_as_int(Lc.l[3]), 0x138, 0xf, 0xf, false));
+        const float left2 = __int_as_float(__builtin_amdgcn_update_dpp(sl2, __float_as_int(Lc.l[2]), 0x138, 0xf, 0xf, false));
+        const float rnext = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sr), __float_as_int(Lc.l[0]), 0x130, 0xf, 0xf, false));
+        const float right = right_lane ? sr : rnext;
 #endif
         const float row[7] = {left2, left1, Lc.l[0], Lc.l[1], Lc.l[2], Lc.l[3], right};
         float dx[6];                                                           // dx[j] = |row[j+1] - row[j]|: pixel k's own delta is dx[k+1]
@@ -262,8 +311,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
         Lc = Lb;
         dyt = dyc;
         dyc = dyb;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { cc[k] = cb[k]; cb[k] = cn[k]; }
     }
     SMAA_EP(3);
     // append: per-slot ballots rank the pixels; one atomic reserves the strip's entries
@@ -644,8 +691,12 @@ hipError_t smaa_launch(const SmaaBuffers& b, int preset, unsigned frame, hipStre
     const dim3 grid((b.w + STRIP_W * WAVES_PER_WG - 1) / (STRIP_W * WAVES_PER_WG), (b.h + strip_h - 1) / strip_h);
 #endif
     const float thr = smaa::preset_of(preset).threshold;
-    if (strip_h == 8) hipExtLaunchKernelGGL(smaa_edges_kernel<8>, grid, dim3(64 * WAVES_PER_WG), 0, stream, ev_start, nullptr, 0, b, thr, cur);
-    else hipExtLaunchKernelGGL(smaa_edges_kernel<16>, grid, dim3(64 * WAVES_PER_WG), 0, stream, ev_start, nullptr, 0, b, thr, cur);
+    const bool vec = (b.w & 3) == 0 && b.w >= 4;
+    const dim3 wg(64 * WAVES_PER_WG);
+    if (strip_h == 8 && vec) hipExtLaunchKernelGGL((smaa_edges_kernel<8, true>), grid, wg, 0, stream, ev_start, nullptr, 0, b, thr, cur);
+    else if (strip_h == 8) hipExtLaunchKernelGGL((smaa_edges_kernel<8, false>), grid, wg, 0, stream, ev_start, nullptr, 0, b, thr, cur);
+    else if (vec) hipExtLaunchKernelGGL((smaa_edges_kernel<16, true>), grid, wg, 0, stream, ev_start, nullptr, 0, b, thr, cur);
+    else hipExtLaunchKernelGGL((smaa_edges_kernel<16, false>), grid, wg, 0, stream, ev_start, nullptr, 0, b, thr, cur);
 #if SMAA_ROLE_WAVES
     hipLaunchKernelGGL(smaa_weights_roles_kernel, dim3(SMAA_ROLE_GRID), dim3(256), 0, stream, b, preset, cur);
 #else
