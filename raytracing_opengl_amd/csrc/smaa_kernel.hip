@@ -86,10 +86,18 @@ namespace {
 
 constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels = one 1 KiB row segment per load
 #ifndef SMAA_ABL
-#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = (round 4's strip-border loads; gone), 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 512 = the weight kernel only walks its list */
+#define SMAA_ABL 0   /* timing ablations only (tools/ab_smaa_ablate.sh): 1 = no edge arithmetic, 2 = (round 4's strip-border loads; gone), 4 = no cross-lane moves, 8 = no LDS luma tables, 16 = no append, 32 = rows above the first are not loaded, 64 = no screen copy, 128 = the append's atomic is not issued (entries overwrite each other), 256 = no plane / texel stores, 512 = the weight kernel only walks its list */
+#endif
+#ifndef SMAA_STORES_IN_LOOP
+#define SMAA_STORES_IN_LOOP 1  /* a row's plane byte and its RG8 edge texels are stored in the row's own iteration of the strip walk, under the row stream, instead
+                                  of sixteen stores per wave behind the walk -- where every wave of the frame arrives at the same time (round 5) */
+#endif
+#ifndef SMAA_SCALAR_ATOMIC
+#define SMAA_SCALAR_ATOMIC 1  /* the append reserves its list entries with a SCALAR atomic (s_atomic_add, returns under lgkmcnt): a vector atomic's return value is
+                                 counted by vmcnt, in order behind every store the wave has issued -- an appending wave waited for its eight row stores to drain (round 5) */
 #endif
 #ifndef SMAA_EARLY_ATOMIC
-#define SMAA_EARLY_ATOMIC 1   /* the append's atomic is issued before the plane and texel stores (round 4: traced ULTRA edges 25.2 -> 23.9 us, other presets +-0) */
+#define SMAA_EARLY_ATOMIC (!SMAA_SCALAR_ATOMIC)   /* the append's atomic is issued before the plane and texel stores (round 4: traced ULTRA edges 25.2 -> 23.9 us, other presets +-0) */
 #endif
 #ifndef SMAA_ROW_DIST
 #define SMAA_ROW_DIST 1       /* a row is requested this many iterations of the strip walk before the one that needs it */
@@ -245,6 +253,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #pragma unroll
     for (int k = 0; k < 4; k++) { dyt.l[k] = fabsf(Lt.l[k] - Ltt.l[k]); dyc.l[k] = fabsf(Lc.l[k] - Lt.l[k]); }
     SMAA_EP(2);
+    // a lane's four RG8 edge texels of a row as ONE 8-byte store (wherever this frame or the previous one has an edge among them)
+    auto store_texels = [&](int y, unsigned bits8) {
+        uint16_t tx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tx[k] = (uint16_t)((((bits8 >> (2 * k)) & 1u) ? 0x00ffu : 0u) | (((bits8 >> (2 * k)) & 2u) ? 0xff00u : 0u));
+        uint16_t* const dst = b.edges + (size_t)y * w + px;
+        if (vec_ok) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)tx[0] | ((unsigned)tx[1] << 16), (unsigned)tx[2] | ((unsigned)tx[3] << 16));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (px + k < w) dst[k] = tx[k];
+        }
+    };
     unsigned long long ebits[2] = {0, 0};                                      // worked on. 2 bits (R, G) per pixel: bit (row * 4 + k) * 2
     unsigned valid = 0;
 #pragma unroll
@@ -267,6 +289,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
         }
         const Row4 Lb = lumas(cb);
         // the dense copy: pass 3 for every pixel without weights (streamed: nothing reads these lines again before the sparse passes)
+#if SMAA_ABL & 64
+        if (threshold < -1.0e30f)                                             // (timing ablation: the screen copy is never stored)
+#endif
         if constexpr (VEC) {
             if (vec_ok) {
                 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -307,6 +332,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #endif
         }
         ebits[r >> 3] |= (unsigned long long)(bits & valid) << ((r & 7) * 8);
+#if SMAA_STORES_IN_LOOP && !(SMAA_ABL & 256)
+        {
+            const unsigned bits8 = bits & valid, old8 = (unsigned)(pbits[r >> 3] >> ((r & 7) * 8)) & 0xffu;
+            if (byte_x < pw8) reinterpret_cast<uint8_t*>(b.bits)[(size_t)y * pw8 + byte_x] = (uint8_t)bits8;
+            if ((bits8 | old8) != 0u) store_texels(y, bits8);
+        }
+#endif
         Lt = Lc;
         Lc = Lb;
         dyt = dyc;
@@ -339,13 +371,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #endif
     // the bit planes (dense: edge-free strips write their zeros too, so the planes need no clearing). Rows: this lane's four pixels of a
     // row are one byte, 64 lanes = 64 consecutive bytes. Columns: per 8-row block and column 16 bits, this lane's four columns = 8 bytes.
+#if SMAA_ABL & 256
+    if (threshold < -1.0e30f)
+#endif
     {
         uint8_t* const plane = reinterpret_cast<uint8_t*>(b.bits);
+#if !SMAA_STORES_IN_LOOP
         if (byte_x < pw8) {
 #pragma unroll
             for (int r = 0; r < STRIP_H; r++)
                 if (y0 + r < h) plane[(size_t)(y0 + r) * pw8 + byte_x] = (uint8_t)(ebits[r >> 3] >> ((r & 7) * 8));
         }
+#else
+        (void)plane;
+#endif
 #pragma unroll
         for (int blk = 0; blk < (STRIP_H + 7) / 8; blk++) {
             if (y0 + blk * 8 >= h) break;                                      // wave-uniform
@@ -373,25 +412,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
     // previous list's texels with a kernel of its own: 5 us, the fixed cost of any sparse kernel here).
     SMAA_EP(4);
     SMAA_EP(5);
+#if !SMAA_STORES_IN_LOOP
     if (__ballot((ebits[0] | ebits[1] | pbits[0] | pbits[1]) != 0) == 0) return;   // wave-uniform: most strips leave here
 #pragma unroll
     for (int r = 0; r < STRIP_H; r++) {
         const unsigned bits8 = (unsigned)(ebits[r >> 3] >> ((r & 7) * 8)) & 0xffu, old8 = (unsigned)(pbits[r >> 3] >> ((r & 7) * 8)) & 0xffu;
         if (__ballot((bits8 | old8) != 0u) == 0) continue;                     // wave-uniform
-        if ((bits8 | old8) != 0u) {
-            uint16_t tx[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) tx[k] = (uint16_t)((((bits8 >> (2 * k)) & 1u) ? 0x00ffu : 0u) | (((bits8 >> (2 * k)) & 2u) ? 0xff00u : 0u));
-            uint16_t* const dst = b.edges + (size_t)(y0 + r) * w + px;
-            if (vec_ok) {
-                *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)tx[0] | ((unsigned)tx[1] << 16), (unsigned)tx[2] | ((unsigned)tx[3] << 16));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (px + k < w) dst[k] = tx[k];
-            }
-        }
+        if ((bits8 | old8) != 0u) store_texels(y0 + r, bits8);
     }
+#endif
     if (__ballot((ebits[0] | ebits[1]) != 0) == 0) return;                     // wave-uniform: nothing to append
     const unsigned long long any[2] = {(ebits[0] | (ebits[0] >> 1)) & 0x5555555555555555ull, (ebits[1] | (ebits[1] >> 1)) & 0x5555555555555555ull};
     // The list: an inclusive scan of the lanes' pixel counts ranks them (six cross-lane steps instead of a ballot per pixel slot), the last
@@ -409,7 +438,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 #endif
     const unsigned seg = strip % SMAA_SEGMENTS;
     unsigned base = 0;
-#if SMAA_EARLY_ATOMIC
+#if SMAA_SCALAR_ATOMIC
+    {
+        // lane 63's inclusive sum is the strip's total; the counter's address is wave-uniform
+        uint32_t* const cnt = b.count + cur * SMAA_COUNT_SET + (unsigned)__builtin_amdgcn_readfirstlane((int)seg) * SMAA_COUNT_STRIDE;
+        base = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+#if !(SMAA_ABL & 128)
+        asm volatile("s_nop 4\n\ts_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(base) : "s"(cnt) : "memory");
+#endif
+    }
+#elif SMAA_EARLY_ATOMIC
     base = __shfl(base_e, 63, 64);
 #else
     if (lane == 63) base = atomicAdd(b.count + cur * SMAA_COUNT_SET + seg * SMAA_COUNT_STRIDE, incl);   // lane 63's inclusive sum is the total
