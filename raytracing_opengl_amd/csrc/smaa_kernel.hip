@@ -93,7 +93,7 @@ constexpr int STRIP_W = 256;     // pixels per wave and row: 64 lanes x 4 pixels
                                   of sixteen stores per wave behind the walk -- where every wave of the frame arrives at the same time (round 5) */
 #endif
 #ifndef SMAA_SCALAR_ATOMIC
-#define SMAA_SCALAR_ATOMIC 1  /* the append reserves its list entries with a SCALAR atomic (s_atomic_add, returns under lgkmcnt): a vector atomic's return value is
+#define SMAA_SCALAR_ATOMIC 0  /* the append reserves its list entries with a SCALAR atomic (s_atomic_add, returns under lgkmcnt): a vector atomic's return value is
                                  counted by vmcnt, in order behind every store the wave has issued -- an appending wave waited for its eight row stores to drain (round 5) */
 #endif
 #ifndef SMAA_EARLY_ATOMIC

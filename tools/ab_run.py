@@ -18,8 +18,9 @@ def child(scene_names, steps):
     out = []
     for name in scene_names:
         name, _, depth = name.partition(":")          # "torus:6" = the torus scene at reflection depth 6 (default 4)
-        sc = scenes.build_scene(name, 3840, 2160, int(depth or 4))
-        gl = wrapper.make_renderer(sc, 3840, 2160, ts["textures"], ts["cubemap"])
+        W, H = (int(v) for v in os.environ.get("AB_SIZE", "3840x2160").split("x"))   # AB_SIZE=1920x1080: configs[1]
+        sc = scenes.build_scene(name, W, H, int(depth or 4))
+        gl = wrapper.make_renderer(sc, W, H, ts["textures"], ts["cubemap"])
         for _ in range(3):
             gl.draw()
         gl.finish()
