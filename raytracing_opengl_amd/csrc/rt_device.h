@@ -703,7 +703,7 @@ RT_HD TorusRay torus_ray_setup(const DevTorus& T, f3 ro, f3 rd)
     return w;
 }
 // The iteration itself (rt.frag:462-485): the smallest iterate that looks like a real, non-negative root, 10000 if none does. Takes nothing but the
-// seven ray terms -- which is what lets a solve run in ANOTHER lane than the ray's (torus_pool_round).
+// seven ray terms -- which is what would let a solve run in ANOTHER lane than the ray's (round 5 built that as a workgroup-wide pool: profiles/r05s_torus_pool_ab.txt, not shipped).
 RT_COLD float dk_solve(const TorusRay& w)
 {
     const float eps = 0.001f;
@@ -999,83 +999,6 @@ RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t
     bool solved;
     return intersect_torus_c<false>(T, ro, rd, tmin, t, solved);
 }
-
-// ---- the workgroup's solver pool (round 5; the many-primitive product variant only) ----
-// A solver run costs a wave the same whether one lane or all 64 hold a quartic, and on the torus-heavy frame a run is entered by 35 lanes
-// (tools/dk_stats.py): which lanes' rays survive the culls of THEIR torus is decided per wave. The four waves of a workgroup trace neighbouring
-// 8x8 tiles and reach their torus scans together, so in the pooled form a scan does not solve: every lane that holds a candidate which survived
-// its culls writes the seven ray terms of its quartic (TorusRay -- all dk_solve needs) into a request slot in LDS, the workgroup meets at a
-// barrier, the requests are solved by the first ceil(n / 64) waves with full lanes, the results go back through LDS behind a second barrier
-// and every lane judges its own root as before (torus_root_accepted, in candidate order with its live tmin: strict <, first wins, any-hit
-// exits unchanged; a shadow lane whose first candidate hits has at most solved a later one for nothing). One request per lane and round,
-// rounds until a round is empty. For the barriers to be legal every wave of the workgroup must take the same number of rounds: the bounce
-// loop, the closest-hit scan, the shading site and every light's shadow scan run workgroup-uniformly in this form (a wave whose lanes are
-// all dead walks through them with every scan voted off), and the loop ends when no lane of the WORKGROUP is alive (voted in the round).
-// The barriers are plain __syncthreads(): their fences would cost every scalar load behind them if the scene were read through global
-// pointers (a fence is a possible store to everything: the lesson of profiles/r05d_setprio_builtin_clobbers_scalar_loads.txt) -- the kernel
-// hands the scene on as pointers into the constant address space for exactly that reason (rt_kernel.hip).
-// (explicit LDS address space: as generic pointers carried through this struct the accesses came out as FLAT loads and stores -- and a flat
-// store may alias the scene, which again costs every scalar load behind it: s_load 305 -> 42 in the first build)
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) float rt_lds_float;
-typedef __attribute__((address_space(3))) unsigned rt_lds_uint;
-#endif
-struct TorusPool {
-#if defined(__HIP_DEVICE_COMPILE__)
-    rt_lds_float* slot;      // 8 columns of 256: the seven ray terms and the result of up to 255 requests; entry 255 of columns 0..3 = the counters:
-                             // requests of this / the next round (alternating), "a lane of the workgroup is alive" (alternating)
-    int round;                 // rounds taken so far: the same in every wave
-#endif
-};
-#if defined(__HIP_DEVICE_COMPILE__)
-// One round. `has`: this lane holds a request (w); on return `has` is false if it was taken (t_out = the smallest root the solver reports) and
-// still true if the round was full (255 requests: the lane offers it again in the next round). Returns the number of requests solved: 0 ends the scan.
-RT_HD unsigned torus_pool_round(TorusPool& Q, bool& has, const TorusRay& w, float& t_out, bool alive, bool& wg_alive)
-{
-    enum { COL = 256, CAP = 255, RESULT = 7 * COL };   // entry 255 of columns 0..3 holds the four counters: a round takes 255 requests
-    const int p = Q.round & 1;
-    const int rot = Q.round >> 1;
-    Q.round++;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    rt_lds_uint* const ctr = (rt_lds_uint*)Q.slot;
-    // the other parity's words are free: every wave has left the previous round (it is here, or on its way here with nothing left to read there)
-    if (tid == 0) { ctr[(p ^ 1) * COL + CAP] = 0u; ctr[(2 + (p ^ 1)) * COL + CAP] = 0u; }
-    const unsigned long long m = __ballot(has), am = __ballot(alive);
-    int slot = 0;
-    bool taken = false;
-    if (m != 0ull) {
-        unsigned base = 0u;
-        if (lane == 0) base = __hip_atomic_fetch_add(&ctr[p * COL + CAP], (unsigned)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_rtn: one per wave and round
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        slot = (int)base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        taken = has && slot < CAP;
-        if (taken) {
-            Q.slot[slot] = w.a; Q.slot[slot + COL] = w.b; Q.slot[slot + 2 * COL] = w.c; Q.slot[slot + 3 * COL] = w.axy;
-            Q.slot[slot + 4 * COL] = w.bxy; Q.slot[slot + 5 * COL] = w.cxy; Q.slot[slot + 6 * COL] = w.k;
-        }
-    }
-    if (lane == 0 && am != 0ull) ctr[(2 + p) * COL + CAP] = 1u;
-    __syncthreads();
-    unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)ctr[p * COL + CAP]);
-    n = n < (unsigned)CAP ? n : (unsigned)CAP;
-    wg_alive = __builtin_amdgcn_readfirstlane((int)ctr[(2 + p) * COL + CAP]) != 0;
-    if (n == 0u) return 0u;
-    // The requests are solved by ceil(n / 64) waves with full lanes -- not always the workgroup's first ones: wave k of every workgroup sits on
-    // SIMD k of its CU, and the pool of a whole CU would run on one or two of its four SIMDs.
-    const int q = ((((tid >> 6) - rot - (int)blockIdx.x) & 3) << 6) | lane;
-    if ((unsigned)q < n) {
-        TorusRay r;
-        r.a = Q.slot[q]; r.b = Q.slot[q + COL]; r.c = Q.slot[q + 2 * COL]; r.axy = Q.slot[q + 3 * COL];
-        r.bxy = Q.slot[q + 4 * COL]; r.cxy = Q.slot[q + 5 * COL]; r.k = Q.slot[q + 6 * COL];
-        Q.slot[RESULT + q] = dk_solve(r);
-    }
-    __syncthreads();
-    if (taken) { t_out = Q.slot[RESULT + slot]; has = false; }
-    return n;
-}
-#else
-RT_HD unsigned torus_pool_round(TorusPool&, bool&, const TorusRay&, float&, bool, bool&) { return 0u; }   // the host build never pools
-#endif
 
 // ---- general quadric (rt.frag:499-572) ----
 RT_HD bool is_between(f3 v, f3 lo, f3 hi) { return (v.x > lo.x && v.y > lo.y && v.z > lo.z) && (v.x < hi.x && v.y < hi.y && v.z < hi.z); }
@@ -1596,20 +1519,14 @@ RT_HD PencilScan pencil_open(const SceneView& S, int pencil, f3 ro, f3 rd, float
     return ps;
 }
 
-// POOL (with Q): the pooled form of the torus scan, see TorusPool -- EVERY lane of the workgroup enters, `on` says which cast a ray; without POOL
-// the function is called by the casting lanes only and `on` is true.
-template <bool CULL, bool COUNT, bool GROUPS = true, bool POOL = false>
-RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1, bool on = true,
-                       TorusPool* Q = nullptr, bool* wg_alive = nullptr)
+template <bool CULL, bool COUNT, bool GROUPS = true>
+RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, LaneCounters& cnt, int pencil = -1)
 {
     float tmin = RT_MAXDIST;
     float t = 0.0f;
     if (COUNT) cnt.closest++;
     RT_PH_DECL;
-    PencilScan ps = {};
-    uint32_t slabw[RT_SLAB_MAX_WORDS];
-    if (!POOL || on) {
-    ps = pencil_open<GROUPS && CULL>(S, pencil, ro, rd, 0.0f, true);
+    PencilScan ps = pencil_open<GROUPS && CULL>(S, pencil, ro, rd, 0.0f, true);
     for (int i = 0; i < S.h->n_plane; i++) {
         if (intersect_plane(ro, rd, xyz(S.planes()[i].normal), xyz(S.planes()[i].pos), tmin, t)) { num = i; tmin = t; type = TYPE_PLANE; }
     }
@@ -1623,6 +1540,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         }
     }
     RT_PH_LAP(cnt, PH_C_SPH);
+    uint32_t slabw[RT_SLAB_MAX_WORDS];
     if (GROUPS && CULL && !ps.use && slabs_available(S)) {   // a ray of no pencil: its candidates from the slab tables, up to the closest hit so far
         slab_ray_mask(S, ro, rd, tmin, slabw);
         ps.use = true;
@@ -1685,7 +1603,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         }
     }
     RT_PH_LAP(cnt, PH_C_BOX);
-    }   // (!POOL || on)
     if (CULL && S.h->n_torus >= RT_LANE_DIVERGENT_MIN) {
         const int n = S.h->n_torus;
         const f4* bound = S.torus_bound();
@@ -1694,8 +1611,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             const int end = base + 64 < n ? base + 64 : n;
             const bool grouped = GROUPS && n >= RT_GROUP_MIN;
             bool group_live = true;
-            if (POOL && !on) {
-            } else
             if (ps.use) {   // phase 1 over the wave's pencil candidates only
                 for (int w = base >> 5; w << 5 < end; w++) {
                     uint32_t u = wave_or(ps.next(S, slabw), true);
@@ -1713,26 +1628,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd)) cand |= 1ull << (i + k - base);)
             }
             dk_stats_scan(cand);
-            if (POOL) {
-                bool has = false;
-                int i = 0;
-                TorusRay w = {};
-                for (;;) {   // rounds of the workgroup's pool: workgroup-uniform
-                    while (cand != 0ull && !has) {   // the lane's next candidate that survives the culls in its own frame
-                        i = base + lane_pop(cand);
-                        const DevTorus& Tr = S.tori()[i];
-                        const bool ident = ident_flag(Tr.pos.w);
-                        const f3 o = quat_rotate_id(Tr.quat, ident, ro - xyz(Tr.pos)), d = quat_rotate_id(Tr.quat, ident, rd);
-                        if (!torus_local_cull<GROUPS>(Tr, o, d)) { has = true; w = torus_ray_setup(Tr, o, d); }
-                    }
-                    bool wga = false;
-                    const bool asked = has;
-                    const unsigned nreq = torus_pool_round(*Q, has, w, t, on, wga);
-                    if (wg_alive != nullptr && base == 0) *wg_alive = wga;   // (every round of the scan sees the same votes)
-                    if (nreq == 0u) break;
-                    if (asked && !has && torus_root_accepted(t, tmin)) { num = i; tmin = t; type = TYPE_TORUS; }
-                }
-            } else
             while (RT_ANY(cand != 0ull)) {
                 if (cand != 0ull) {
                     const int i = base + lane_pop(cand);          // differs from lane to lane
@@ -1743,7 +1638,7 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 }
             }
         }
-    } else if (!POOL || on) {
+    } else {
         const int n = S.h->n_torus;
         const f4* bound = S.torus_bound();
         for (int i = 0; i < n; i += 4) {
@@ -1767,7 +1662,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         }
     }
     RT_PH_LAP(cnt, PH_C_TORUS);
-    if (!POOL || on) {
     {
         const int n = S.h->n_ring;
         const f4* bound = S.ring_bound();
@@ -1790,7 +1684,6 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         if (intersect_sphere(ro, rd, S.lights_point()[i].pos_r2, false, tmin, t)) { num = i; tmin = t; type = TYPE_POINT_LIGHT; }
     }
     RT_PH_LAP(cnt, PH_C_LIGHT);
-    }   // (!POOL || on)
     return tmin;
 }
 
@@ -1798,9 +1691,8 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
 // set it to 1 or add a non-negative alpha and the result is min(shadow,1) (rt.frag:657), so the
 // early exit is exact. The any-hit scan is an OR (a float sum for textured rings only), so the
 // cheap classes go first; ring order is kept for the sum.
-template <bool CULL, bool COUNT, bool GROUPS = true, bool POOL = false>
-RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt, int pencil = -1,
-                      TorusPool* Q = nullptr)
+template <bool CULL, bool COUNT, bool GROUPS = true>
+RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_on, f3 ro, f3 rd, float dist, LaneCounters& cnt, int pencil = -1)
 {
     float shadow = 0.0f;
     float t = 0.0f;
@@ -1878,7 +1770,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         }
     }
     if (CULL && S.h->n_torus >= RT_LANE_DIVERGENT_MIN) {
-        if (POOL || RT_ANY(on)) {   // (pooled: workgroup-uniform, a wave without a casting lane still takes the rounds)
+        if (RT_ANY(on)) {
             const int n = S.h->n_torus;
             const f4* bound = S.torus_bound();
             for (int base = 0; base < n; base += 64) {
@@ -1886,8 +1778,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 const int end = base + 64 < n ? base + 64 : n;
                 const bool grouped = GROUPS && n >= RT_GROUP_MIN;
                 bool group_live = true;
-                if (POOL && !RT_ANY(on)) {
-                } else
                 if (ps.use) {
                     for (int w = base >> 5; w << 5 < end; w++) {
                         uint32_t u = wave_or(ps.next(S, slabw), on);
@@ -1905,22 +1795,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                     RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd)) cand |= 1ull << (i + k - base);)
                 }
                 dk_stats_scan(cand);
-                if (POOL) {
-                    bool has = false;
-                    TorusRay w = {};
-                    for (;;) {   // rounds of the workgroup's pool (see calc_inter)
-                        while (cand != 0ull && !has) {
-                            const DevTorus& Tr = S.tori()[base + lane_pop(cand)];
-                            const bool ident = ident_flag(Tr.pos.w);
-                            const f3 o = quat_rotate_id(Tr.quat, ident, ro - xyz(Tr.pos)), d = quat_rotate_id(Tr.quat, ident, rd);
-                            if (!torus_local_cull<GROUPS>(Tr, o, d)) { has = true; w = torus_ray_setup(Tr, o, d); }
-                        }
-                        bool wga = false;
-                        const bool asked = has;
-                        if (torus_pool_round(*Q, has, w, t, false, wga) == 0u) break;
-                        if (asked && !has && torus_root_accepted(t, dist)) { shadow = 1.0f; on = false; cand = 0ull; }
-                    }
-                } else {
                 while (RT_ANY(cand != 0ull)) {
                     if (cand != 0ull) {
                         const int i = base + lane_pop(cand);
@@ -1931,7 +1805,6 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                     }
                 }
                 if (!RT_ANY(on)) break;
-                }
             }
         }
     } else if (RT_ANY(on)) {
@@ -1943,7 +1816,7 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 const f4 b[4] = {bound[i], bound[i + 1], bound[i + 2], bound[i + 3]};
                 RT_UNROLL4(need[k] = need[k] && !torus_cull(b[k], ro, rd);)
             }
-#ifdef RT_ABL_TORUS   /* timing ablation only (wrong frames): 1 = the second light's shadow rays skip the tori, 2 = every shadow ray does */
+#ifdef RT_ABL_TORUS   /* timing ablation only (wrong frames): 1 = the second light's shadow rays skip the tori, 2 = every shadow ray does (profiles/r05q_*) */
             if ((RT_ABL_TORUS & 2) || ((RT_ABL_TORUS & 1) && pencil == 2)) { need[0] = need[1] = need[2] = need[3] = false; }
 #endif
             for (int k = 0; k < 4; k++) {
@@ -2010,8 +1883,8 @@ struct Surf {           // what calcShade needs from a hit
     float kd, ks;
 };
 
-template <bool CULL, bool COUNT, bool GROUPS = true, bool POOL = false>
-RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd, const Surf& m, f3 normal, LaneCounters& cnt, TorusPool* Q = nullptr)
+template <bool CULL, bool COUNT, bool GROUPS = true>
+RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd, const Surf& m, f3 normal, LaneCounters& cnt)
 {
     f3 diffuse = mk3(0.0f, 0.0f, 0.0f);
     f3 specular = mk3(0.0f, 0.0f, 0.0f);
@@ -2044,7 +1917,7 @@ RT_HD f3 calc_shade(const SceneView& S, const TexTable& T, bool on, f3 pt, f3 rd
         // (NaN dp must still take the full path so that it propagates like in the shader.)
         const bool cast = on && !(dp == 0.0f);
         RT_PH_BEGIN(_sh0);
-        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS, POOL>(S, T, cast, on, pt, light_dir, dist, cnt, 1 + li, Q);   // pencil 0 is the camera's
+        const float sh = 1.0f - in_shadow<CULL, COUNT, GROUPS>(S, T, cast, on, pt, light_dir, dist, cnt, 1 + li);   // pencil 0 is the camera's
         RT_PH_END(cnt, PH_SHADOW, _sh0);
         if (cast) {
             light_color = light_color * mk3(gl_max(sh, shadow_ambient.x), gl_max(sh, shadow_ambient.y), gl_max(sh, shadow_ambient.z));
@@ -2289,12 +2162,9 @@ struct PathScalars {   // the four loop scalars: LDS slots PS_SCALARS.. (WIDE la
     RT_HDM void sti(const PathStore& P, int k, int v) { st(P, k, __builtin_bit_cast(float, v)); }
 };
 
-template <bool CULL, bool COUNT, bool WIDE = false, bool GROUPS = true, bool POOL = false>
-RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, bool alive, float frag_x, float frag_y, LaneCounters& cnt,
-                     TorusPool* pool = nullptr)
+template <bool CULL, bool COUNT, bool WIDE = false, bool GROUPS = true>
+RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
 {
-    // pooled solver runs (TorusPool): only where the lane-divergent torus scan runs at all; a scene constant, so the same in the whole grid
-    const bool pooled = POOL && CULL && S.h->n_torus >= RT_LANE_DIVERGENT_MIN;
     PathScalars<WIDE> Q;
     P.st3(PS_MASK, mk3(1.0f, 1.0f, 1.0f));
     P.st3(PS_COLOR, mk3(0.0f, 0.0f, 0.0f));
@@ -2313,7 +2183,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
     alive = alive && iterations > 0;
     RT_PH_DECL;
     RT_PH_LAP(cnt, PH_SETUP);
-    while (pooled || RT_ANY(alive)) {   // (pooled: left below, when no lane of the WORKGROUP is alive)
+    while (RT_ANY(alive)) {
         RT_PH_ADD(cnt, PH_TRIPS, 1);
         const bool is_side = side;  // what THIS trip traces
         if (alive && !is_side) Q.sti(P, QS_COUNT, Q.ldi(P, QS_COUNT) + 0x10000);   // segments++
@@ -2322,11 +2192,7 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         // ---- one closest-hit ray per live lane ----
         int num = 0, type = -1;  // type is written only on a hit (rt.frag:593...); -1 = "nothing" (trap T3)
         float tm = RT_MAXDIST;
-        if (pooled) {
-            bool wg_alive = false;
-            tm = calc_inter<CULL, COUNT, GROUPS, POOL>(S, ro, rd, num, type, cnt, cam_pencil, alive, pool, &wg_alive);
-            if (!wg_alive) break;
-        } else if (alive) tm = calc_inter<CULL, COUNT, GROUPS, POOL>(S, ro, rd, num, type, cnt, cam_pencil, true, pool, nullptr);
+        if (alive) tm = calc_inter<CULL, COUNT, GROUPS>(S, ro, rd, num, type, cnt, cam_pencil);
         cam_pencil = -1;
         const bool hit = alive && (tm < RT_MAXDIST);  // false for NaN tm (trap T5)
         RT_PH_LAP(cnt, PH_SCAN);
@@ -2443,11 +2309,11 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         RT_PH_LAP(cnt, PH_SKY);
         // ---- the single shading site ----
         f3 col = mk3(0.0f, 0.0f, 0.0f);
-        if (pooled || RT_ANY(act != ACT_NONE)) {
+        if (RT_ANY(act != ACT_NONE)) {
             Q.st(P, QS_W, w_s);
             Q.st(P, QS_K, k_mask);
             P.fence();
-            col = calc_shade<CULL, COUNT, GROUPS, POOL>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt, pool);
+            col = calc_shade<CULL, COUNT, GROUPS>(S, T, act != ACT_NONE, sh_pt, rd, h.surf, n, cnt);
         }
         RT_PH_LAP(cnt, PH_SHADE);
 

@@ -86,9 +86,6 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 #ifndef RT_CONST_SCENE
 #define RT_CONST_SCENE 1
 #endif
-#ifndef RT_TORUS_POOL
-#define RT_TORUS_POOL 1   /* the many-primitive product variant solves its torus quartics in a workgroup-wide pool (rt_device.h TorusPool) */
-#endif
 // Two register budgets of the same code (WPE = waves per SIMD the compiler must make room for; numbers for 4K frames,
 // built with -mllvm -disable-machine-licm, see the Makefile):
 //   WPE = RT_WAVES_PER_EU (6: 80 VGPRs, path state in LDS, 44 B of scratch per lane around the torus solver's register
@@ -186,8 +183,8 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     // The scene blob, its header and the pencil masks are read-only for the whole launch: handed on as pointers into the CONSTANT address space
     // (cast there and back; the compiler's address-space inference sees through the round trip), every wave-uniform load of them is a scalar
     // load by definition. As plain global pointers they are scalar only where the compiler can prove that no store in the kernel may have
-    // clobbered them -- a proof it gives up on beyond a hundred stores or at the first barrier (round 5: the pooled variant's s_load count fell
-    // from 305 to 42; every "one harmless line made the kernel 40 % slower" of rounds 2 - 5 was this).
+    // clobbered them -- a proof it gives up on beyond a hundred stores or at the first barrier (round 5: a pooled-solver variant's s_load count fell
+    // from 305 to 42, profiles/r05s_torus_pool_ab.txt; most likely every "one harmless line made the kernel 40 % slower" of rounds 2 - 5 was this).
 #if defined(__HIP_DEVICE_COMPILE__) && RT_CONST_SCENE
     typedef const __attribute__((address_space(4))) char* rt_const_ptr;
     rt_const_ptr scene_k = (rt_const_ptr)p.scene, masks_k = (rt_const_ptr)(const char*)p.pencil_masks;
@@ -213,20 +210,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     path.base = path_lds + threadIdx.x;
     path.fence_slot = p.ps_fence_slot;
 #endif
-    // The workgroup's solver pool (rt_device.h TorusPool): the many-primitive PRODUCT variant only -- the counting variant keeps the per-wave
-    // solver runs, so "product == counting variant, bit for bit" (tests, tools/fuzz_gpu.py) compares the two forms on every frame.
-    constexpr bool POOL = HEAVY && !COUNT && (RT_TORUS_POOL != 0);
-    __shared__ float pool_slots[POOL ? 8 * 256 : 1];   // (24 KB of path state + 8 KB = 32 KB: five workgroups per CU; the counters live inside)
-    rtdev::TorusPool pool;
-#if defined(__HIP_DEVICE_COMPILE__)
-    pool.slot = (rtdev::rt_lds_float*)pool_slots;
-    pool.round = 0;
-    if (POOL) {
-        if (threadIdx.x < 4) ((rtdev::rt_lds_uint*)pool.slot)[threadIdx.x * 256 + 255] = 0u;
-        __syncthreads();
-    }
-#endif
-    const f4 px = trace_pixel<CULL, COUNT, WIDE, HEAVY, POOL>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt, &pool);   // group culls: the many-primitive variant only
+    const f4 px = trace_pixel<CULL, COUNT, WIDE, HEAVY>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);   // group culls: the many-primitive variant only
 
     // The pixel's coordinates are needed again only here. They are RE-DERIVED from the thread index
     // (laundered through an empty asm so the compiler cannot keep the first copy alive) instead of

@@ -7,7 +7,10 @@
 #ifndef SMAA_COUNT_STRIDE
 #define SMAA_COUNT_STRIDE 32   /* dwords between two segment counters: every counter in a 128-byte line of its own (smaa_kernel.hip) */
 #endif
-enum { SMAA_SEGMENTS = 64, SMAA_COUNT_SET = SMAA_SEGMENTS * SMAA_COUNT_STRIDE };
+#ifndef SMAA_SEGMENTS_N
+#define SMAA_SEGMENTS_N 64     /* list segments (64 or 256): a strip appends to segment (strip index mod SMAA_SEGMENTS_N) */
+#endif
+enum { SMAA_SEGMENTS = SMAA_SEGMENTS_N, SMAA_COUNT_SET = SMAA_SEGMENTS * SMAA_COUNT_STRIDE };
 
 struct SmaaBuffers {
     int w, h;

@@ -472,26 +472,43 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void smaa_edges_kernel(SmaaBuffe
 // the segments' individual lengths.
 struct SegmentedList {
     unsigned prefix[SMAA_SEGMENTS + 1];
+    unsigned wave_sum[4];
     __device__ __forceinline__ unsigned load(const uint32_t* counts)    // returns the total; all 256 threads must call it
     {
-        static_assert(SMAA_SEGMENTS == 64, "one count per lane of the first wave");
-        if (threadIdx.x < 64) {
+        static_assert(SMAA_SEGMENTS == 64 || SMAA_SEGMENTS == 256, "one count per lane of the first wave, or one per thread of the workgroup");
+        if (SMAA_SEGMENTS == 64) {
+            if (threadIdx.x < 64) {
+                unsigned v = counts[threadIdx.x * SMAA_COUNT_STRIDE];
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned u = __shfl_up(v, off, 64);
+                    if ((int)threadIdx.x >= off) v += u;
+                }
+                prefix[threadIdx.x + 1] = v;
+                if (threadIdx.x == 0) prefix[0] = 0;
+            }
+            __syncthreads();
+        } else {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
             unsigned v = counts[threadIdx.x * SMAA_COUNT_STRIDE];
             for (int off = 1; off < 64; off <<= 1) {
                 const unsigned u = __shfl_up(v, off, 64);
-                if ((int)threadIdx.x >= off) v += u;
+                if (lane >= off) v += u;
             }
-            prefix[threadIdx.x + 1] = v;
+            if (lane == 63) wave_sum[wave] = v;
+            __syncthreads();
+            unsigned add = 0;
+            for (int k = 0; k < wave; k++) add += wave_sum[k];
+            prefix[threadIdx.x + 1] = v + add;
             if (threadIdx.x == 0) prefix[0] = 0;
+            __syncthreads();
         }
-        __syncthreads();
         return prefix[SMAA_SEGMENTS];
     }
     __device__ __forceinline__ unsigned locate(unsigned i, unsigned& within) const   // flat index -> segment, index within it
     {
         unsigned lo = 0;                                                  // largest seg with prefix[seg] <= i
 #pragma unroll
-        for (int bit = 32; bit > 0; bit >>= 1)
+        for (int bit = SMAA_SEGMENTS / 2; bit > 0; bit >>= 1)
             if (prefix[lo + bit] <= i) lo += bit;
         within = i - prefix[lo];
         return lo;
