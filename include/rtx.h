@@ -197,9 +197,12 @@ RTX_API int rtx_texture2d_create(rtx_context* ctx, int width, int height, int ch
 /* GLWrapper::load_cubemap(faces,genMipmap) minus the file decode  [GLWrapper.cpp:284-317]:
  * faces in +X,-X,+Y,-Y,+Z,-Z order; a NULL face is skipped (stays black) like a face that
  * failed to load. LINEAR, CLAMP_TO_EDGE, not seamless.
- * gen_mipmap must be 0 (the reference's default, what main.cpp:137-147 passes): with genMipmap = true the reference builds cube mips and
- * filters the sky trilinearly (GLWrapper.cpp:307-310), which this library does not do -- gen_mipmap != 0 fails with RTX_ERR_INVALID and a
- * message instead of rendering a different sky silently. On any failure *handle is 0. */
+ * gen_mipmap = 0 is the reference's default (what main.cpp:137-147 passes): the sky is sampled at level 0. gen_mipmap != 0 is
+ * load_cubemap(faces, true) (GLWrapper.cpp:307-310: glGenerateMipmap(GL_TEXTURE_CUBE_MAP), GL_LINEAR_MIPMAP_LINEAR): every face gets a mip
+ * chain (the 2-D textures' rounded integer mean) and texture(skybox, rd) (rt.frag:893) is trilinear, its level of detail from the 2x2
+ * quad's direction differences projected on the pixel's own face (cube part); needs RTX_OPT_TEXTURE_LOD = 1 (the
+ * default; with 0 level 0 is sampled, as for the 2-D textures) and is not available together with RTX_OPT_SCENE_IN_LDS = 1 (rtx_draw
+ * fails with RTX_ERR_INVALID). On any failure *handle is 0. */
 RTX_API int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels,
                                const uint8_t* const faces[6], int gen_mipmap, uint32_t* handle);
 /* shader.setInt(uniformName, unit)  [GLWrapper.cpp:138,360]: sampler names skybox,

@@ -32,7 +32,7 @@ class Texture(ctypes.Structure):
 
 
 class Cubemap(ctypes.Structure):
-    _fields_ = [("face_size", ctypes.c_int32), ("channels", ctypes.c_int32), ("faces", ctypes.c_void_p * 6)]
+    _fields_ = [("face_size", ctypes.c_int32), ("channels", ctypes.c_int32), ("faces", ctypes.c_void_p * 6), ("gen_mipmap", ctypes.c_int32)]
 
 
 class Frame(ctypes.Structure):
@@ -90,15 +90,16 @@ def lib():
     return _lib
 
 
-TAG_BOX_INSIDE, TAG_REFRACT, TAG_TORUS, TAG_TEXTURE, TAG_BOX_NAN, TAG_TIR, TAG_QUAD_DIVERGENT = 1, 2, 4, 8, 16, 32, 64   # ORC_TAG_* of rt_oracle.c
+TAG_BOX_INSIDE, TAG_REFRACT, TAG_TORUS, TAG_TEXTURE, TAG_BOX_NAN, TAG_TIR, TAG_QUAD_DIVERGENT, TAG_SKY_LOD = 1, 2, 4, 8, 16, 32, 64, 128   # ORC_TAG_* of rt_oracle.c
 
 
 class OracleScene:
     """Holds one frame description (blocks + textures) alive for orc_render calls."""
 
-    def __init__(self, scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, texture_lod: int = 1):
+    def __init__(self, scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, texture_lod: int = 1, cube_mipmap: bool = False):
         """scene_blocks: object with .defines (15-tuple) and .blocks (name -> bytes);
-        textures: iterable of (sampler_uniform_name, unit, HxWxC uint8 array); cubemap: six NxNxC uint8 arrays."""
+        textures: iterable of (sampler_uniform_name, unit, HxWxC uint8 array); cubemap: six NxNxC uint8 arrays;
+        cube_mipmap: GLWrapper::load_cubemap(faces, genMipmap = true) (GLWrapper.cpp:307-310)."""
         self._keep = []
         fr = Frame()
         fr.fb_width, fr.fb_height = fb_width, fb_height
@@ -127,6 +128,7 @@ class OracleScene:
             fr.skybox.channels = first.shape[2]
             for i, f in enumerate(faces):
                 fr.skybox.faces[i] = None if f is None else f.ctypes.data
+            fr.skybox.gen_mipmap = 1 if cube_mipmap else 0
         fr.texture_lod = texture_lod
         self.frame = fr
         self.width, self.height = fb_width, fb_height

@@ -70,6 +70,7 @@ typedef struct {
 typedef struct {
     int32_t face_size, channels;
     const uint8_t* faces[6]; /* +X,-X,+Y,-Y,+Z,-Z; NULL face = black */
+    int32_t gen_mipmap;      /* load_cubemap(faces, genMipmap): != 0 -> glGenerateMipmap + GL_LINEAR_MIPMAP_LINEAR (GLWrapper.cpp:307-310) */
 } orc_cubemap;
 
 enum { ORC_TEX_SPHERE_1 = 0, ORC_TEX_SPHERE_2, ORC_TEX_SPHERE_3, ORC_TEX_SPHERE_4, ORC_TEX_RING, ORC_TEX_BOX, ORC_TEX_COUNT };
@@ -206,6 +207,7 @@ enum { ORC_TAG_BOX_INSIDE = 1,   /* intersectBox returned a negative distance (t
        ORC_TAG_TEXTURE = 8,      /* a 2-D texture was sampled (mip level selection, atan/asin uv) */
        ORC_TAG_BOX_NAN = 16,     /* NaN through intersectBox (trap T5) */
        ORC_TAG_TIR = 32,
+       ORC_TAG_SKY_LOD = 128,    /* the sky was fetched from a mip-mapped cube map (load_cubemap(faces, true)): level selection as for ORC_TAG_TEXTURE */
        ORC_TAG_QUAD_DIVERGENT = 64 };   /* a mip-mapped fetch for which a 2x2-quad neighbour did not execute the same fetch: GLSL leaves
                                           derivatives undefined in non-uniform control flow (GLSL 4.50 section 8.13.1); the oracle's rule
                                           takes that derivative as 0, llvmpipe differences whatever its masked-off lanes hold */
@@ -382,16 +384,33 @@ static vec4 sample2d_level0(const orc_texture* t, vec2 uv)
     return bilerp(texel_rgba(t->texels, t->channels, t->width, i0, j0), texel_rgba(t->texels, t->channels, t->width, i1, j0),
                   texel_rgba(t->texels, t->channels, t->width, i0, j1), texel_rgba(t->texels, t->channels, t->width, i1, j1), a, b);
 }
-/* texture(skybox, dir): GL cube face selection table (OpenGL 3.3 spec table 3.19), per-face
- * bilinear with CLAMP_TO_EDGE, not seamless (GLWrapper.cpp:310-314). */
-static vec4 sample_cube(const orc_cubemap* c, vec3 d)
+/* GL cube face selection table (OpenGL 3.3 spec table 3.19; ties x >= y >= z). */
+static int cube_face(vec3 d)
 {
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int face;
-    float sc, tc, ma;
-    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
-    else if (ay >= az)        { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; }  else { face = 3; sc = d.x; tc = -d.z; } }
-    else                      { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    if (ax >= ay && ax >= az) return d.x >= 0.0f ? 0 : 1;
+    if (ay >= az) return d.y >= 0.0f ? 2 : 3;
+    return d.z >= 0.0f ? 4 : 5;
+}
+/* (sc, tc, ma) of table 3.19 for a FIXED face as a linear map of the vector: applied to the direction it yields the face coordinates
+ * and |major axis| (ma >= 0 on the direction's own face), applied to a derivative of the direction it yields their derivatives. */
+static vec3 cube_project(int face, vec3 v)
+{
+    switch (face) {
+    case 0: return v3(-v.z, -v.y, v.x);
+    case 1: return v3(v.z, -v.y, -v.x);
+    case 2: return v3(v.x, v.z, v.y);
+    case 3: return v3(v.x, -v.z, -v.y);
+    case 4: return v3(v.x, -v.y, v.z);
+    default: return v3(-v.x, -v.y, -v.z);
+    }
+}
+/* texture(skybox, dir) at level 0: per-face bilinear with CLAMP_TO_EDGE, not seamless (GLWrapper.cpp:310-314). */
+static vec4 sample_cube(const orc_cubemap* c, vec3 d)
+{
+    const int face = cube_face(d);
+    const vec3 p = cube_project(face, d);
+    const float sc = p.x, tc = p.y, ma = p.z;
     if (c->face_size <= 0 || !c->faces[face]) return v4(0.0f, 0.0f, 0.0f, 1.0f);
     float s = 0.5f * (sc / ma + 1.0f);
     float t = 0.5f * (tc / ma + 1.0f);
@@ -426,8 +445,10 @@ typedef struct {
     int levels; int w[ORC_MAX_MIPS], h[ORC_MAX_MIPS];
     uint8_t* data[ORC_MAX_MIPS]; /* RGBA8 */
 } orc_mipchain;
-static orc_mipchain g_mips[16];
+#define ORC_MIP_CACHE 48
+static orc_mipchain g_mips[ORC_MIP_CACHE];
 static int g_mips_n = 0;
+static int g_mips_built = 0; /* chains built so far (orc_render repeats its serial pre-pass until a pass builds none) */
 
 static uint64_t fnv1a(const uint8_t* p, size_t n)
 {
@@ -457,11 +478,12 @@ static const orc_mipchain* mip_get(const orc_texture* t)
     if (t->width <= 0 || !t->texels) return NULL;
     const orc_mipchain* hit = mip_lookup(t, 0);
     if (hit) return hit;
-    if (g_mips_n == 16) { /* recycle the oldest */
+    if (g_mips_n == ORC_MIP_CACHE) { /* recycle the oldest */
         for (int l = 0; l < g_mips[0].levels; l++) free(g_mips[0].data[l]);
-        memmove(&g_mips[0], &g_mips[1], 15 * sizeof g_mips[0]);
-        g_mips_n = 15;
+        memmove(&g_mips[0], &g_mips[1], (ORC_MIP_CACHE - 1) * sizeof g_mips[0]);
+        g_mips_n = ORC_MIP_CACHE - 1;
     }
+    g_mips_built++;
     orc_mipchain* m = &g_mips[g_mips_n++];
     memset(m, 0, sizeof *m);
     m->key_texels = t->texels; m->key_w = t->width; m->key_h = t->height; m->key_c = t->channels;
@@ -553,9 +575,48 @@ static float orc_log2(float xf)
     return (float)((double)e + ln_m * 1.4426950408889634074);
 }
 
+/* Cube mips (load_cubemap(faces, true), GLWrapper.cpp:307-310 -> the sky fetch rt.frag:893 is min-filtered GL_LINEAR_MIPMAP_LINEAR).
+ * Rule (DESIGN.md "Texture rule", cube part): every face has the mip chain of a 2-D RGBA8 image of its own (same rounded integer mean);
+ * the level of detail comes from the derivatives of the FACE coordinates s = (sc/ma + 1)/2, t = (tc/ma + 1)/2 of the pixel's OWN face,
+ * obtained from the quad differences of the direction by the quotient rule, d(sc/ma) = (dsc * ma - sc * dma) / ma^2 -- a neighbour that
+ * looks at another face still contributes through its direction (this is also how Mesa llvmpipe does it);
+ * lambda = log2(size * max(|(ds/dx, dt/dx)|, |(ds/dy, dt/dy)|)); levels floor(lambda), +1 blended like the 2-D ones. */
+static float cube_lambda(const orc_cubemap* c, vec3 d, vec3 ddx, vec3 ddy, int mesa_log2)
+{
+    const int face = cube_face(d);
+    const vec3 p = cube_project(face, d), px = cube_project(face, ddx), py = cube_project(face, ddy);
+    const float ma = p.z, ma2 = ma * ma;
+    const float dsdx = 0.5f * ((px.x * ma - p.x * px.z) / ma2), dtdx = 0.5f * ((px.y * ma - p.y * px.z) / ma2);
+    const float dsdy = 0.5f * ((py.x * ma - p.x * py.z) / ma2), dtdy = 0.5f * ((py.y * ma - p.y * py.z) / ma2);
+    const float n = (float)c->face_size;
+    const float rx = sqrtf((dsdx * n) * (dsdx * n) + (dtdx * n) * (dtdx * n));
+    const float ry = sqrtf((dsdy * n) * (dsdy * n) + (dtdy * n) * (dtdy * n));
+    if (mesa_log2) { /* texture_lod == 2, diagnostic: llvmpipe's 0.5 * L(rho^2), see quad_resolve */
+        const float r2 = gl_max(rx * rx, ry * ry);
+        int e;
+        const float m = frexpf(r2, &e);
+        return r2 > 0.0f ? 0.5f * ((float)(e - 1) + (2.0f * m - 1.0f)) : -1000.0f;
+    }
+    return orc_log2(gl_max(rx, ry));
+}
+static vec4 sample_cube_lod(const orc_cubemap* c, vec3 d, float lambda)
+{
+    const int face = cube_face(d);
+    const vec3 p = cube_project(face, d);
+    if (c->face_size <= 0 || !c->faces[face]) return v4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float s = 0.5f * (p.x / p.z + 1.0f);
+    const float t = 0.5f * (p.y / p.z + 1.0f);
+    orc_texture ft;
+    ft.width = ft.height = c->face_size;
+    ft.channels = c->channels;
+    ft.wrap = 1;
+    ft.texels = c->faces[face];
+    return sample2d_lod(&ft, v2(s, t), lambda);
+}
+
 /* ---- 2x2 quad lock-step machinery ---- */
-enum { SITE_HIT = 0, SITE_SHADOW = 1 };
-enum { LOD_EXPLICIT_SPHERE = 0, LOD_IMPLICIT = 1 };
+enum { SITE_HIT = 0, SITE_SHADOW = 1, SITE_SKY = 2 };
+enum { LOD_EXPLICIT_SPHERE = 0, LOD_IMPLICIT = 1, LOD_CUBE = 2 };
 typedef struct { int step, site, a, b, slot, ptype, pnum; } fetch_key;
 typedef struct {
     int active;      /* pixel exists in this quad (inside the even-rounded framebuffer) */
@@ -563,6 +624,7 @@ typedef struct {
     int waiting;
     fetch_key key;
     vec2 uv;
+    vec3 dir;        /* LOD_CUBE: the fetch direction (uv unused) */
     int mode;
     vec4 result;
     ucontext_t ctx;
@@ -599,6 +661,22 @@ static vec4 tex_fetch(inv_t* iv, int slot, int site, int a, int b, int ptype, in
     return me->result;
 }
 
+/* texture(skybox, rd), rt.frag:893 */
+static vec4 sky_fetch(inv_t* iv, vec3 rd)
+{
+    const orc_cubemap* c = &iv->fr->skybox;
+    if (!iv->quad || !c->gen_mipmap) return sample_cube(c, rd); /* no cube mips (the reference's default) or texture_lod == 0 */
+    iv->tag |= ORC_TAG_SKY_LOD | ORC_TAG_TEXTURE;
+    quad_t* q = iv->quad;
+    quad_lane* me = &q->lane[iv->quad_slot];
+    me->key.step = iv->step; me->key.site = SITE_SKY; me->key.a = 0; me->key.b = 0; me->key.slot = ORC_TEX_COUNT; me->key.ptype = 0; me->key.pnum = 0;
+    me->dir = rd;
+    me->mode = LOD_CUBE;
+    me->waiting = 1;
+    swapcontext(&me->ctx, &q->sched);
+    return me->result;
+}
+
 static void quad_resolve(quad_t* q, const orc_frame* fr)
 {
     /* smallest pending key */
@@ -616,6 +694,18 @@ static void quad_resolve(quad_t* q, const orc_frame* fr)
         if (in_set[kx]) { const quad_lane* r = &q->lane[k | 1]; const quad_lane* l = &q->lane[k & ~1]; ddx = v2(r->uv.x - l->uv.x, r->uv.y - l->uv.y); }
         if (in_set[ky]) { const quad_lane* tp = &q->lane[k | 2]; const quad_lane* bt = &q->lane[k & ~2]; ddy = v2(tp->uv.x - bt->uv.x, tp->uv.y - bt->uv.y); }
         if (!in_set[kx] || !in_set[ky]) q->lane[k].iv.tag |= ORC_TAG_QUAD_DIVERGENT;
+        if (q->lane[k].mode == LOD_CUBE) {
+            vec3 dx = v3(0.0f, 0.0f, 0.0f), dy = dx;
+            if (in_set[kx]) dx = sub3(q->lane[k | 1].dir, q->lane[k & ~1].dir);
+            if (in_set[ky]) dy = sub3(q->lane[k | 2].dir, q->lane[k & ~2].dir);
+            float lambda = cube_lambda(&fr->skybox, q->lane[k].dir, dx, dy, fr->texture_lod == 2);
+            if (g_lod_bias != 0.0f) lambda += g_lod_bias;
+            if (g_lod_force >= 0.0f) lambda = g_lod_force;
+            for (int f = 0; f < 2; f++)
+                if (g_lod_force2_level[f] >= 0.0f && key.slot == g_lod_force2_slot[f] && key.site == g_lod_force2_site[f]) lambda = g_lod_force2_level[f];
+            res[k] = sample_cube_lod(&fr->skybox, q->lane[k].dir, lambda);
+            continue;
+        }
         const orc_texture* t = &fr->tex[key.slot];
         float lambda;
         if (q->lane[k].mode == LOD_EXPLICIT_SPHERE) {
@@ -1222,7 +1312,7 @@ static vec4 shade_pixel(inv_t* iv) /* main(), :804-902 */
                 }
             }
         } else {
-            vec4 sky = sample_cube(&iv->fr->skybox, rd);
+            vec4 sky = sky_fetch(iv, rd);
             color = add3(color, mul3(v3(sky.x, sky.y, sky.z), mask));
             break;
         }
@@ -1346,11 +1436,23 @@ int orc_render(const orc_frame* fr, int y0, int y1, float* out_rgba, orc_counter
     memset(&total, 0, sizeof total);
     if (y0 < 0) y0 = 0;
     if (y1 > fr->fb_height) y1 = fr->fb_height;
-    if (fr->texture_lod)
-        for (int k = 0; k < ORC_TEX_COUNT; k++) { /* (re)build mip chains before the parallel region */
-            (void)mip_lookup(&fr->tex[k], 1);     /* drops a stale chain whose address was reused for other texels */
+    /* (re)build the mip chains before the parallel region (mip_get is not thread-safe when it builds); repeated until a pass builds
+     * nothing, so that a chain recycled while a later one was built is back before the threads start */
+    for (int pass = 0, built = -1; fr->texture_lod && built != g_mips_built && pass < 8; pass++) {
+        built = g_mips_built;
+        for (int k = 0; k < ORC_TEX_COUNT; k++) {
+            (void)mip_lookup(&fr->tex[k], pass == 0); /* drops a stale chain whose address was reused for other texels */
             (void)mip_get(&fr->tex[k]);
         }
+        if (fr->skybox.gen_mipmap && fr->skybox.face_size > 0)
+            for (int f = 0; f < 6; f++) {
+                if (!fr->skybox.faces[f]) continue;
+                orc_texture ft;
+                ft.width = ft.height = fr->skybox.face_size; ft.channels = fr->skybox.channels; ft.wrap = 1; ft.texels = fr->skybox.faces[f];
+                (void)mip_lookup(&ft, pass == 0);
+                (void)mip_get(&ft);
+            }
+    }
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     else omp_set_num_threads(omp_get_num_procs());

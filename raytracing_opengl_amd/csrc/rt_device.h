@@ -453,6 +453,83 @@ RT_HD f4 sample_cube(const DevCubemap& c, f3 d)
     return bilinear_taps(c.texels, (uint32_t)face * (uint32_t)c.size * (uint32_t)c.size, c.size, i0, i1, j0, j1, a, b);
 }
 
+// ---- mip-mapped sky box: GLWrapper::load_cubemap(faces, genMipmap = true), GLWrapper.cpp:307-310 -> texture(skybox, rd) (rt.frag:893)
+// is min-filtered GL_LINEAR_MIPMAP_LINEAR. Rule (DESIGN.md "Texture rule", cube part; oracle: cube_lambda / sample_cube_lod): the level of
+// detail comes from the derivatives of the face coordinates s = (sc/ma + 1)/2, t = (tc/ma + 1)/2 on the pixel's OWN face, obtained from
+// the quad differences of the DIRECTION by the quotient rule d(sc/ma) = (dsc * ma - sc * dma) / ma^2.
+RT_HD int cube_face(f3 d)
+{
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    if (ax >= ay && ax >= az) return d.x >= 0.0f ? 0 : 1;
+    if (ay >= az) return d.y >= 0.0f ? 2 : 3;
+    return d.z >= 0.0f ? 4 : 5;
+}
+// (sc, tc, ma) of the GL face table for a FIXED face: a linear map, applied to the direction and to its derivatives alike
+RT_HD f3 cube_project(int face, f3 v)
+{
+    const int axis = face >> 1;
+    const bool neg = (face & 1) != 0;
+    const float m = axis == 0 ? v.x : (axis == 1 ? v.y : v.z);
+    const float sc = axis == 0 ? (neg ? v.z : -v.z) : (axis == 1 ? v.x : (neg ? -v.x : v.x));
+    const float tc = axis == 1 ? (neg ? -v.z : v.z) : -v.y;
+    return mk3(sc, tc, neg ? -m : m);
+}
+RT_HD float cube_lambda(const DevCubemap& c, f3 d, f3 ddx, f3 ddy)
+{
+    const int face = cube_face(d);
+    const f3 p = cube_project(face, d), px = cube_project(face, ddx), py = cube_project(face, ddy);
+    const float ma = p.z, ma2 = ma * ma;
+    const float dsdx = 0.5f * ((px.x * ma - p.x * px.z) / ma2), dtdx = 0.5f * ((px.y * ma - p.y * px.z) / ma2);
+    const float dsdy = 0.5f * ((py.x * ma - p.x * py.z) / ma2), dtdy = 0.5f * ((py.y * ma - p.y * py.z) / ma2);
+    const float n = c.fsize;
+    const float rx = sqrtf((dsdx * n) * (dsdx * n) + (dtdx * n) * (dtdx * n));
+    const float ry = sqrtf((dsdy * n) * (dsdy * n) + (dtdy * n) * (dtdy * n));
+    return rt_log2(gl_max(rx, ry));
+}
+// lambda as in sample2d_lod; level L of the cube: 6 faces of max(1, size>>L)^2 texels behind the levels before it
+RT_COLD f4 sample_cube_lod(const DevCubemap& c, f3 d, float lambda)
+{
+    const int face = cube_face(d);
+    const f3 p = cube_project(face, d);
+    if (c.texels == nullptr || !((c.face_mask >> face) & 1)) return mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float s = 0.5f * (p.x / p.z + 1.0f);
+    const float t = 0.5f * (p.y / p.z + 1.0f);
+    int l0 = 0;
+    float f = 0.0f;
+    bool two = false;
+    if (lambda > 0.0f) {
+        const float top = (float)(c.levels - 1);
+        if (lambda > top) lambda = top;
+        const float fl = floorf(lambda);
+        l0 = (int)fl;
+        f = lambda - fl;
+        two = l0 + 1 <= c.levels - 1;
+    }
+    int w = c.size;
+    uint32_t first = 0;
+    for (int l = 0; l < l0; l++) {   // dword offset of level l0 (per lane; a handful of integer operations per level)
+        first += 6u * (uint32_t)w * (uint32_t)w;
+        w = w > 1 ? w >> 1 : 1;
+    }
+    f4 c0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && !RT_ANY(two)) break;
+        if (pass == 1 && two) {
+            first += 6u * (uint32_t)w * (uint32_t)w;
+            w = w > 1 ? w >> 1 : 1;
+        }
+        int i0, i1, j0, j1;
+        float a, b;
+        axis_taps(s, w, (float)w, 1, i0, i1, a);
+        axis_taps(t, w, (float)w, 1, j0, j1, b);
+        const f4 v = bilinear_taps(c.texels, first + (uint32_t)face * (uint32_t)w * (uint32_t)w, w, i0, i1, j0, j1, a, b);
+        if (pass == 0) c0 = v; else c1 = v;
+    }
+    if (!two) return c0;
+    return mk4((1.0f - f) * c0.x + f * c1.x, (1.0f - f) * c0.y + f * c1.y, (1.0f - f) * c0.z + f * c1.z, (1.0f - f) * c0.w + f * c1.w);
+}
+
 // The single 2-D texture fetch site. Each lane may request a fetch from a different sampler slot;
 // the wave serves one slot per pass (wave-uniform slot -> the sampler state is read with scalar
 // loads at a computed address, nothing is hoisted into long-lived registers), lanes of other slots
@@ -888,12 +965,13 @@ RT_HD bool torus_hull_cull(const DevTorus& T, f3 o, f3 d)
 // set up about the interval's midpoint, where |p| is of the torus' own size whatever the origin's distance, so float evaluates it to ~1e-6 of
 // its terms; `eps` asks for 1e-4 of them. Same premise as every torus cull (measured in DESIGN.md section 3: a ray that clears the real tube by
 // more than 3.7 mm is never reported as a hit; the inflation is 10 mm + 1 %).
-RT_HD bool torus_tube_cull(const DevTorus& T, f3 o, f3 d, float t0, float t1)
+// (rp: the tube radius the quartic is set up for; eps_rel: the share of the sum of the terms' magnitudes every coefficient has to exceed)
+RT_HD bool torus_quartic_positive(const DevTorus& T, f3 o, f3 d, float t0, float t1, float rp, float eps_rel)
 {
     const float tm = 0.5f * (t0 + t1), hl = 0.5f * (t1 - t0);
     if (!(hl >= 0.0f) || !(tm < 1.0e3f)) return false;
     const f3 p = mk3(fmaf(d.x, tm, o.x), fmaf(d.y, tm, o.y), fmaf(d.z, tm, o.z));
-    const float rp = T.cull.x, k4 = T.k.x;                                  // inflated tube radius, 4 R^2
+    const float k4 = T.k.x;                                                 // 4 R^2
     const float a = dot3_fma(d, d), b = dot3_fma(p, d), c = dot3_fma(p, p) + (T.radii.z - rp * rp);
     const float axy = fmaf(d.y, d.y, d.x * d.x), bxy = fmaf(p.y, d.y, p.x * d.x), cxy = fmaf(p.y, p.y, p.x * p.x);
     // F(tm + s) = q0 + q1 s + q2 s^2 + q3 s^3 + q4 s^4; with s = hl u, u in [-1, 1]: coefficients c_k = q_k hl^k
@@ -903,7 +981,7 @@ RT_HD bool torus_tube_cull(const DevTorus& T, f3 o, f3 d, float t0, float t1)
     const float c2 = (4.0f * b * b + 2.0f * a * c - k4 * axy) * h2;
     const float c3 = (4.0f * a * b) * (h2 * hl);
     const float c4 = (a * a) * (h2 * h2);
-    const float eps = 1.0e-4f * (fabsf(c0) + fabsf(c1) + fabsf(c2) + fabsf(c3) + fabsf(c4)) + 1.0e-12f;
+    const float eps = eps_rel * (fabsf(c0) + fabsf(c1) + fabsf(c2) + fabsf(c3) + fabsf(c4)) + 1.0e-12f;
     // Bernstein coefficients over u in [-1, 1] (blossoms of the monomials at -1 / +1)
     const float b0 = c0 - c1 + c2 - c3 + c4, b4 = c0 + c1 + c2 + c3 + c4;
     const float b1 = c0 - 0.5f * c1 + 0.5f * c3 - c4, b3 = c0 + 0.5f * c1 - 0.5f * c3 - c4;
@@ -915,6 +993,40 @@ RT_HD bool torus_tube_cull(const DevTorus& T, f3 o, f3 d, float t0, float t1)
     const float l3 = 0.5f * (l2 + mm), r1 = 0.5f * (mm + r2);
     const float mid = 0.5f * (l3 + r1);
     return l1 > eps && l2 > eps && l3 > eps && mid > eps && r1 > eps && r2 > eps && r3 > eps;
+}
+// The tube test proper: the inflated tube (T.cull.x) over the ray's part inside the puck, for rays whose origin is outside the inflated tube.
+// Round 5, last session -- START: the rays that start ON a torus and inside its convex hull (the inner half of the tube: its own shadow and
+// mirror rays there; the hull cull takes the outer half). Measured on the host build (64 tori, 960 x 540, depth 6): 76 k of 282 k solves that
+// survive every other cull start inside the inflated tube of their own torus, 66 k of them report no hit -- three quarters of ALL solves
+// without a hit. Such an origin sits one hit bias (~1e-3) off the surface, inside the inflation, so the first stretch is judged against the
+// tube of radius r + RT_TORUS_HULL_MARGIN (T.cull.w; the margin the hull cull's premise was measured with: a ray that starts >= 2.5e-4 off
+// the surface and only moves away has no reported root) at a threshold of 2e-5 of the terms (F there is ~3e-4 of them; float gives 1e-6):
+//     F_(r + margin) > 0 on [0, ts],  ts = min(t1, 4 (r' - r)),    and    F_(r') > 0 on [ts, t1]  (the inflated tube, as for every other ray)
+// -- by the first the ray never comes back within the margin of the surface it left, by the second it has left the inflated tube at ts and
+// stays outside it. One evaluation per pass of a two-trip loop (the second trip only for lanes whose stretch inside the puck is longer
+// than ts), so that the code exists once.
+#ifndef RT_TORUS_START
+#define RT_TORUS_START 1        /* A/B switch: 0 = the tube test as it was before the START part (no ray that starts inside the inflated tube is culled) */
+#endif
+RT_HD bool torus_tube_cull(const DevTorus& T, f3 o, f3 d, float t0, float t1)
+{
+    const float rp = T.cull.x;
+    const float q = rt_sqrt_approx(o.x * o.x + o.y * o.y) - T.cull.z, dist2 = q * q + o.z * o.z;   // distance^2 to the centre circle
+    const bool start = dist2 < rp * rp;          // the origin is inside the inflated tube (hence inside the puck: t0 = 0)
+    if (start && (!RT_TORUS_START || !(dist2 > T.cull.y))) return false;   // closer to the surface than the margin (or a torus that is never culled: +inf)
+    const float ts = 4.0f * (rp - T.radii.y);
+    bool ok = true, more = true;
+    float ta = start ? 0.0f : t0, tb = start ? gl_min(t1, ts) : t1;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const bool first = start && pass == 0;
+        if (more) ok = ok && torus_quartic_positive(T, o, d, ta, tb, first ? T.cull.w : rp, first ? 2.0e-5f : 1.0e-4f);
+        more = more && ok && start && pass == 0 && t1 > ts;
+        if (!RT_ANY(more)) break;
+        ta = ts;
+        tb = t1;
+    }
+    return ok;
 }
 // (t0, t1: on a `false` return, the part of the ray inside the inflated puck and the reach -- what torus_tube_cull then looks at)
 RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float& t0, float& t1)
@@ -981,6 +1093,8 @@ RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
     // hits that sheet stays where the inflated quartic is positive. (The first form of this test had no such condition: the bench scenes and
     // the whole GPU suite were bit-identical, and tools/cull_audit.py counted 6.2 M culled hits in 7.9e9 culled rays -- every one on the
     // r >= R tori of tests/random_scenes.py nasty_scene.)
+    // (The START part alone in the default kernel variant, whose one torus has no tube test: 459 -> 468 us at 4K, 198 -> 206 us at 1920 x 1080 --
+    // measured and not compiled in, profiles/r05u_start_cull_ab.txt.)
     return TUBE && T.k.w > 0.0f && torus_tube_cull(T, o, d, t0, t1);
 }
 template <bool CULL, bool TUBE = true>
@@ -2162,7 +2276,9 @@ struct PathScalars {   // the four loop scalars: LDS slots PS_SCALARS.. (WIDE la
     RT_HDM void sti(const PathStore& P, int k, int v) { st(P, k, __builtin_bit_cast(float, v)); }
 };
 
-template <bool CULL, bool COUNT, bool WIDE = false, bool GROUPS = true>
+// SKYLOD: the sky box has a mip chain (load_cubemap(faces, true)) -- an instantiation of its own, so that the kernels of the reference's
+// default (genMipmap = false) are the same machine code with and without the feature in the source
+template <bool CULL, bool COUNT, bool WIDE = false, bool GROUPS = true, bool SKYLOD = false>
 RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, bool alive, float frag_x, float frag_y, LaneCounters& cnt)
 {
     PathScalars<WIDE> Q;
@@ -2300,7 +2416,21 @@ RT_HD f4 trace_pixel(const SceneView& S, const TexTable& T, const PathStore& P, 
         RT_PH_LAP(cnt, PH_CLASSIFY);
         // ---- sky fetch (wave-uniform site) ----
         if (RT_ANY(sky)) {
-            if (sky) {
+            if (SKYLOD) {
+                // mip-mapped sky box: the direction's quad differences (a neighbour counts only if it fetches the sky in this very trip,
+                // i.e. at the same lock-step index); every lane of the quad takes part in the DPP exchange, whatever it is doing
+                const int lane = rt_lane_id();
+                const int kx = quad_other_x(sky ? 1 : 0), ky = quad_other_y(sky ? 1 : 0);
+                const f3 ox = mk3(quad_other_x(rd.x), quad_other_x(rd.y), quad_other_x(rd.z));
+                const f3 oy = mk3(quad_other_y(rd.x), quad_other_y(rd.y), quad_other_y(rd.z));
+                if (sky) {
+                    f3 ddx = mk3(0.0f, 0.0f, 0.0f), ddy = ddx;
+                    if (kx) ddx = (lane & 1) != 0 ? rd - ox : ox - rd;   // right - left
+                    if (ky) ddy = (lane & 2) != 0 ? rd - oy : oy - rd;   // top - bottom
+                    const f4 c = sample_cube_lod(T.sky, rd, cube_lambda(T.sky, rd, ddx, ddy));
+                    P.st3(PS_COLOR, P.ld3(PS_COLOR) + mk3(c.x, c.y, c.z) * P.ld3(PS_MASK));
+                }
+            } else if (sky) {
                 const f4 c = sample_cube(T.sky, rd);
                 P.st3(PS_COLOR, P.ld3(PS_COLOR) + mk3(c.x, c.y, c.z) * P.ld3(PS_MASK));
             }

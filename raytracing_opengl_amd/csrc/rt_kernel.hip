@@ -99,7 +99,8 @@ __device__ __forceinline__ uint32_t pack_rgba8(f4 c)
 constexpr bool ps_wide(int wpe) { return wpe <= 6; }   // 6 workgroups x 24 KB fit the CU's 160 KB of LDS, 7 do not
 
 // HEAVY: the many-primitive variant -- its own register budget and the candidate tables of rt_device.h (group culls, ray pencils, slabs)
-template <bool CULL, bool COUNT, bool LDS, int WPE, bool HEAVY = false>
+// SKYLOD: the mip-mapped sky box (GLWrapper::load_cubemap(faces, true)); instantiated for the scalar-load variants only
+template <bool CULL, bool COUNT, bool LDS, int WPE, bool HEAVY = false, bool SKYLOD = false>
 __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256, WPE) void rt_trace_kernel(const RtLaunchParams
     path.base = path_lds + threadIdx.x;
     path.fence_slot = p.ps_fence_slot;
 #endif
-    const f4 px = trace_pixel<CULL, COUNT, WIDE, HEAVY>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);   // group culls: the many-primitive variant only
+    const f4 px = trace_pixel<CULL, COUNT, WIDE, HEAVY, SKYLOD>(S, p.tex, path, alive, (float)x + 0.5f, (float)y + 0.5f, cnt);   // group culls: the many-primitive variant only
 
     // The pixel's coordinates are needed again only here. They are RE-DERIVED from the thread index
     // (laundered through an empty asm so the compiler cannot keep the first copy alive) instead of
@@ -283,20 +284,20 @@ __global__ void rt_selftest_kernel(int* result)
 
 }  // namespace
 
-template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU, bool HEAVY = false>
+template <bool CULL, bool COUNT, bool LDS, int WPE = RT_WAVES_PER_EU, bool HEAVY = false, bool SKYLOD = false>
 static hipError_t launch_variant(const RtLaunchParams& p_in, dim3 grid, size_t shmem, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     RtLaunchParams p = p_in;
     p.ps_fence_slot = rtdev::path_slots(ps_wide(WPE));   // the pad column behind this variant's path-state slots
     if (LDS && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY, SKYLOD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
     // With events: the launch's own begin / end timestamps land in them (hipExtLaunchKernel) -- no marker packets in front of and behind the
     // kernel, which cost the queue ~2.5 us each and keep consecutive launches from overlapping their ramp-down and ramp-up.
-    if (ev_start && ev_stop) hipExtLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>), grid, dim3(256), (uint32_t)shmem, stream, ev_start, ev_stop, 0, p);
-    else hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY>), grid, dim3(256), shmem, stream, p);
+    if (ev_start && ev_stop) hipExtLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY, SKYLOD>), grid, dim3(256), (uint32_t)shmem, stream, ev_start, ev_stop, 0, p);
+    else hipLaunchKernelGGL((rt_trace_kernel<CULL, COUNT, LDS, WPE, HEAVY, SKYLOD>), grid, dim3(256), shmem, stream, p);
     return hipGetLastError();
 }
 
@@ -319,6 +320,16 @@ hipError_t rt_launch_trace(const RtLaunchParams& p_in, bool cull, bool count, bo
     }
     const size_t shmem = lds ? (size_t)((p.scene_bytes + 15) & ~15) : 0;
     const int sel = (cull ? 4 : 0) | (count ? 2 : 0) | (lds ? 1 : 0);
+    if (p.tex.lod && p.tex.sky.levels > 1) {   // mip-mapped sky box: the SKYLOD instantiations (not built for the LDS-staged experiment)
+        if (lds) return hipErrorNotSupported;
+        if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY, true, true>(p, grid, shmem, stream, ev_start, ev_stop);
+        switch (sel) {
+            case 0: return launch_variant<false, false, false, RT_WAVES_PER_EU, false, true>(p, grid, shmem, stream, ev_start, ev_stop);
+            case 2: return launch_variant<false, true, false, RT_WAVES_PER_EU, false, true>(p, grid, shmem, stream, ev_start, ev_stop);
+            case 4: return launch_variant<true, false, false, RT_WAVES_PER_EU, false, true>(p, grid, shmem, stream, ev_start, ev_stop);
+            default: return launch_variant<true, true, false, RT_WAVES_PER_EU, false, true>(p, grid, shmem, stream, ev_start, ev_stop);
+        }
+    }
     if (high_occupancy && sel == 4) return launch_variant<true, false, false, RT_WPE_HEAVY, true>(p, grid, shmem, stream, ev_start, ev_stop);  // the product path only
     switch (sel) {
         case 0: return launch_variant<false, false, false>(p, grid, shmem, stream, ev_start, ev_stop);

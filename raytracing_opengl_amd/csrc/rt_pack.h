@@ -573,7 +573,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         s.qinv = quat_inv(s.quat);
         // y, z: the convex-hull cull of torus_local_cull -- (|r| + margin)^2 and |R|
         const double hull = std::fabs(static_cast<double>(r)) + RT_TORUS_HULL_MARGIN;
-        s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), static_cast<float>(hull * hull), std::fabs(R), 0.0f);
+        s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), static_cast<float>(hull * hull), std::fabs(R), static_cast<float>(hull));
         // The culls rest on "a geometric miss makes Durand-Kerner report no root". That holds for tori with a real tube
         // (validated on random rays), but not for degenerate ones: with tube radius 0 the solver, out of sweeps, can stop
         // on an iterate whose imaginary part happens to be below 1e-3 far away from the (zero-thickness) torus -- found by

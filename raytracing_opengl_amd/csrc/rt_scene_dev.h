@@ -80,7 +80,7 @@ struct alignas(16) DevTorus {
     f4 radii;          // R, r, R*R, r*r
     f4 k;              // x = 4*R*R, y = world cull-sphere radius^2, z = puck radius^2 ((R+r) inflated), w = hole radius^2 ((R-r) deflated, 0 = none)
     f4 qinv;
-    f4 cull;           // x = puck half height (r inflated), y = (r + RT_TORUS_HULL_MARGIN)^2, z = |R| (convex-hull cull), w unused
+    f4 cull;           // x = puck half height (r inflated), y = (r + RT_TORUS_HULL_MARGIN)^2, z = |R| (convex-hull cull), w = r + RT_TORUS_HULL_MARGIN (start cull)
 };
 struct alignas(16) DevRing {
     f4 quat;
@@ -189,10 +189,12 @@ struct DevTexture {
     uint32_t level_off[MAX_MIPS];  // dword offset of each mip level
 };
 struct DevCubemap {
-    const uint32_t* texels;  // 6 faces back to back (+X,-X,+Y,-Y,+Z,-Z), each size*size dwords
+    const uint32_t* texels;  // level 0: 6 faces back to back (+X,-X,+Y,-Y,+Z,-Z), each size*size dwords; level L (load_cubemap(faces, true))
+                             // follows level L-1: 6 faces of max(1, size>>L)^2 dwords each
     int32_t size;
     int32_t face_mask;       // bit f set = face present (a missing face samples black)
     float fsize;             // (float)size
+    int32_t levels;          // 1 = no mip chain (the reference's default genMipmap = false, or RTX_OPT_TEXTURE_LOD = 0)
 };
 
 }  // namespace rtdev

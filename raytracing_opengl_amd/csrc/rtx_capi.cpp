@@ -300,6 +300,7 @@ void fill_tex_table(rtx_context* ctx, TexTable& T)
             T.sky.size = it->second.width;
             T.sky.fsize = static_cast<float>(it->second.width);
             T.sky.face_mask = it->second.face_mask;
+            T.sky.levels = ctx->opt_lod ? it->second.levels : 1;   // RTX_OPT_TEXTURE_LOD = 0: level 0 everywhere, as for the 2-D textures
         }
     }
 }
@@ -399,6 +400,9 @@ int draw_impl(rtx_context* ctx, int band_rows, int band_first, int band_stride, 
     p.counters = ctx->d_counters;
     p.pencil_masks = ctx->opt_pencils && ctx->n_pencil > 0 ? ctx->d_pencil : nullptr;
     fill_tex_table(ctx, p.tex);
+    if (ctx->opt_lds && p.tex.lod && p.tex.sky.levels > 1)
+        return fail(RTX_ERR_INVALID, "RTX_OPT_SCENE_IN_LDS = 1 is not built for a mip-mapped sky box (rtx_cubemap_create with gen_mipmap = 1): the kernels that sample "
+                                     "cube mips exist for the scalar-load scene tables only");
     if (ctx->opt_count) HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), stream));
     if (ctx->ev_pending == EVENT_RING) {  // ring full: retire the oldest pair only (recorded EVENT_RING launches ago, long finished)
         const int idx = (ctx->ev_head - ctx->ev_pending + EVENT_RING * 2) % EVENT_RING;
@@ -1347,13 +1351,6 @@ int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint
 {
     if (!ctx || !handle || !faces) return fail(RTX_ERR_INVALID, "rtx_cubemap_create: null argument");
     *handle = 0;
-    // load_cubemap(faces, genMipmap = true) makes the reference generate cube mips and min-filter the sky trilinearly
-    // (GLWrapper.cpp:307-310), which changes what texture(skybox, rd) (rt.frag:893) returns. This library samples level 0 only. Accepting the
-    // flag and ignoring it (rounds 1-3) was a silent difference from the reference; it is refused instead. (The reference's own program passes
-    // the default, false: main.cpp:137-147. The call sits in non-uniform control flow, where GLSL leaves implicit derivatives undefined.)
-    if (gen_mipmap)
-        return fail(RTX_ERR_INVALID, "rtx_cubemap_create: gen_mipmap = 1 (GLWrapper::load_cubemap(faces, true): cube mips + trilinear sky) is not supported -- "
-                                     "the sky is sampled at level 0, as with the reference's default genMipmap = false");
     int st = use_device(ctx);
     if (st) return st;
     Texture t;
@@ -1368,6 +1365,21 @@ int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint
         std::vector<uint32_t> host(fsz * 6, 0u);
         for (int f = 0; f < 6; f++)
             if (faces[f]) { rtpack::to_rgba8(faces[f], face_size, face_size, channels, host.data() + fsz * f); t.face_mask |= 1 << f; }
+        if (gen_mipmap) {
+            // load_cubemap(faces, genMipmap = true): glGenerateMipmap(GL_TEXTURE_CUBE_MAP) + GL_LINEAR_MIPMAP_LINEAR (GLWrapper.cpp:307-310), so
+            // texture(skybox, rd) (rt.frag:893) is trilinear. Every face gets the chain of a 2-D image of its own (the same rounded integer
+            // mean); device layout: level L = 6 faces of max(1, size>>L)^2 dwords, behind level L-1 (rt_scene_dev.h DevCubemap)
+            std::vector<uint32_t> chain[6];
+            uint32_t off[MAX_MIPS] = {0};
+            for (int f = 0; f < 6; f++) {
+                chain[f].assign(host.begin() + static_cast<std::ptrdiff_t>(fsz * f), host.begin() + static_cast<std::ptrdiff_t>(fsz * (f + 1)));
+                t.levels = rtpack::build_mip_chain(chain[f], face_size, face_size, off, MAX_MIPS);
+            }
+            for (int l = 1; l < t.levels; l++) {
+                const size_t n = (l + 1 < t.levels ? off[l + 1] : chain[0].size()) - off[l];
+                for (int f = 0; f < 6; f++) host.insert(host.end(), chain[f].begin() + off[l], chain[f].begin() + off[l] + static_cast<std::ptrdiff_t>(n));
+            }
+        }
         t.dwords = host.size();
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_texels), t.dwords * 4));
         HIP_TRY(hipMemcpy(t.d_texels, host.data(), t.dwords * 4, hipMemcpyHostToDevice));
@@ -1375,7 +1387,7 @@ int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint
     const uint32_t h = ctx->next_handle++;
     ctx->textures[h] = t;
     *handle = h;
-    RTX_FORWARD_TEXTURE(rtx_cubemap_create(ctx, face_size, channels, faces, 0, handle));
+    RTX_FORWARD_TEXTURE(rtx_cubemap_create(ctx, face_size, channels, faces, gen_mipmap, handle));
     return RTX_OK;
 }
 

@@ -98,11 +98,15 @@ def crate(seed: int, w: int, h: int, smooth: bool = False) -> np.ndarray:
     return _to_u8(img)
 
 
-def nebula_face(seed: int, n: int) -> np.ndarray:
-    """RGB8 sky face: dim coloured clouds plus sparse stars."""
+def nebula_face(seed: int, n: int, smooth: bool = False) -> np.ndarray:
+    """RGB8 sky face: dim coloured clouds plus sparse stars. smooth: band-limited (brighter clouds of the coarse noise only, no stars), for
+    the fixtures that pin mip-mapped sky fetches (load_cubemap(faces, true)) without an implementation's level choice mattering much."""
     rng = np.random.default_rng(seed)
     c1 = _upsampled_noise(rng, n, n, max(1, n // 6))
-    c2 = _upsampled_noise(rng, n, n, max(1, n // 24))
+    c2 = _upsampled_noise(rng, n, n, max(1, n // (10 if smooth else 24)))
+    if smooth:
+        cloud = np.clip(0.8 * c1 + 0.5 * c2 - 0.3, 0, 1)
+        return _to_u8(np.stack([0.75 * cloud + 0.05, 0.5 * cloud * c2 + 0.1, 0.8 * cloud * c1 + 0.1], axis=-1))
     cloud = np.clip(0.9 * c1 + 0.4 * c2 - 0.7, 0, 1)
     img = np.stack([0.55 * cloud + 0.02, 0.25 * cloud * c2 + 0.02, 0.7 * cloud * c1 + 0.04], axis=-1)
     stars = rng.random((n, n), dtype=np.float32) > 0.9993
@@ -110,7 +114,7 @@ def nebula_face(seed: int, n: int) -> np.ndarray:
     return _to_u8(img)
 
 
-def default_texture_set(scale: int = 1, seed: int = 2024, smooth: bool = False) -> dict:
+def default_texture_set(scale: int = 1, seed: int = 2024, smooth: bool = False, smooth_sky: bool = False) -> dict:
     """Returns {'textures': [(uniform, unit, array HxWxC uint8)], 'cubemap': [6 arrays NxNx3 uint8]}. smooth: the band-limited variants of
     the planets, the ring and the crate (see planet)."""
     s = max(1, int(scale))
@@ -127,5 +131,5 @@ def default_texture_set(scale: int = 1, seed: int = 2024, smooth: bool = False) 
         assert img.shape == (h, w, c) and img.dtype == np.uint8
         out.append((uniform, unit, img))
     n = max(4, CUBEMAP_FACE // s)
-    faces = [nebula_face(seed + 100 + f, n) for f in range(6)]
+    faces = [nebula_face(seed + 100 + f, n, smooth_sky) for f in range(6)]
     return {"textures": out, "cubemap": faces}

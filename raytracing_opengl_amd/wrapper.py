@@ -270,15 +270,15 @@ def rccl_unique_id() -> bytes:
 
 
 def make_renderer(scene_blocks, fb_width: int, fb_height: int, textures=None, cubemap=None, device: int = 0, texture_lod: int = 1, devices=None,
-                  gather: int = _capi.RTX_GATHER_RCCL, rank=None) -> GLWrapper:
+                  gather: int = _capi.RTX_GATHER_RCCL, rank=None, cube_mipmap: bool = False) -> GLWrapper:
     """The start-up sequence of reference main.cpp:25-157 for a prepared scene: context, specialise,
-    skybox, textures, blocks."""
+    skybox, textures, blocks. cube_mipmap: load_cubemap(faces, genMipmap = true) (main.cpp:137 passes the default, false)."""
     gl = GLWrapper(fb_width, fb_height, False, device=device, devices=devices, gather=gather, rank=rank)
     if not gl.init_window():
         raise RtxError(f"init_window failed: {getattr(gl, 'last_error', '')}")
     gl.init_shaders(scene_blocks.defines)
     if cubemap is not None:
-        gl.set_skybox(gl.load_cubemap(cubemap, False))
+        gl.set_skybox(gl.load_cubemap(cubemap, bool(cube_mipmap)))
     for uniform, unit, img in (textures or ()):
         gl.load_texture(unit, img, uniform)
     up = SceneUploader(scene_blocks, gl)

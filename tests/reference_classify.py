@@ -96,7 +96,7 @@ def _build_probe(ref, texture_lod, gl_mips, threads):
     key = (id(ref["frame"]), ref.get("name"), texture_lod, gl_mips)
     if key not in _PROBES:
         oracle.OracleScene.drop_mips()      # no override left behind by another probe
-        O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod)
+        O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod, cube_mipmap=ref.get("cube_mipmap", False))
         if gl_mips:
             assert ref.get("gl_mips"), "this fixture holds no GL mip levels"
             for uniform, levels in ref["gl_mips"].items():
@@ -122,7 +122,8 @@ def _build_probe(ref, texture_lod, gl_mips, threads):
         lod_lo = lod_hi = None
         if texture_lod and (tags & oracle.TAG_TEXTURE).any():
             # every mip-mapped fetch at level 0, 1, ..., top: the bracket of whatever level an implementation took (divergent quads)
-            top = max(int(np.ceil(np.log2(max(img.shape[0], img.shape[1])))) for _u, _n, img in ref["textures"])
+            top = max([int(np.ceil(np.log2(max(img.shape[0], img.shape[1])))) for _u, _n, img in ref["textures"]]
+                      + ([int(np.ceil(np.log2(ref["cubemap"][0].shape[0])))] if ref.get("cube_mipmap") else []))
             lod_lo, lod_hi = lo.copy(), hi.copy()
             for level in range(top + 1):
                 il, _ = O.render(threads=threads, lod_force=float(level))
@@ -140,7 +141,7 @@ def _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img):
     w, h = ref["width"], ref["height"]
     top = max(int(np.ceil(np.log2(max(im.shape[0], im.shape[1])))) for _u, _n, im in ref["textures"])
     oracle.OracleScene.drop_mips()
-    O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod)
+    O = oracle.OracleScene(ref["scene"], w, h, ref["textures"], ref["cubemap"], texture_lod=texture_lod, cube_mipmap=ref.get("cube_mipmap", False))
     if gl_mips:
         for uniform, levels in ref["gl_mips"].items():
             O.set_mip_levels(uniform, levels)

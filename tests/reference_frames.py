@@ -71,6 +71,11 @@ CASES = {
     # reference's own program (main.cpp:7-8: 1280 x 720; SceneManager.cpp:233: reflect_depth 5) at animation time t = 3
     "config0_full": (lambda: scenes.build_scene("default", 640, 480, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0), True, (0.10, 0.012)),
     "app_default_full": (lambda: scenes.build_scene("default", 1280, 720, 5, time=3.0, delta=0.016), True, (0.10, 0.012)),
+    # ---- round 5: GLWrapper::load_cubemap(faces, genMipmap = true) (GLWrapper.cpp:307-310: glGenerateMipmap(GL_TEXTURE_CUBE_MAP) and
+    # GL_LINEAR_MIPMAP_LINEAR): the sky fetch rt.frag:893 is mip-mapped. Objects untextured, so the sky is the ONLY mip-mapped fetch of
+    # these frames; band-limited sky faces (textures.nebula_face(smooth=True)) hold the `texture` class at 5e-3
+    "moved_cube_mips": (lambda: _strip_textures(scenes.build_scene("default", W, H, 4, time=1.25, delta=0.016, yaw=-38.0, pitch=-14.0, cam_pos=(2.5, 1.5, -6.0))), True, (0.30, 0.016)),
+    "config0_cube_mips": (lambda: _strip_textures(scenes.build_scene("default", 320, 240, 1, time=12.5, delta=0.75, yaw=25.0, pitch=10.0)), True, (0.03, 0.002)),
     # a moved and rotated camera (SceneManager.cpp:43-50: quat(vec3(radians(-pitch), radians(yaw), 0)))
     "moved_camera": (lambda: _strip_textures(scenes.build_scene("default", W, H, 4, time=1.25, delta=0.016, yaw=-38.0, pitch=-14.0, cam_pos=(2.5, 1.5, -6.0))), False, (0.004, 0.0006)),
 }
@@ -86,7 +91,7 @@ def _fuzz(seed):
 
 for _s in FUZZ_SEEDS:
     CASES[f"fuzz_{_s}"] = ((lambda s=_s: _fuzz(s)), False, (0.02, 0.004))
-SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "config0_smooth": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180),
+SIZES = {"config0_untextured": (320, 240), "config0": (320, 240), "config0_cube_mips": (320, 240), "config0_smooth": (320, 240), "app_default_t3": (320, 180), "app_default_t7_5": (320, 180),
          "config0_full": (640, 480), "app_default_full": (1280, 720)}
 SIZES.update({f"fuzz_{_s}": FUZZ_SIZE for _s in FUZZ_SEEDS})
 
@@ -107,6 +112,7 @@ SAME_MIPS = ("default_same_mips", 0.025, 0.008)   # name, max fraction > 1e-4, >
 TEXTURED = ("default", "trap_degenerate_rings")     # pinned three ways (variants below)
 TEXTURED_PLAIN_ONLY = ("config0",)                  # textured, plain run only (with llvmpipe's generated mip levels stored)
 SMOOTH = ("default_smooth", "config0_smooth")       # textured with the band-limited set, plain run only, llvmpipe's mip levels stored
+CUBE_MIPS = ("moved_cube_mips", "config0_cube_mips")   # the sky box loaded with genMipmap = true (objects untextured, band-limited faces)
 FULL_SIZE = ("config0_full", "app_default_full")    # textured, plain run only, at the configuration's own size: the pixel-by-pixel accounting of
                                                     # these runs on the GPU box (GPU_PLAN; its host has the cores for the oracle's probes), the
                                                     # CPU suite holds the oracle to their limits only
@@ -116,8 +122,13 @@ VARIANTS = {f"{c}_{v}": (c, v) for c in TEXTURED for v in ("same_mips", "level0"
 
 
 def texture_set(name: str = ""):
-    """The texture set of a case: the band-limited one for the *_smooth cases."""
-    return textures.default_texture_set(scale=TEX_SCALE, smooth=name.endswith("_smooth"))
+    """The texture set of a case: the band-limited one for the *_smooth cases, band-limited sky faces for the *_cube_mips cases."""
+    return textures.default_texture_set(scale=TEX_SCALE, smooth=name.endswith("_smooth"), smooth_sky=cube_mipmap(name))
+
+
+def cube_mipmap(name: str) -> bool:
+    """Was the case's sky box loaded with load_cubemap(faces, genMipmap = true)?"""
+    return name.endswith("_cube_mips")
 
 
 def input_digest(sc, ts) -> str:
@@ -164,7 +175,7 @@ def load(name):
     primary = None
     if "primary_t" in z.files:
         primary = dict(t=z["primary_t"], type=z["primary_type"].astype(np.int32), num=z["primary_num"].astype(np.int32))
-    _LOADED[name] = dict(primary=primary, gl_mips=gl_mips, name=name, scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
+    _LOADED[name] = dict(cube_mipmap=cube_mipmap(name), primary=primary, gl_mips=gl_mips, name=name, scene=sc, width=int(z["width"]), height=int(z["height"]), textures=ts["textures"], cubemap=ts["cubemap"],
                          frame=z["frame"], limits=CASES[name][2] if name in CASES else SAME_MIPS[1:], renderer=str(z["renderer"]))
     return _LOADED[name]
 

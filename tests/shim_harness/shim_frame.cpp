@@ -56,7 +56,8 @@ int main(int argc, char** argv)
 
     std::vector<std::string> faces = {"textures/sky0.png", "textures/sky1.png", "textures/sky2.png",
                                       "textures/sky3.png", "textures/sky4.png", "textures/sky5.png"};
-    glWrapper.set_skybox(GLWrapper::load_cubemap(faces, false));               // main.cpp:137-147
+    // main.cpp:137-147 passes the default (false); SHIM_CUBE_MIPS=1: load_cubemap(faces, true), GLWrapper.cpp:307-310
+    glWrapper.set_skybox(GLWrapper::load_cubemap(faces, std::getenv("SHIM_CUBE_MIPS") != nullptr));
     auto jupiterTex = glWrapper.load_texture(1, "t1.jpg", "texture_sphere_1");  // main.cpp:149-153
     auto saturnTex = glWrapper.load_texture(2, "t2.jpg", "texture_sphere_2");
     auto marsTex = glWrapper.load_texture(3, "t3.jpg", "texture_sphere_3");

@@ -613,3 +613,45 @@ def test_torus_culls_never_use_the_rays_own_limit(built):
         assert harness.kat(oracle.TYPE_TORUS, rec, ro, (0.0, 0.0, 1.0), 1e6)[2], "a torus behind the origin is culled"
         if dist <= 150.0:   # (from 5 000 units out the discriminant's rounding doubt, 1e-5 |oc|^2, exceeds what the line misses the sphere by)
             assert harness.kat(oracle.TYPE_TORUS, rec, (3.0, 1.0, dist), rd, 1e6)[2], "a torus beside the ray's line is culled"
+
+
+def test_torus_start_cull_takes_the_inner_half_and_agrees_with_the_oracle(built):
+    """Round 5, last session: the START part of the tube test (rt_device.h torus_tube_cull) -- a torus' own shadow / mirror rays that start
+    on the INNER half of the tube, inside the convex hull, where the hull cull cannot help. Origins one hit bias (1e-3) off the surface of
+    the bench scenes' torus shape (R 0.9, r 0.3), directions over the outward hemisphere: every culled ray is a miss for the oracle's
+    literal rt.frag:462-487, the cull fires for most of the inner-half rays that miss, and never for an origin closer than the margin."""
+    rng = np.random.default_rng(17)
+    R, r = 0.9, 0.3
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    pos = np.array([1.5, -0.5, 2.0])
+    rec = _mat() + struct.pack("<4f", *q) + struct.pack("<3f f 2f 2f", *pos, 0, R, r, 0, 0)
+
+    def rot(v):     # torus frame -> world: conj(q) v q undoes rotate(q, .) (rt.frag:306-311)
+        x, y, z, w = -q[0], -q[1], -q[2], q[3]
+        u = np.array([x, y, z])
+        return v + 2.0 * np.cross(u, np.cross(u, v) + w * v)
+    inner = culled_inner = miss_inner = 0
+    for k in range(1500):
+        phi, th = rng.uniform(0, 2 * np.pi), rng.uniform(0.55 * np.pi, 1.45 * np.pi)        # th around pi: the side that faces the axis
+        n = np.array([np.cos(th) * np.cos(phi), np.cos(th) * np.sin(phi), np.sin(th)])
+        gap = 1e-3 if k % 10 else 1e-4                                                      # every tenth: closer than RT_TORUS_HULL_MARGIN
+        o = np.array([(R + r * np.cos(th)) * np.cos(phi), (R + r * np.cos(th)) * np.sin(phi), r * np.sin(th)]) + n * gap
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if d @ n < 0.05:
+            d = d - 2.0 * (d @ n) * n + 0.05 * n
+            d /= np.linalg.norm(d)
+        ro = tuple(float(np.float32(v)) for v in rot(o) + pos)
+        rd = tuple(float(np.float32(v)) for v in rot(d))
+        ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, ro, rd, 1e6)
+        dhit, dt, dcull = harness.kat(oracle.TYPE_TORUS, rec, ro, rd, 1e6)
+        assert dhit == ohit and (not ohit or dt == ot)                  # the literal solve is the oracle's
+        assert not (dcull and ohit), (ro, rd)                          # a culled ray is a miss
+        if gap < 2.5e-4:
+            assert not dcull, "an origin closer to the surface than the margin must reach the solver"
+        else:
+            inner += 1
+            miss_inner += not ohit
+            culled_inner += dcull
+    assert miss_inner > 300 and culled_inner > 0.8 * miss_inner, (inner, miss_inner, culled_inner)

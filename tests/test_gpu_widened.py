@@ -60,7 +60,7 @@ def _write_png(path, arr):
 JPEGS = ["pil_RGB_420_48x32_base_q90_r2", "pil_RGB_420_48x32_prog_q35_r0", "hm_rst_fill_40x24"]   # baseline, progressive, restart markers
 
 
-def _asset_dir(tmp_path):
+def _asset_dir(tmp_path, sky_scale=32):
     """textures/ with three golden JPEGs (sphere maps), a ring strip and a crate as PNGs, six sky faces as PNGs.
     Returns (dir, textures-for-the-oracle, cubemap-for-the-oracle): the oracle never sees a file, it gets the texels the
     REFERENCE's decoder produced for the JPEGs (expected.npz) and the arrays the PNGs were written from."""
@@ -78,9 +78,10 @@ def _asset_dir(tmp_path):
     _write_png(tdir / "box.png", by_uniform["texture_box"])
     tex.append(("texture_ring", 4, by_uniform["texture_ring"]))
     tex.append(("texture_box", 5, by_uniform["texture_box"]))
-    for f, face in enumerate(small["cubemap"]):
+    sky = small["cubemap"] if sky_scale == 32 else textures.default_texture_set(scale=sky_scale)["cubemap"]
+    for f, face in enumerate(sky):
         _write_png(tdir / f"sky{f}.png", face)
-    return tmp_path, tex, small["cubemap"]
+    return tmp_path, tex, sky
 
 
 def test_decoded_image_files_render_like_the_expected_texels(built, tmp_path):
@@ -125,6 +126,24 @@ def test_cpp_shim_program_renders_the_oracles_frame(built, tmp_path, w, h, kw, e
     assert np.array_equal(img8, quantise(img))
     png = _decode(str(out) + ".png")                           # top row first
     assert np.array_equal(png[::-1], img8)
+
+
+@pytest.mark.parametrize("env", [{}, {"RTX_DEVICES": "0,0,0", "RTX_GATHER": "peer"}], ids=["one_device", "three_ranks_peer_copy"])
+def test_cpp_shim_program_with_a_mip_mapped_sky_box(built, tmp_path, env):
+    """GLWrapper::load_cubemap(faces, genMipmap = true) (GLWrapper.cpp:307-310) through the C++ shim, from image files: the oracle's frame with
+    cube mips, and not the one without; with three ranks the flag reaches every rank's copy of the sky box (bands of one frame)."""
+    d, tex, cube = _asset_dir(tmp_path, sky_scale=8)          # 256-texel faces on a 160-pixel-wide frame: the sky is minified
+    w, h, depth = 160, 88, 4
+    kw = dict(time=2.0, delta=0.02, yaw=-120.0, pitch=35.0)
+    out = tmp_path / "frame"
+    subprocess.run([SHIM, str(w), str(h), str(depth), repr(kw["time"]), repr(kw["delta"]), repr(kw["yaw"]), repr(kw["pitch"]), "0", str(out)],
+                   check=True, cwd=d, timeout=300, env=dict(os.environ, SHIM_CUBE_MIPS="1", **env))
+    img = np.fromfile(str(out) + ".f32", np.float32).reshape(h, w, 4)
+    sc = scenes.build_scene("default", w, h, depth, **kw)
+    ref, _cnt = oracle.OracleScene(sc, w, h, tex, cube, cube_mipmap=True).render()
+    flat, _cnt = oracle.OracleScene(sc, w, h, tex, cube, cube_mipmap=False).render()
+    assert float(np.abs(img - ref).max()) <= TOL
+    assert float(np.abs(flat - ref).max()) > 1e-2
 
 
 def test_cpp_shim_program_with_smaa(built, tmp_path):

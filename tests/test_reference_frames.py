@@ -99,6 +99,21 @@ def test_oracle_matches_reference_shader_with_band_limited_textures(built, name,
     assert r["divergent_alpha"] <= 8, (name, r)                # the ring-alpha class stays a handful of pixels
 
 
+# Round 5: the sky box loaded the way GLWrapper::load_cubemap(faces, genMipmap = true) loads it (GLWrapper.cpp:307-310) -- cube mips and a
+# trilinear sky fetch (rt.frag:893). Objects untextured: the sky is the only mip-mapped fetch. Judged like the band-limited 2-D fixtures:
+# pixels whose quad executes the sky fetch together within 5e-3 (the rule: quotient-rule derivatives of the face coordinates, DESIGN.md
+# section 9), pixels of divergent quads inside the forced-level envelope. lod 2 = llvmpipe's level formula, lod 1 = the product's exact log2.
+@pytest.mark.parametrize("name,lod", [(n, l) for n in rf.CUBE_MIPS for l in (2, 1)], ids=[f"{n}_lod{l}" for n in rf.CUBE_MIPS for l in (2, 1)])
+def test_oracle_matches_reference_shader_with_cube_mips(built, name, lod):
+    ref = rf.load(name)
+    r = _accept(name, rc.classify(ref, texture_lod=lod, tex_tol=SMOOTH_TEX_TOL, tex_level_envelope=True), True)
+    assert r["texture"] > 100, (name, r)                       # (there are mip-mapped sky pixels to judge)
+    assert r["texture_level"] <= 0.001 * r["pixels"], (name, r)
+    # and the mips matter in these frames: the oracle WITHOUT cube mips is further from the reference's pixels than the class bound on many pixels
+    flat = oracle.OracleScene(*_scene_args(ref), texture_lod=1, cube_mipmap=False).render(threads=8)[0]
+    assert int((rc._diff(flat, ref["frame"]) > SMOOTH_TEX_TOL).sum()) > 4 * int((rc._diff(rc.probe(ref, lod)[0], ref["frame"]) > SMOOTH_TEX_TOL).sum()), name
+
+
 def _scene_args(ref):
     return ref["scene"], ref["width"], ref["height"], ref["textures"], ref["cubemap"]
 
@@ -267,7 +282,7 @@ def test_reference_run_is_reproducible(built):
 # the very mip texels the kernel builds; only the level formula differs) and the plain runs at 0.1 or a sample of another level
 GPU_PLAN = ([(n, 1, 0.0, False) for n in UNTEXTURED] + [(c + "_level0", 0, 0.01, False) for c in rf.TEXTURED]
             + [(c + "_same_mips", 1, 0.1, True) for c in rf.TEXTURED] + [(c, 1, 0.1, True) for c in rf.TEXTURED + rf.TEXTURED_PLAIN_ONLY + ("config0_full",)]
-            + [(c, 1, SMOOTH_TEX_TOL, True) for c in rf.SMOOTH])
+            + [(c, 1, SMOOTH_TEX_TOL, True) for c in rf.SMOOTH + rf.CUBE_MIPS])
 # (app_default_full -- 1280x720, depth 5, the app's own pose -- is not in this plan since round 5: its accounting needs the oracle's 41 + 12 renders of
 # that frame, 215 s of the GPU box's host CPU for one test, a third of the suite. The frame is pinned in two steps instead: the oracle against the
 # reference's pixels by the full accounting in the CPU suite (test_oracle_is_within_the_limits_of_the_full_size_reference_frames), the HIP kernel
@@ -281,7 +296,7 @@ def test_hip_kernel_matches_reference_shader(built, name, lod, tex_tol, level_en
     stability probe; the pixels judged are the GPU's)."""
     from raytracing_opengl_amd import wrapper
     ref = rf.load(name)
-    gl = wrapper.make_renderer(*_scene_args(ref), texture_lod=1 if lod else 0)
+    gl = wrapper.make_renderer(*_scene_args(ref), texture_lod=1 if lod else 0, cube_mipmap=ref["cube_mipmap"])
     gl.draw()
     img = gl.read_pixels(wrapper.RTX_RGBA32F)
     gl.stop()

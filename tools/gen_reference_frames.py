@@ -37,7 +37,8 @@ def main():
         same_mips = name.endswith("_same_mips")
         level0 = name.endswith("_level0")
         W, H = rf.size(name)
-        ref, inactive = ref_gl.render(sc, W, H, ts["textures"], ts["cubemap"], oracle_mips=same_mips, level0_only=level0)
+        cube_mips = rf.cube_mipmap(name)
+        ref, inactive = ref_gl.render(sc, W, H, ts["textures"], ts["cubemap"], cube_mipmap=cube_mips, oracle_mips=same_mips, level0_only=level0)
         arrays = dict(width=W, height=H, frame=np.ascontiguousarray(ref[..., :3]), digest=rf.input_digest(sc, ts),
                       renderer=ref_gl.renderer() + " GALLIVM_PERF=" + os.environ["GALLIVM_PERF"], tex_scale=rf.TEX_SCALE,
                       defines=np.asarray(sc.defines, dtype=np.float64), inactive_blocks=",".join(sorted(inactive)))
@@ -51,7 +52,7 @@ def main():
             arrays["primary_t"] = np.ascontiguousarray(hit[..., 0])
             arrays["primary_type"] = hit[..., 1].astype(np.int8)
             arrays["primary_num"] = hit[..., 2].astype(np.int16)
-        if textured and not same_mips and not level0:
+        if textured and not same_mips and not level0 and not cube_mips:
             # the plain run: glGenerateMipmap built the mip levels, and its filter is the implementation's. Keep what llvmpipe built --
             # as the difference from the oracle's integer-mean levels (0 or +-1 nearly everywhere: compresses to a few KB) -- so that the
             # frame can also be judged with the SAME mip texels on both sides (tests/reference_classify.py, gl_mips)
@@ -63,7 +64,7 @@ def main():
                     assert a.shape == b.shape
                     arrays[f"glmip_{uniform}_{L}"] = (b.astype(np.int16) - a.astype(np.int16)).astype(np.int8)
         np.savez_compressed(rf.path(name), **arrays)
-        img, _ = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=2 if same_mips else (0 if level0 else 1)).render(0, H, threads=os.cpu_count() or 1)
+        img, _ = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=2 if same_mips else (0 if level0 else 1), cube_mipmap=cube_mips).render(0, H, threads=os.cpu_count() or 1)
         f4, f2, mx = rf.compare(img, ref[..., :3])
         assert np.all(ref[..., 3] == 1.0)
         print(f"{name:34s} oracle vs reference: {100*f4:7.3f}% of pixels > 1e-4, {100*f2:7.3f}% > 1e-2, max {mx:.3g}   "
