@@ -2,7 +2,8 @@
 """GPU box: many random scenes (tests/random_scenes.py) through the C ABI against the oracle -- max pixel difference and
 ray counts -- beyond the seeds the test suite runs. Each scene is drawn twice: with the counting kernel variant (ray counts) and with the
 PRODUCT variant (no counters; the many-primitive variant with its group culls where it is selected); both frames must be within the bar.
-usage: [FUZZ_GEN=random_scene|nasty_scene|scaled_quat_scene|crowd_scene|pencil_scene] tools/fuzz_gpu.py first_seed count [width height]"""
+usage: [FUZZ_GEN=random_scene|nasty_scene|scaled_quat_scene|crowd_scene|pencil_scene] [FUZZ_CUBE_MIPS=1] tools/fuzz_gpu.py first_seed count [width height]
+FUZZ_CUBE_MIPS: the sky box is loaded with genMipmap = true (GLWrapper.cpp:307-310) on both sides."""
 import os
 import sys
 
@@ -24,15 +25,16 @@ def main():
     ts = textures.default_texture_set(scale=16)
     worst, bad = 0.0, 0
     tally = dict(needed_relative=0, above_one=0, values=0)
+    cube_mips = bool(os.environ.get("FUZZ_CUBE_MIPS"))
     ctx = {}   # one context per frame size, re-specialised per scene (creating a context costs ~0.2 s -- 40 GPU-minutes per 10 000 scenes)
     for seed in range(first, first + count):
         w, h = fixed or sizes[seed % len(sizes)]
         gen = os.environ.get("FUZZ_GEN", "nasty_scene" if os.environ.get("FUZZ_NASTY") else "random_scene")
         sc = getattr(random_scenes, gen)(seed, w, h)
-        ref, cnt = oracle.OracleScene(sc, w, h, ts["textures"], ts["cubemap"], texture_lod=1).render()
+        ref, cnt = oracle.OracleScene(sc, w, h, ts["textures"], ts["cubemap"], texture_lod=1, cube_mipmap=cube_mips).render()
         gl = ctx.get((w, h))
         if gl is None:
-            gl = ctx[(w, h)] = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"])
+            gl = ctx[(w, h)] = wrapper.make_renderer(sc, w, h, ts["textures"], ts["cubemap"], cube_mipmap=cube_mips)
         else:
             gl.init_shaders(sc.defines)
             gl.uploader = wrapper.SceneUploader(sc, gl)
