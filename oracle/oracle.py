@@ -202,9 +202,15 @@ class OracleScene:
         if tags is not None:
             assert tags.shape == (y1 - y0, self.width) and tags.dtype == np.uint32 and tags.flags.c_contiguous
             l.orc_set_tag_buffer(tags.ctypes.data)
+        # the level-0 texels are re-hashed (a stale mip chain under a reused address is dropped) on this object's FIRST render only: its arrays
+        # are pinned in self._keep from then on, and the accounting of tests/reference_classify.py renders one description thousands of times
+        l.orc_set_mip_validation.argtypes = [ctypes.c_int]
+        l.orc_set_mip_validation(0 if getattr(self, "_validated", False) else 1)
         try:
             rc = l.orc_render(ctypes.byref(self.frame), y0, y1, out.ctypes.data, ctypes.byref(cnt), threads)
+            self._validated = True
         finally:
+            l.orc_set_mip_validation(1)
             l.orc_set_ray_jitter(0.0, 0.0)
             l.orc_set_lod_force(-1.0)
             l.orc_set_lod_force_site(0, -1, -1, -1.0)
