@@ -682,8 +682,8 @@ def test_the_behind_rays_are_what_the_fixture_says(built):
         assert dcull
 
 
-@pytest.mark.xfail(strict=True, reason="known residual of the torus culls (DESIGN.md section 3, 'behind' rays): the reference's solver, out of sweeps on "
-                                       "its way to negative roots 26 / 54 units back, reports a positive phantom root; the product culls the ray unsolved. "
+@pytest.mark.xfail(strict=True, reason="known residual of the torus culls (DESIGN.md section 3, 'behind' rays): the reference's solver has the four negative "
+                                       "roots 26 / 54 units back, cannot meet its stop criterion in float32, and its 60th sweep throws an iterate to a positive t; the product culls the ray unsolved. "
                                        "2 rays in 4.2e11 culled ones (profiles/r05zz_cull_audit_torus_8e11_101_scenes.txt); remedy sized in DESIGN.md section 10")
 def test_the_product_reports_the_reference_phantom_hit_on_the_behind_rays(built):
     """What parity with the reference would demand on those two rays: the product's composition (cull, then solve) reports the reference's hit.
