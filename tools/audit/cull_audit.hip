@@ -26,7 +26,7 @@ using namespace rtdev;
 
 namespace {
 
-enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6 };
+enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6, F_TORUS_BEHIND = 7 };
 enum { N_COUNTERS = 128, BAD_FLOATS = 12 };
 
 struct AuditParams {
@@ -401,6 +401,53 @@ __device__ void audit_torus_lead(const AuditParams& p, const SceneView& S, unsig
     }
 }
 
+// "Behind" rays (round 5, last session): rays that point AWAY from a torus their backward extension goes through -- every real root
+// of the quartic is negative, every cull rejects them, and the reference's solver, which in float32 cannot meet its stop criterion on far real
+// roots, occasionally ends its 60 sweeps with an iterate thrown to a positive t on the real axis: a phantom hit. The rate where it lives: every ray
+// of this family is such a ray (a point of the tube's surface, jittered; an origin 1.5 ... 100 units from the centre aimed at it, half of them
+// grazing; then the direction REVERSED), every one is solved. bins b = 0..9 of the origin's distance as in the lead family.
+// counters: 0 rays, 1 culled by the product's composition (torus_cull or the local culls), 2 hits reported, 20+b rays per bin, 30+b VIOLATIONS
+//           phantom hits per bin (hit reported, the half-line clears the real tube by more than 1 mm in double arithmetic), 40+b of those: culled
+__device__ void audit_torus_behind(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = S.h->n_torus;
+    if (n == 0) return;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevTorus T = S.tori()[i];
+        if (!(T.cull.y < RT_FLT_MAX)) continue;
+        const float Rm = fabsf(T.radii.x), rt = fabsf(T.radii.y);
+        const float phi = 6.2831853f * R.u01(), th = 6.2831853f * R.u01();
+        const float cp = __cosf(phi), sp = __sinf(phi), ct = __cosf(th), st = __sinf(th);
+        const f3 nl = mk3(ct * cp, ct * sp, st);
+        const f3 sl = mk3((Rm + rt * ct) * cp, (Rm + rt * ct) * sp, rt * st) + mk3(R.gauss(), R.gauss(), R.gauss()) * (R.u01() < 0.5f ? 1.0e-3f : 0.05f * (Rm + rt));
+        const float dist = R.logu(1.5f, 100.0f);
+        f3 ol = R.unit() * dist;
+        if (R.u01() < 0.5f) {
+            f3 dl = normalize3(sl - ol);
+            dl = normalize3(dl - nl * (dot3(dl, nl) * (1.0f - 0.1f * R.u01())));
+            ol = sl - dl * dist;
+        }
+        const f3 ro = quat_rotate(T.qinv, ol) + xyz(T.pos);
+        const f3 rd = -normalize3(quat_rotate(T.qinv, normalize3(sl - ol)));       // away from the torus
+        const float tmin = ray_tmin(R);
+        bool culled = torus_cull(S.torus_bound()[i], ro, rd);
+        float t2 = 0.0f;
+        bool solved = false;
+        if (!culled) { intersect_torus_c<true, true>(T, ro, rd, tmin, t2, solved); culled = !solved; }
+        const bool ident = ident_flag(T.pos.w);
+        const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
+        const int b = lead_bin(sqrtf(dot3(o, o)));
+        c[0]++; c[1] += culled; c[20 + b]++;
+        float t = 0.0f;
+        if (!intersect_torus(T, ro, rd, tmin, t)) continue;
+        c[2]++;
+        if (ray_tube_clearance(T, o, d, 100.11) > 1.0e-3) { c[30 + b]++; c[40 + b] += culled; record_bad(p, 30 + b, i, ro, rd, tmin, t, sqrtf(dot3(o, o))); }
+    }
+}
+
 // The one length premise the torus culls keep: a torus the ray enters beyond the reference's own reach (roots are accepted for t < 100 only,
 // rt.frag:486; RT_TORUS_REACH = 102.5) is culled -- i.e. "a solve from more than 100 units out does not report a root below 100". Every ray
 // of this family is such a ray (origin 104 ... 3000 from the centre, aimed at the tube; the product's torus_cull is checked to fire) and
@@ -720,6 +767,7 @@ __global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
         }
     }
     else if (p.family == F_TORUS_FAR) audit_torus_far(p, S, gid, c);
+    else if (p.family == F_TORUS_BEHIND) audit_torus_behind(p, S, gid, c);
     else audit_tables(p, S, gid, c);
     flush(p, c);
     if (p.family == F_TORUS_MARGIN && worst) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 20), worst);

@@ -22,10 +22,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BLOCKS = ("scene_buf", "spheres_buf", "planes_buf", "surfaces_buf", "boxes_buf", "toruses_buf", "rings_buf", "lights_point_buf", "lights_direct_buf")
-FAMILIES = {"torus": 0, "torus_margin": 1, "quadric": 2, "ring": 3, "tables": 4, "torus_lead": 5, "torus_far": 6}
+FAMILIES = {"torus": 0, "torus_margin": 1, "quadric": 2, "ring": 3, "tables": 4, "torus_lead": 5, "torus_far": 6, "torus_behind": 7}
 N_COUNTERS = 128
 LEAD_BINS = ("<2", "2..4", "4..6", "6..8", "8..10", "10..12", "12..16", "16..24", "24..48", ">=48")      # |o|: origin to torus centre
-NEEDS = {"torus": 4, "torus_margin": 4, "torus_lead": 4, "torus_far": 4, "quadric": 2, "ring": 5}      # index into defines of the count that must be > 0
+NEEDS = {"torus": 4, "torus_margin": 4, "torus_lead": 4, "torus_far": 4, "torus_behind": 4, "quadric": 2, "ring": 5}      # index into defines of the count that must be > 0
 LABELS = {
     "torus": {0: "rays", 1: "culled by any test", 2: "sphere cull", 3: "group sphere", 4: "convex-hull cull", 5: "puck / hole cull", 6: "the ray up to the reference's reach (t < 100) stays >= 6 mm clear of the real tube (exact)",
               7: "solver runs", 8: "solver hits among them", 16: "rays with a non-unit direction", 17: "tube (Bernstein) cull, behind the puck test",
@@ -45,6 +45,11 @@ LABELS = {
                        (10, "VIOLATIONS a root below the ray's limit is reported")] +
                       [(20 + b, f"rays from {n} units out") for b, n in enumerate(("< 120", "120..150", "150..200", "200..400", "400..1000", ">= 1000"))] +
                       [(30 + b, f"hits reported from {n} units out") for b, n in enumerate(("< 120", "120..150", "150..200", "200..400", "400..1000", ">= 1000"))]),
+    "torus_behind": dict([(0, "rays that point AWAY from a torus their backward extension goes through (origins 1.5 .. 100 from the centre), every one solved"),
+                          (1, "culled by the product's composition"), (2, "hits reported")] +
+                         [(20 + b, f"rays from |o| {LEAD_BINS[b]}") for b in range(10)] +
+                         [(30 + b, f"VIOLATIONS |o| {LEAD_BINS[b]}: a hit is reported although the half-line clears the real tube by more than 1 mm") for b in range(10)] +
+                         [(40 + b, f"of those from |o| {LEAD_BINS[b]}: culled by the product") for b in range(10)]),
     "quadric": {0: "rays", 1: "culled by surface_cull", 2: "culled by the group test", 3: "literal hits", 4: "literal hits on the degenerate branch", 5: "left early by the product intersector (no real root)", 6: "culled by the clip-box test behind surface_cull",
                 10: "VIOLATIONS surface_cull", 11: "VIOLATIONS group test", 12: "VIOLATIONS product intersector != literal rt.frag:513-572", 13: "VIOLATIONS clip-box test"},
     "ring": {0: "rays", 1: "culled", 2: "literal hits", 10: "VIOLATIONS"},
