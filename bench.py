@@ -296,8 +296,8 @@ def bench_c_boundary(args, mode, n_ranks, rank, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)     # (round 6: 100 timed draws = 47 ms at 4K; kernel_ms_stats has their spread)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--depth", type=int, default=DEPTH)
@@ -455,6 +455,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     n_ev = min(args.steps, 128)
+    each_ms = sorted(gl.recent_draw_ms(n_ev))       # the spread of the timed draws: a 9 ms window is not the whole measurement
     kernel_ms = gl.sum_recent_draw_ms(n_ev) / n_ev  # HIP events on the launch stream
     st_end = gl.stats()
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
@@ -491,6 +492,8 @@ def main():
                        "clock_ramp": {"draws": ramp_draws, "ms": round(ramp_ms, 1), "note": "untimed draws in front of the warm-up"}},
             "ms_per_frame": round(ms_per_step, 4),
             "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_stats": {"n": n_ev, "min": round(each_ms[0], 4), "median": round(each_ms[len(each_ms) // 2], 4), "max": round(each_ms[-1], 4),
+                                "note": "HIP-event durations of the timed draws one by one (rtx_recent_draw_ms); kernel_ms is their mean"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "note": f"HBM-write roofline of the {target.upper()} frame ({px_bytes} B/pixel); the path is bound by VALU issue, see roofline.valu and DESIGN.md"},
@@ -522,8 +525,15 @@ def main():
                 rate = v["valu_insts_per_launch"] / (kernel_ms * 1e-3)
                 cyc = peak["cycles_per_wave_inst_per_simd"]
                 clock = (v.get("shader_clock_GHz") or 2.3) * 1e9
+                # frac_nominal: against the guide's figure -- one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs
+                # (/opt/skills/guides/MI355X_MICROARCH.md) -- beside the mix-weighted `frac`, whose ceiling is this repository's own micro-benchmark
+                # (profiles/valu_peak.json: v_fma_f32 3.95, v_add / v_mul 2.34 cycles). Both are quoted so that neither has to be taken on trust.
+                nominal_peak = 1024.0 * clock / 2.0
                 val = {"insts_per_launch": v["valu_insts_per_launch"], "achieved": round(rate / 1e9, 1), "unit": "G wave-instructions/s",
-                       "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash}
+                       "cycles_per_valu_inst": v.get("cycles_per_valu_inst"), "lane_utilisation": v.get("lane_utilisation"), "kernel_hash": khash,
+                       "peak_nominal": round(nominal_peak / 1e9, 1), "frac_nominal": round(rate / nominal_peak, 4),
+                       "frac_nominal_x_lane_utilisation": (round(rate / nominal_peak * v["lane_utilisation"], 4) if v.get("lane_utilisation") else None),
+                       "nominal_note": "1024 SIMDs x shader clock / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); x lane utilisation = the share of FP32 lanes doing work"}
                 cls = v.get("classes")
                 if cls:
                     # Mix-weighted issue ceiling: every instruction class at its MEASURED issue cost (cycles per wave-instruction per SIMD,
@@ -540,7 +550,8 @@ def main():
                                 "shader_clock_GHz": v.get("shader_clock_GHz")})
                     val["note"] = ("mix-weighted VALU issue ceiling: per-class instruction counts (rocprofv3 PMC, " + v.get("source", "") + ") x measured issue "
                                    "cycles per class (" + peak.get("source", "") + "), unnamed classes at the cheapest measured cost, so frac <= 1 by "
-                                   "construction; duration live")
+                                   "construction; duration live. 'other' = SQ_INSTS_VALU minus the classes the SQ_INSTS_VALU_* counters name (add / mul / fma / "
+                                   "trans f32, int32, int64, cvt): v_mov, v_cmp, v_cndmask, v_min / v_max, lane moves (readlane / writelane / DPP)")
                 else:
                     val.update({"peak": peak["simple_op_peak_G_per_s"], "frac": round(rate / 1e9 / peak["simple_op_peak_G_per_s"], 4),
                                 "note": "no per-class counts in the profile: peak = the issue rate of an all-v_add stream (a loose ceiling)"})

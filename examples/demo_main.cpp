@@ -41,9 +41,8 @@ int main(int argc, char** argv)
 {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 60;
     GLWrapper glWrapper(wind_width, wind_height, false);
-#ifdef RTX_SHIM_HAVE_SMAA_TABLES
-    glWrapper.enable_SMAA(ULTRA);  // main.cpp:32. The post-process needs the reference's two look-up tables, which this repository does not
-#endif                             // carry: built with -I<reference>/src the shim finds AreaTex.h / SearchTex.h and hands them over
+    glWrapper.enable_SMAA(ULTRA);  // main.cpp:32, unconditionally like the reference: the library computes the two look-up tables itself
+                                   // (include/rtx/smaa_tables.h, byte-identical to the reference's AreaTex.h / SearchTex.h arrays)
     if (!glWrapper.init_window()) return 1;
     wind_width = glWrapper.getWidth();
     wind_height = glWrapper.getHeight();
@@ -100,7 +99,7 @@ int main(int argc, char** argv)
         glWrapper.draw();
     }
     std::vector<unsigned char> rgba(static_cast<size_t>(glWrapper.getWidth()) * glWrapper.getHeight() * 4);
-    glWrapper.read_pixels(RTX_RGBA8, rgba.data(), rgba.size());  // synchronises
+    glWrapper.read_pixels(RTX_SCREEN_RGBA8, rgba.data(), rgba.size());  // synchronises; what the reference's window shows: the frame after SMAA
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("FPS: %.1f (%d frames, %dx%d, depth 5)\n", frames / secs, frames, glWrapper.getWidth(), glWrapper.getHeight());
 

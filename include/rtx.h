@@ -276,6 +276,8 @@ RTX_API int rtx_get_stats_sized(rtx_context* ctx, void* out, size_t out_bytes);
 /* Sum of the HIP-event durations (ms) of the n most recent draws (n <= 128): the kernel time a
  * bench needs when it enqueues K draws back to back. A context should be driven from ONE stream. */
 RTX_API int rtx_sum_recent_draw_ms(rtx_context* ctx, int n, float* sum_ms);
+/* The same durations one by one, ms_each[0] = the most recent draw (n <= 128); does not retire them (call it before rtx_sum_recent_draw_ms). */
+RTX_API int rtx_recent_draw_ms(rtx_context* ctx, int n, float* ms_each);
 /* Device-side exhaustive check of the divide-free byte->float conversion used by the samplers
  * (must report 0 mismatches against byte/255.0f). */
 RTX_API int rtx_selftest(rtx_context* ctx, int* mismatches);

@@ -405,13 +405,22 @@ static vec3 cube_project(int face, vec3 v)
     default: return v3(-v.x, -v.y, -v.z);
     }
 }
+/* load_cubemap(faces, genMipmap = true) with a face that failed to load (GLWrapper.cpp:296-310): the texture is not cube complete, so
+ * glGenerateMipmap raises GL_INVALID_OPERATION and builds nothing, and with GL_LINEAR_MIPMAP_LINEAR an incomplete texture samples
+ * (0, 0, 0, 1) on EVERY face -- not only on the missing one. */
+static int cube_incomplete(const orc_cubemap* c)
+{
+    if (!c->gen_mipmap) return 0;
+    for (int f = 0; f < 6; f++) if (!c->faces[f]) return 1;
+    return 0;
+}
 /* texture(skybox, dir) at level 0: per-face bilinear with CLAMP_TO_EDGE, not seamless (GLWrapper.cpp:310-314). */
 static vec4 sample_cube(const orc_cubemap* c, vec3 d)
 {
     const int face = cube_face(d);
     const vec3 p = cube_project(face, d);
     const float sc = p.x, tc = p.y, ma = p.z;
-    if (c->face_size <= 0 || !c->faces[face]) return v4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (c->face_size <= 0 || !c->faces[face] || cube_incomplete(c)) return v4(0.0f, 0.0f, 0.0f, 1.0f);
     float s = 0.5f * (sc / ma + 1.0f);
     float t = 0.5f * (tc / ma + 1.0f);
     orc_texture ft;
@@ -607,7 +616,7 @@ static vec4 sample_cube_lod(const orc_cubemap* c, vec3 d, float lambda)
 {
     const int face = cube_face(d);
     const vec3 p = cube_project(face, d);
-    if (c->face_size <= 0 || !c->faces[face]) return v4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (c->face_size <= 0 || !c->faces[face] || cube_incomplete(c)) return v4(0.0f, 0.0f, 0.0f, 1.0f);
     const float s = 0.5f * (p.x / p.z + 1.0f);
     const float t = 0.5f * (p.y / p.z + 1.0f);
     orc_texture ft;

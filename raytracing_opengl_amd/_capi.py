@@ -25,7 +25,7 @@ SYMBOLS = (
     "rtx_specialize", "rtx_block_create", "rtx_block_update", "rtx_texture2d_create", "rtx_cubemap_create",
     "rtx_sampler_unit", "rtx_bind_texture", "rtx_texture_destroy", "rtx_set_option", "rtx_get_option", "rtx_draw",
     "rtx_draw_bands", "rtx_draw_rows", "rtx_finish", "rtx_read_pixels", "rtx_framebuffer_device", "rtx_get_stats", "rtx_get_stats_sized",
-    "rtx_sum_recent_draw_ms", "rtx_selftest",
+    "rtx_sum_recent_draw_ms", "rtx_recent_draw_ms", "rtx_selftest",
     "rtx_enable_smaa", "rtx_smaa_set_tables", "rtx_smaa_default_tables", "rtx_smaa_resolve", "rtx_write_pixels",
     "rtx_create_multi", "rtx_device_count", "rtx_rank", "rtx_rccl_unique_id", "rtx_create_rank",
     "rtx_set_band_split", "rtx_get_band_split", "rtx_get_rank_draw_ms",
@@ -96,6 +96,7 @@ def load():
     lib.rtx_get_stats.argtypes = [vp, P(Stats)]
     lib.rtx_get_stats_sized.argtypes = [vp, vp, c.c_size_t]
     lib.rtx_sum_recent_draw_ms.argtypes = [vp, i, P(c.c_float)]
+    lib.rtx_recent_draw_ms.argtypes = [vp, i, P(c.c_float)]
     lib.rtx_selftest.argtypes = [vp, P(i)]
     lib.rtx_create_multi.argtypes = [i, i, i, P(i), i, P(vp)]
     lib.rtx_device_count.argtypes = [vp, P(i)]

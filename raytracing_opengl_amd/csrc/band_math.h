@@ -138,4 +138,55 @@ inline size_t bytes_moved(int width, size_t rows, int target, bool rgb) { return
 // the buffer set (0 / 1) frame number `frame_no` uses: the gather of frame k overlaps the trace of frame k + 1, which uses the other set
 inline int buffer_set(unsigned long long frame_no) { return static_cast<int>(frame_no & 1ull); }
 
+// ---- first contact between ranks in separate processes (rtx_create_rank) -------------------------------------------------------------
+// Every rank decides the byte counts of its paired ncclSend / ncclRecv on its own, from ITS copy of the frame configuration: frame size,
+// rank count, band layout and rows, the contiguous split, which colour targets travel and whether the float target travels without its
+// alpha. Two ranks that disagree (an option set on one process only) would hang or exchange garbage. So the configuration is digested to
+// 16 bytes, and whenever a rank's digest differs from the one it last had confirmed, the ranks compare digests BEFORE any band travels:
+// every peer sends its digest to rank 0, rank 0 answers each with a verdict (rtx_capi.cpp config_handshake; fixed-size messages, so
+// they pair whatever the configurations are). FNV-1a over the fields, two seeds.
+struct FrameConfig {
+    int width = 0, height = 0, n_ranks = 0, band_rows = 0, band_layout = 0, gather_targets = 0, gather_rgb = 0, loopback = 0;
+    std::vector<int> split_rows;      // contiguous layouts only (empty for the interleaved one)
+};
+struct ConfigDigest {
+    unsigned long long a = 0, b = 0;
+    bool operator==(const ConfigDigest& o) const { return a == o.a && b == o.b; }
+    bool operator!=(const ConfigDigest& o) const { return !(*this == o); }
+};
+inline ConfigDigest config_digest(const FrameConfig& c)
+{
+    std::vector<int> v{c.width, c.height, c.n_ranks, c.band_rows, c.band_layout, c.gather_targets, c.gather_rgb, c.loopback, static_cast<int>(c.split_rows.size())};
+    if (c.band_layout != 0) v.insert(v.end(), c.split_rows.begin(), c.split_rows.end());
+    ConfigDigest d;
+    d.a = 1469598103934665603ull; d.b = 0x9e3779b97f4a7c15ull;
+    for (int x : v)
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long byte = (static_cast<unsigned int>(x) >> (8 * k)) & 0xffu;
+            d.a = (d.a ^ byte) * 1099511628211ull;
+            d.b = (d.b ^ (byte + 0x51ull)) * 0x100000001b3ull + (d.b >> 29);
+        }
+    return d;
+}
+// rank 0's side of the handshake: digests[r] = what rank r sent (digests[0] = its own). Returns the first rank that disagrees, -1 if none.
+inline int config_first_mismatch(const std::vector<ConfigDigest>& digests)
+{
+    for (size_t r = 1; r < digests.size(); r++)
+        if (digests[r] != digests[0]) return static_cast<int>(r);
+    return -1;
+}
+// A wait on the transfer stream that cannot hang the process: `done()` is polled (hipStreamQuery in the product, a counter in the host
+// tests) until it reports completion or `timeout_ms` have passed on `now_ms()`; `nap()` yields between polls. timeout_ms <= 0: wait for ever
+// (the behaviour of rounds 1-5). Returns true when the work completed.
+template <class Done, class Now, class Nap>
+inline bool bounded_wait(Done done, Now now_ms, Nap nap, double timeout_ms)
+{
+    const double t0 = now_ms();
+    for (;;) {
+        if (done()) return true;
+        if (timeout_ms > 0.0 && now_ms() - t0 > timeout_ms) return false;
+        nap();
+    }
+}
+
 }  // namespace rtbands

@@ -915,10 +915,52 @@ RT_HD bool unit_direction(float dd) { return fabsf(dd - 1.0f) <= 1e-3f; }   // f
 #ifndef RT_TORUS_REACH
 #define RT_TORUS_REACH 102.5f      /* 100 + 2.5 % (round 4's widening at t = 100); sphere_cull and the puck test add their own slack */
 #endif
+// "BEHIND" RAYS (round 6). A ray that points AWAY from a torus its backward extension goes through has four real NEGATIVE roots, and the
+// reference still solves it (rt.frag:462-487 never culls). From a near origin the iteration converges on them and reports nothing. From a far
+// origin the quartic's coefficients (~ |o|^4) put the float noise of a Durand-Kerner step above the 1e-3 stop criterion: the solve runs all 60
+// sweeps with its iterates jittering around the roots, and when two of them nearly coincide in the last sweep one is thrown along the real
+// axis -- now and then to a positive t below the limit: a hit where there is no torus, which the reference shows. Measured
+// (tools/cull_audit.py family torus_behind, profiles/r05zz_cull_audit_torus_behind_6e10.txt: every ray of that kind solved): no phantom among
+// 1.4e10 such rays from within 4 units of the torus' centre, 1 in 5.7e9 at 4..6, 862 in 9.7e9 at 24..48. Rule: "the torus lies behind the
+// origin" is a reason to cull it only for a NEAR origin; for a far one every test looks at the ray's whole LINE -- the backward half is culled
+// only where it clears the inflated torus (then the roots are two complex pairs, the lateral premise of the comment above) or enters it
+// beyond RT_TORUS_REACH_BACK. Near = closer to the centre than torus_near2(bound radius^2): 3 units at most (a margin below the 4 the
+// measurement supports), two bound radii for a small torus (the noise grows as |o|^4 / (r R^2): what "far" means scales with the torus),
+// and never less than 1.25 bound radii, so that a torus' own shadow and mirror rays (|o| <= R + r) keep their culls whatever its size.
+#ifndef RT_TORUS_BEHIND_RULE
+#define RT_TORUS_BEHIND_RULE 1      /* A/B switch: 0 = the culls of round 5 (a torus behind the origin is culled from any distance) */
+#endif
+#ifndef RT_TORUS_REACH_BACK
+#define RT_TORUS_REACH_BACK 102.5f  /* how far back along the line a torus still has to be looked at (measured: tools/cull_audit.py family torus_behind_far) */
+#endif
+#if defined(RT_AB_NEAR_INF)     /* measurement only: the rule compiled in, never taken (what its CODE costs) */
+RT_HD float torus_near2(float rb2) { return rb2 * 0.0f + 3.0e38f; }
+#else
+RT_HD float torus_near2(float rb2) { return gl_max(gl_min(9.0f, 4.0f * rb2), 1.5625f * rb2); }
+#endif
+// sphere_cull(c, r2, ro, rd, RT_TORUS_REACH) with the "behind" rule in its `b >= 0` branch; near2: squared distance up to which "the sphere
+// lies behind the origin" is still a reason to cull (0 = from nowhere: a group's sphere, whose members each have their own)
+RT_HD bool torus_sphere_cull(f3 c, float r2, float near2, f3 ro, f3 rd)
+{
+    const float a = dot3_fma(rd, rd);
+    if (!unit_direction(a)) return false;
+    const f3 oc = ro - c;
+    const float d2 = dot3_fma(oc, oc);
+    const float cc = d2 - r2;                 // > 0: origin outside
+    if (!(cc > 0.0f)) return false;           // (also: a torus that is never culled, r2 = +inf; NaN)
+    const float b = dot3_fma(oc, rd);
+    const float h = fmaf(b, b, -(a * cc));
+    const float err = 1e-5f * a * d2;
+    if (h < -err) return true;                // the LINE misses the sphere, beyond rounding doubt
+    if (b >= 0.0f) {                          // sphere behind the origin
+        if (!RT_TORUS_BEHIND_RULE || !(d2 > near2)) return true;
+        return sphere_entry_beyond(a, -b, h + err, d2, RT_TORUS_REACH_BACK);     // far origin: only if the reversed ray enters it beyond the reach
+    }
+    return sphere_entry_beyond(a, b, h + err, d2, RT_TORUS_REACH);
+}
 RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd)
 {
-    if (!unit_direction(dot3_fma(rd, rd))) return false;
-    return sphere_cull(xyz(bound), bound.w, ro, rd, RT_TORUS_REACH);
+    return torus_sphere_cull(xyz(bound), bound.w, torus_near2(bound.w), ro, rd);
 }
 // A ring hit lies within sqrt(r2) of the ring centre (p < r2, rt.frag:384) and needs 0 < t < tmin;
 // intersect_ring has no NaN-accepting path (all four comparisons must hold), so missing the
@@ -1029,10 +1071,10 @@ RT_HD bool torus_tube_cull(const DevTorus& T, f3 o, f3 d, float t0, float t1)
     return ok;
 }
 // (t0, t1: on a `false` return, the part of the ray inside the inflated puck and the reach -- what torus_tube_cull then looks at)
-RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float& t0, float& t1)
+RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d, float& t0, float& t1, float reach = RT_TORUS_REACH)
 {
     t0 = 0.0f;
-    t1 = RT_TORUS_REACH * 1.001f + 0.01f;     // the reference's own t < 100, never the ray's limit (see torus_cull)
+    t1 = reach * 1.001f + 0.01f;              // the reference's own t < 100, never the ray's limit (see torus_cull)
     // slab |z| <= hz
     const float hz = T.cull.x;
     if (d.z != 0.0f) {
@@ -1079,11 +1121,12 @@ RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d)
 // TUBE: the Bernstein test of the inflated tube behind the puck test (round 4). Compiled into the many-primitive kernel variant (and the host
 // build): 64 tori, 4K, depth 6: 5.25 M -> 4.47 M solves, 141 k -> 128 k solver runs, 1 904 -> 1 794 us; in the default variant its one torus gains
 // a tenth fewer runs and loses as much to the 90 instructions per candidate pass (472 -> 477 us: not compiled in there).
+#ifndef RT_TORUS_BACK_TUBE
+#define RT_TORUS_BACK_TUBE 1     /* the tube test on the backward half-line in every kernel variant (a ray it does not remove is a 60-sweep solve) */
+#endif
 template <bool TUBE = true>
-RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
+RT_HD bool torus_forward_cull(const DevTorus& T, f3 o, f3 d)
 {
-    const float dd = dot3(d, d);
-    if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
     if (torus_hull_cull(T, o, d)) return true;
     float t0, t1;
     if (torus_puck_cull(T, o, d, t0, t1)) return true;
@@ -1096,6 +1139,29 @@ RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
     // (The START part alone in the default kernel variant, whose one torus has no tube test: 459 -> 468 us at 4K, 198 -> 206 us at 1920 x 1080 --
     // measured and not compiled in, profiles/r05u_start_cull_ab.txt.)
     return TUBE && T.k.w > 0.0f && torus_tube_cull(T, o, d, t0, t1);
+}
+// The "behind" rule (torus_cull): from a far origin the part of the LINE behind the origin has to clear the inflated torus too -- the same puck
+// and tube tests on the reversed ray (the hull test is a statement about half-lines that move away from the disc; a reversed ray of this
+// kind moves towards it).
+RT_HD bool torus_backward_cull(const DevTorus& T, f3 o, f3 d)
+{
+    const f3 nd = mk3(-d.x, -d.y, -d.z);
+    float t0, t1;
+    if (torus_puck_cull(T, o, nd, t0, t1, RT_TORUS_REACH_BACK)) return true;
+    return RT_TORUS_BACK_TUBE && T.k.w > 0.0f && torus_tube_cull(T, o, nd, t0, t1);
+}
+template <bool TUBE = true>
+RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
+{
+    const float dd = dot3(d, d);
+    if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
+    if (!torus_forward_cull<TUBE>(T, o, d)) return false;
+#if defined(RT_AB_EXPECT)
+    if (!RT_TORUS_BEHIND_RULE || __builtin_expect(!(dot3(o, o) > T.k.y), 1)) return true;
+#else
+    if (!RT_TORUS_BEHIND_RULE || !(dot3(o, o) > T.k.y)) return true;     // near origin (the common case; T.k.y: rt_pack.h): the forward half-line decides
+#endif
+    return torus_backward_cull(T, o, d);
 }
 template <bool CULL, bool TUBE = true>
 RT_HD bool intersect_torus_c(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t, bool& solved)
@@ -1242,8 +1308,7 @@ RT_HD bool surface_box_miss(const DevSurface& Q, f3 ro, f3 rd, float tlimit)
 RT_HD bool torus_group_cull(f4 g, f3 ro, f3 rd)
 {
     if (!(g.w >= 0.0f)) return false;   // a member that is never culled (zero tube, non-unit quaternion): neither is the group
-    if (!unit_direction(dot3_fma(rd, rd))) return false;
-    return sphere_cull(xyz(g), g.w, ro, rd, RT_TORUS_REACH);
+    return torus_sphere_cull(xyz(g), g.w, 0.0f, ro, rd);    // (no "near" for a group: each member has its own)
 }
 RT_HD bool surface_group_cull(f4 g, f3 ro, f3 rd)
 {
@@ -1381,7 +1446,7 @@ RT_HD void scan_stats_level2(int kind, bool need)
 struct PencilPrim {
     f4 a;   // APEX: unit vector from the apex to the centre of the bound, w = sin(alpha), alpha = angular radius of the (padded) bound
             // PARALLEL: x, y = the centre across the direction, z = padded radius, w = |p2| of the pencil's direction (quadrics)
-    f4 b;   // x = cos(alpha); y = 1: set in every cell (no finite bound / the apex is inside it / NaNs); z = |M|_F, w = p2 margin (quadrics)
+    f4 b;   // x = cos(alpha); y = 1: set in every cell (no finite bound / the apex is inside it / NaNs); z = |M|_F, w = p2 margin (quadrics); tori: z = 1 if the apex is a far origin (torus_cull, "behind" rule)
 };
 RT_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RT_HD float angle_between(f3 a, f3 b) { return atan2f(length3(cross3(a, b)), dot3(a, b)); }   // well-conditioned at 0 and pi, unlike acos
@@ -1407,6 +1472,9 @@ RT_HD PencilPrim pencil_prim(const DevPencil& P, f4 bound, const DevSurfaceCull*
         const float D = sqrtf(D2), sa = rad / D;                        // sin(alpha) < 0.996: alpha is well-conditioned
         r.a = mk4(v.x / D, v.y / D, v.z / D, sa);
         r.b.x = sqrtf(1.0f - sa * sa);
+        // tori: the apex is a FAR origin in the sense of torus_cull's "behind" rule (with 2 % to spare) -- a ray that STARTS at the apex keeps
+        // this torus as a candidate in the cells its bound's antipodal cone meets as well
+        if (!Q && RT_TORUS_BEHIND_RULE && D2 > 0.98f * torus_near2(bound.w)) r.b.z = 1.0f;
     } else {
         const float cu = dot3(c, xyz(P.e1)), cv = dot3(c, xyz(P.e2));
         const float rr = rad + 1.0e-3f * gl_max(P.grid.z, P.grid.w);
@@ -1481,7 +1549,8 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
     // A light's pencil (P.a.w != 0: its rays run TOWARDS the apex): the cell of a ray only tells where the ray comes from, so "the bound is
     // not in the cell's cone" also drops every torus BEHIND the light -- the ray's own length limit in disguise (the ray would reach it beyond
     // its distance to the light), which no torus cull may use (torus_cull). A torus therefore stays a candidate of the cells its bound's
-    // ANTIPODAL cone meets as well.
+    // ANTIPODAL cone meets as well. A pencil of rays that START at the apex (the camera's): the antipodal cells too, where the apex is a far
+    // origin for the torus (pp.b.z, round 6: torus_cull's "behind" rule -- the ray's backward extension goes through the bound).
     auto misses_behind = [&](const PencilPrim& pp) { return -dot3_fma(C.axis, xyz(pp.a)) < fmaf(C.ct, pp.b.x, -(C.st * pp.a.w)) - 4.0e-6f; };
     const bool towards_apex = apex && P.a.w != 0.0f;
     uint32_t bits = 0u;
@@ -1494,7 +1563,7 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
                 const float p2 = apex ? fabsf(quadric_p2(S.surf_cull()[first + b], C.axis)) : pp.a.w;
                 if (p2 > 2.01f * pp.b.z * C.theta + pp.b.w) clear = misses(pp);
             } else {
-                clear = misses(pp) && (!towards_apex || misses_behind(pp));
+                clear = misses(pp) && ((!towards_apex && pp.b.z == 0.0f) || misses_behind(pp));
             }
         }
         if (!clear) bits |= 1u << b;
@@ -1555,6 +1624,9 @@ struct PencilScan {
 // ---- rays of no pencil: slab tables (rt_scene_dev.h DevSlabs) + the direction table ----
 // words[0 .. stride): the lane's candidate mask. A lane the tables cannot vouch for (not a unit direction, far-away or non-finite origin)
 // gets every primitive. tlimit: hits beyond it do not matter (the closest hit so far / the distance to the light) -- see below.
+#ifndef RT_SLAB_BACK_SEGMENTS
+#define RT_SLAB_BACK_SEGMENTS 4     /* pieces of the walk over the line's part BEHIND the origin (tori, "behind" rule); the forward part has RT_SLAB_SEGMENTS */
+#endif
 RT_HD int slab_index(float p, float lo, float inv) { return (int)gl_min(gl_max((p - lo) * inv, 0.0f), (float)(RT_SLABS - 1)); }
 RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_t* words)
 {
@@ -1577,30 +1649,44 @@ RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_
     // then a cylinder at 3018 that the reference therefore shows). A lane with such a quadric among its candidates gets the whole ray.
     // Tori: never the ray's own limit, only the reference's t < 100 (torus_cull) -- in a scene with tori the walk covers at least that.
     const float tB_quadric = any_deg ? 1.0e6f : gl_min(tlimit + 0.025f * gl_max(gl_min(tlimit, 100.0f) - 8.0f, 0.0f), 1.0e6f);   // (the slack is rounds 2-4's, kept)
-    float tA = 0.0f, tB = S.h->n_torus > 0 ? gl_max(tB_quadric, RT_TORUS_REACH * 1.001f + 0.01f) : tB_quadric;
-    bool inside = true;
+    const float tB_forward = S.h->n_torus > 0 ? gl_max(tB_quadric, RT_TORUS_REACH * 1.001f + 0.01f) : tB_quadric;
     const float ov[3] = {o.x, o.y, o.z}, dv[3] = {d.x, d.y, d.z}, lov[3] = {B.lo.x, B.lo.y, B.lo.z}, hiv[3] = {B.hi.x, B.hi.y, B.hi.z};
-    for (int a = 0; a < 3; a++) {
-        if (fabsf(dv[a]) > 1.0e-9f) {
-            const float inv = 1.0f / dv[a], t0 = (lov[a] - ov[a]) * inv, t1 = (hiv[a] - ov[a]) * inv;
-            tA = gl_max(tA, gl_min(t0, t1));
-            tB = gl_min(tB, gl_max(t0, t1));
-        } else if (ov[a] < lov[a] || ov[a] > hiv[a]) {
-            inside = false;       // moves less than 1e-3 along this axis over any length that matters, and starts outside
-        }
-    }
-    inside = inside && tA <= tB;
+    const float invv[3] = {B.inv.x, B.inv.y, B.inv.z};
     uint32_t acc[RT_SLAB_MAX_WORDS] = {0u, 0u, 0u, 0u};
-    if (RT_ANY(inside)) {
-        const float dt = (tB - tA) * (1.0f / RT_SLAB_SEGMENTS);
-        const float invv[3] = {B.inv.x, B.inv.y, B.inv.z};
+    // Pass 1 (scenes with tori; round 6, the "behind" rule of torus_cull): the part of the LINE behind the origin, up to the backward reach --
+    // a torus there is a candidate too (its own first-level test decides whether the origin is far enough for that to matter). Torus words only.
+    const int nws = (S.h->n_surface + 31) >> 5;
+#if defined(RT_AB_NO_SLAB_BACK)  /* measurement only (NOT exact): what the backward walk costs */
+    const int passes = 1;
+#else
+    const int passes = RT_TORUS_BEHIND_RULE && S.h->n_torus > 0 ? 2 : 1;
+#endif
+#pragma unroll 1
+    for (int pass = 0; pass < passes; pass++) {
+        const float sg = pass ? -1.0f : 1.0f;
+        float tA = 0.0f, tB = pass ? RT_TORUS_REACH_BACK * 1.001f + 0.01f : tB_forward;
+        bool inside = true;
+        for (int a = 0; a < 3; a++) {
+            const float da = dv[a] * sg;
+            if (fabsf(da) > 1.0e-9f) {
+                const float inv = 1.0f / da, t0 = (lov[a] - ov[a]) * inv, t1 = (hiv[a] - ov[a]) * inv;
+                tA = gl_max(tA, gl_min(t0, t1));
+                tB = gl_min(tB, gl_max(t0, t1));
+            } else if (ov[a] < lov[a] || ov[a] > hiv[a]) {
+                inside = false;       // moves less than 1e-3 along this axis over any length that matters, and starts outside
+            }
+        }
+        inside = inside && tA <= tB;
+        if (!RT_ANY(inside)) continue;
+        const int nseg = pass ? RT_SLAB_BACK_SEGMENTS : RT_SLAB_SEGMENTS;
+        const float dt = (tB - tA) * (1.0f / (float)nseg);
         int i0[3];
-        for (int a = 0; a < 3; a++) i0[a] = slab_index(fmaf(dv[a], tA, ov[a]), lov[a], invv[a]);
-        for (int j = 1; j <= RT_SLAB_SEGMENTS; j++) {
-            const float t = j == RT_SLAB_SEGMENTS ? tB : fmaf(dt, (float)j, tA);
+        for (int a = 0; a < 3; a++) i0[a] = slab_index(fmaf(dv[a] * sg, tA, ov[a]), lov[a], invv[a]);
+        for (int j = 1; j <= nseg; j++) {
+            const float t = j == nseg ? tB : fmaf(dt, (float)j, tA);
             uint32_t seg[RT_SLAB_MAX_WORDS] = {~0u, ~0u, ~0u, ~0u};
             for (int a = 0; a < 3; a++) {
-                const int i1 = slab_index(fmaf(dv[a], t, ov[a]), lov[a], invv[a]);
+                const int i1 = slab_index(fmaf(dv[a] * sg, t, ov[a]), lov[a], invv[a]);
                 const int lo = i0[a] < i1 ? i0[a] : i1, hi = i0[a] < i1 ? i1 : i0[a];
                 const int lvl = 31 - __builtin_clz((unsigned)(hi - lo + 1));
                 const uint32_t* e0 = T + (size_t)((a * RT_SLAB_LEVELS + lvl) * RT_SLABS + lo) * W;
@@ -1609,7 +1695,7 @@ RT_HD void slab_ray_mask(const SceneView& S, f3 ro, f3 rd, float tlimit, uint32_
                     if (w < W) seg[w] &= e0[w] | e1[w];
                 i0[a] = i1;
             }
-            for (int w = 0; w < RT_SLAB_MAX_WORDS; w++) acc[w] |= inside ? seg[w] : 0u;
+            for (int w = 0; w < RT_SLAB_MAX_WORDS; w++) acc[w] |= inside && (pass == 0 || w >= nws) ? seg[w] : 0u;
         }
     }
     for (int w = 0; w < RT_SLAB_MAX_WORDS; w++)

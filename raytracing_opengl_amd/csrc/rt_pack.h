@@ -567,13 +567,29 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
         const float R = rdf(p, 96), r = rdf(p, 100);
         const float R2 = R * R, r2 = r * r;
         s.radii = mk4(R, r, R2, r2);
-        const double rb = (std::fabs(static_cast<double>(R)) + std::fabs(static_cast<double>(r))) * 1.01 + 0.01;
-        const double hole = (std::fabs(static_cast<double>(R)) - std::fabs(static_cast<double>(r))) * 0.99 - 0.01;
-        s.k = mk4(4.0f * R2, static_cast<float>(rb * rb), static_cast<float>(rb * rb), hole > 0.0 ? static_cast<float>(hole * hole) : 0.0f);
+        // The inflated tube every cull tests against: radius rinf = max(1.01 |r| + 0.01, sqrt(r^2 + RT_TORUS_IM_NOISE^2)). The second term (round 6):
+        // a ray that clears a tube of radius r by delta has a complex root pair with |Im| = sqrt(delta (2 r + delta)), and the reference's solver,
+        // run from tens of units away, reports an iterate as real (|Im| <= 1e-3) although the pair's imaginary part is up to ~0.05 (rt_device.h
+        // RT_TORUS_IM_NOISE) -- for a thin tube that is a clearance of several centimetres, more than the 1 cm + 1 % of rounds 2-5, which had
+        // only been audited on tori of R 0.3 .. 2 (tests/random_scenes.py sized_torus_scene found it). For r >= 0.3 the first term still governs.
+        const double ar = std::fabs(static_cast<double>(r)), aR = std::fabs(static_cast<double>(R));
+        const double rinf = std::fmax(ar * 1.01 + 0.01, std::sqrt(ar * ar + static_cast<double>(RT_TORUS_IM_NOISE) * RT_TORUS_IM_NOISE));
+        const double rb = aR * 1.01 + rinf + 0.01 * ar;              // bounding sphere / puck radius: >= (|R| + |r|) 1.01 + 0.01
+        const double hole = aR * 0.99 - rinf - 0.01 * ar;            // <= (|R| - |r|) 0.99 - 0.01
+        // k.y: the "behind" rule's NEAR distance (squared) of the local culls (rt_device.h torus_local_cull) -- what the torus' own size allows:
+        // the float noise of a Durand-Kerner step grows as |o|^4 / (r R^2), so near^4 = RT_TORUS_NEAR_K r R^2, never below the size-blind value
+        // of the first-level test (torus_near2 of the bound) and never above the 4 units the measurement supports
+        const float near_w2 = torus_near2(static_cast<float>(rb * rb));
+        const double near_k2 = std::sqrt(static_cast<double>(RT_TORUS_NEAR_K) * ar * aR * aR);
+        s.k = mk4(4.0f * R2, std::fmax(near_w2, static_cast<float>(std::fmin(near_k2, 16.0))), static_cast<float>(rb * rb), hole > 0.0 ? static_cast<float>(hole * hole) : 0.0f);
         s.qinv = quat_inv(s.quat);
         // y, z: the convex-hull cull of torus_local_cull -- (|r| + margin)^2 and |R|
-        const double hull = std::fabs(static_cast<double>(r)) + RT_TORUS_HULL_MARGIN;
-        s.cull = mk4(static_cast<float>(std::fabs(static_cast<double>(r)) * 1.01 + 0.01), static_cast<float>(hull * hull), std::fabs(R), static_cast<float>(hull));
+        // (round 6: + 3e-6 / min(|r|, |R|). The iteration stops once a sweep moves every iterate by less than 1e-3; its last, quadratic step then leaves an
+        // error of about 1e-6 / (distance to the next root), and the next root of a ray that has just left the surface is about one tube width
+        // away -- 1e-5 for r = 0.3, inside the margin, but 3.6e-4 for a tube of r = 0.0028, whose own shadow rays then "hit" it at t = 1e-5 .. 3e-4
+        // from 2.5e-4 outside the hull: 18 rays in 2e10 on one torus of tests/random_scenes.py sized_torus_scene(14).)
+        const double hull = ar + RT_TORUS_HULL_MARGIN + 3.0e-6 / std::fmin(ar, aR);
+        s.cull = mk4(static_cast<float>(rinf), static_cast<float>(hull * hull), std::fabs(R), static_cast<float>(hull));
         // The culls rest on "a geometric miss makes Durand-Kerner report no root". That holds for tori with a real tube
         // (validated on random rays), but not for degenerate ones: with tube radius 0 the solver, out of sweeps, can stop
         // on an iterate whose imaginary part happens to be below 1e-3 far away from the (zero-thickness) torus -- found by
@@ -594,7 +610,7 @@ inline bool pack_scene(const Defines& d, const std::vector<unsigned char> blocks
             s.cull.x = inf; s.cull.y = inf;
         }
         std::memcpy(reinterpret_cast<DevTorus*>(blob.data() + h.off_torus) + i, &s, sizeof s);
-        const f4 tb = mk4(s.pos.x, s.pos.y, s.pos.z, s.k.y);
+        const f4 tb = mk4(s.pos.x, s.pos.y, s.pos.z, s.k.z);
         std::memcpy(reinterpret_cast<f4*>(blob.data() + h.off_torus_bound) + i, &tb, sizeof tb);
         std::memcpy(mat_at(TYPE_TORUS, i), p, 64);
     }

@@ -30,6 +30,8 @@ const char* ncclGetErrorString(ncclResult_t);
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -176,6 +178,8 @@ struct rtx_context {
     void* d_packed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [target][frame parity] this rank's packed bands, on its own device
     std::vector<void*> d_stage[2][2];  // root only: [target][frame parity][rank] landing buffers for the peers' bands, on the root's device
     ncclComm_t comm = nullptr;
+    rtbands::ConfigDigest cfg_confirmed;   // rtx_create_rank: the frame configuration the ranks last agreed on (config_handshake)
+    void* d_cfg = nullptr;             // its 16-byte messages: slot r = rank r's digest (root) / own digest + verdict (peer)
     hipStream_t xfer_stream = nullptr; // sends (peers) / receives + band placement (root) run here, beside the next frame's trace
     hipEvent_t traced[2] = {nullptr, nullptr}, moved[2] = {nullptr, nullptr};   // per frame parity: bands traced / buffers free again
     unsigned frame_no = 0;
@@ -618,6 +622,99 @@ inline rtx_context* rank_ctx(rtx_context* ctx, int r) { return r == 0 ? ctx : ct
 inline size_t target_bytes(int t) { return rtbands::target_bytes(t); }   // target 0 = RGBA32F, 1 = RGBA8 (band_math.h)
 inline bool uses_rccl(const rtx_context* ctx) { return ctx->gather_kind != RTX_GATHER_PEER_COPY; }
 
+// ---- waits that cannot hang the process, and the ranks' first contact ----------------------------------------------
+// RTX_GATHER_TIMEOUT_MS (default 30 000; 0 = wait for ever, the behaviour of rounds 1-5): how long a wait on a transfer stream may take. A
+// band whose peer never issued the matching ncclSend / ncclRecv -- or issued it with other byte counts -- never completes; the wait then
+// ends with RTX_ERR_DEVICE and a message instead of a hung process.
+double gather_timeout_ms()
+{
+    static const double v = [] {
+        const char* e = std::getenv("RTX_GATHER_TIMEOUT_MS");
+        return e && *e ? std::atof(e) : 30000.0;
+    }();
+    return v;
+}
+int wait_stream_bounded(rtx_context* c, hipStream_t s, const char* what, int peer = -1)
+{
+    if (!s) return RTX_OK;
+    if (!c->banded || !uses_rccl(c)) { HIP_TRY(hipStreamSynchronize(s)); return RTX_OK; }   // nothing on it waits for another process
+    hipError_t bad = hipSuccess;
+    int polls = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok = rtbands::bounded_wait(
+        [&] { const hipError_t e = hipStreamQuery(s); if (e == hipSuccess) return true; if (e != hipErrorNotReady) { bad = e; return true; } return false; },
+        [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); },
+        [&] { if (++polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); },
+        gather_timeout_ms());
+    if (bad != hipSuccess) return fail(RTX_ERR_DEVICE, "%s: %s", what, hipGetErrorString(bad));
+    if (ok) return RTX_OK;
+    if (peer >= 0)
+        return fail(RTX_ERR_DEVICE, "%s: rank %d did not answer rank %d within %.0f ms (RTX_GATHER_TIMEOUT_MS) -- is every rank making the same calls in the same order?",
+                    what, peer, c->rank, gather_timeout_ms());
+    return fail(RTX_ERR_DEVICE, "%s: the transfer stream of rank %d (of %d) did not finish within %.0f ms (RTX_GATHER_TIMEOUT_MS): a peer has not issued the matching "
+                "ncclSend / ncclRecv, or issued it with other byte counts (band layout, split, RTX_OPT_GATHER_RGB and RTX_OPT_GATHER_TARGETS must be set on EVERY rank)",
+                what, c->rank, c->n_total, gather_timeout_ms());
+}
+rtbands::FrameConfig frame_config(const rtx_context* me)
+{
+    rtbands::FrameConfig fc;
+    fc.width = me->width; fc.height = me->height; fc.n_ranks = me->n_total; fc.band_rows = me->band_rows; fc.band_layout = me->band_layout;
+    fc.gather_targets = me->gather_targets; fc.gather_rgb = me->gather_rgb; fc.loopback = me->loopback ? 1 : 0;
+    if (me->band_layout != 0) fc.split_rows = me->split_rows;
+    return fc;
+}
+// Ranks in separate processes: before a band travels under a configuration this rank has not had confirmed, the ranks compare 16-byte
+// digests of it (band_math.h): peer -> rank 0, rank 0 -> verdict to every peer. Fixed-size messages that pair whatever the configurations
+// are; a rank that does not take part shows up as a timeout that names it. Costs two small messages, only when something changed.
+int config_handshake(rtx_context* me)
+{
+    if (!me->per_process || !me->banded || me->loopback || me->n_total < 2 || !uses_rccl(me)) return RTX_OK;
+    const rtbands::ConfigDigest mine = rtbands::config_digest(frame_config(me));
+    if (mine == me->cfg_confirmed) return RTX_OK;
+    int st = use_device(me);
+    if (st) return st;
+    const int N = me->n_total;
+    const size_t slot = 16;
+    if (!me->d_cfg) HIP_TRY(hipMalloc(&me->d_cfg, slot * static_cast<size_t>(2 * N + 2)));
+    auto at = [&](int k) { return static_cast<void*>(static_cast<char*>(me->d_cfg) + slot * static_cast<size_t>(k)); };
+    unsigned long long msg[2] = {mine.a, mine.b};
+    HIP_TRY(hipMemcpyAsync(at(0), msg, slot, hipMemcpyHostToDevice, me->xfer_stream));
+    if (me->rank != 0) {
+        NCCL_TRY(g_rccl.GroupStart());
+        NCCL_TRY_IN_GROUP(g_rccl.Send(at(0), slot, ncclUint8, 0, me->comm, me->xfer_stream));
+        NCCL_TRY_IN_GROUP(g_rccl.Recv(at(1), slot, ncclUint8, 0, me->comm, me->xfer_stream));
+        NCCL_TRY(g_rccl.GroupEnd());
+        if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check", 0)) != RTX_OK) return st;
+        unsigned long long verdict[2] = {0, 0};
+        HIP_TRY(hipMemcpy(verdict, at(1), slot, hipMemcpyDeviceToHost));
+        if (verdict[0] != 0)
+            return fail(RTX_ERR_INVALID, "frame configuration of rank %d differs from rank 0's (this is rank %d): frame size, rank count, RTX_OPT_BAND_LAYOUT, the band split, "
+                        "RTX_OPT_GATHER_TARGETS and RTX_OPT_GATHER_RGB must be the same on every rank", static_cast<int>(verdict[0]) - 1, me->rank);
+    } else {
+        for (int r = 1; r < N; r++) {      // one peer at a time: a rank that never calls is named by the timeout
+            NCCL_TRY(g_rccl.Recv(at(r), slot, ncclUint8, r, me->comm, me->xfer_stream));
+            if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check", r)) != RTX_OK) return st;
+        }
+        std::vector<rtbands::ConfigDigest> all(static_cast<size_t>(N));
+        std::vector<unsigned long long> host(static_cast<size_t>(2 * N));
+        HIP_TRY(hipMemcpy(host.data(), me->d_cfg, slot * static_cast<size_t>(N), hipMemcpyDeviceToHost));
+        for (int r = 0; r < N; r++) { all[r].a = host[2 * r]; all[r].b = host[2 * r + 1]; }
+        all[0] = mine;
+        const int wrong = rtbands::config_first_mismatch(all);
+        unsigned long long verdict[2] = {wrong < 0 ? 0ull : static_cast<unsigned long long>(wrong) + 1ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(at(N), verdict, slot, hipMemcpyHostToDevice, me->xfer_stream));
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int r = 1; r < N; r++) NCCL_TRY_IN_GROUP(g_rccl.Send(at(N), slot, ncclUint8, r, me->comm, me->xfer_stream));
+        NCCL_TRY(g_rccl.GroupEnd());
+        if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check (verdicts)")) != RTX_OK) return st;
+        if (wrong >= 0)
+            return fail(RTX_ERR_INVALID, "frame configuration of rank %d differs from rank 0's: frame size, rank count, RTX_OPT_BAND_LAYOUT, the band split, "
+                        "RTX_OPT_GATHER_TARGETS and RTX_OPT_GATHER_RGB must be the same on every rank", wrong);
+    }
+    me->cfg_confirmed = mine;
+    return RTX_OK;
+}
+
 int rows_of_rank(const rtx_context* root, int rank)
 {
     if (root->band_layout != 0 && rank < static_cast<int>(root->split_rows.size())) return root->split_rows[rank];
@@ -705,6 +802,7 @@ int multi_draw_contiguous(rtx_context* me)
     int st;
     if (static_cast<int>(me->split_rows.size()) != N) split_equal(me);
     if (me->band_layout == 2) rebalance(me);
+    if ((st = config_handshake(me)) != RTX_OK) return st;
     for (rtx_context* c : local)
         if (c->rank >= first_moved && (st = ensure_packed(c, me)) != RTX_OK) return st;
     const size_t W = static_cast<size_t>(me->width);
@@ -789,6 +887,7 @@ int multi_draw_contiguous(rtx_context* me)
 int multi_draw(rtx_context* me)
 {
     if (me->band_layout != 0) return multi_draw_contiguous(me);
+    { const int hs = config_handshake(me); if (hs) return hs; }
     const int N = n_ranks(me), par = rtbands::buffer_set(me->frame_no);
     const bool root_here = me->rank == 0;
     const int first_moved = me->loopback ? 0 : 1;   // first rank whose bands go through the transport
@@ -888,8 +987,7 @@ int multi_sync(rtx_context* root)
     if (!root->banded) return RTX_OK;
     int st = use_device(root);
     if (st) return st;
-    HIP_TRY(hipStreamSynchronize(root->xfer_stream));
-    return RTX_OK;
+    return wait_stream_bounded(root, root->xfer_stream, "gather");
 }
 
 // the packed band buffers, transfer stream and events of one rank (on its own device); `frame` supplies size, rank count and transport
@@ -1199,10 +1297,10 @@ void rtx_destroy(rtx_context* ctx)
     if (!ctx) return;
     for (rtx_context* p : ctx->peers) {
         (void)hipSetDevice(p->device);
-        if (p->xfer_stream) (void)hipStreamSynchronize(p->xfer_stream);
+        if (p->xfer_stream) (void)wait_stream_bounded(p, p->xfer_stream, "rtx_destroy");
     }
     (void)hipSetDevice(ctx->device);
-    if (ctx->xfer_stream) (void)hipStreamSynchronize(ctx->xfer_stream);
+    if (ctx->xfer_stream) (void)wait_stream_bounded(ctx, ctx->xfer_stream, "rtx_destroy");   // (a transfer that will never complete must not hang the exit)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (rtx_context* p : ctx->peers) {
         if (!uses_rccl(ctx)) p->moved[0] = p->moved[1] = nullptr;   // shared with the root's events in peer-copy mode
@@ -1223,6 +1321,7 @@ void rtx_destroy(rtx_context* ctx)
         if (ctx->traced[p]) (void)hipEventDestroy(ctx->traced[p]);
         if (ctx->moved[p]) (void)hipEventDestroy(ctx->moved[p]);
     }
+    if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
     if (ctx->gather_start) (void)hipEventDestroy(ctx->gather_start);
     if (ctx->gather_stop) (void)hipEventDestroy(ctx->gather_stop);
     if (ctx->xfer_stream) (void)hipStreamDestroy(ctx->xfer_stream);
@@ -1379,6 +1478,9 @@ int rtx_cubemap_create(rtx_context* ctx, int face_size, int channels, const uint
                 const size_t n = (l + 1 < t.levels ? off[l + 1] : chain[0].size()) - off[l];
                 for (int f = 0; f < 6; f++) host.insert(host.end(), chain[f].begin() + off[l], chain[f].begin() + off[l] + static_cast<std::ptrdiff_t>(n));
             }
+            // A face that failed to load (GLWrapper.cpp:296-305 skips it) leaves the texture cube-incomplete: glGenerateMipmap raises
+            // GL_INVALID_OPERATION, and with a mip-mapping minification filter an incomplete texture samples (0, 0, 0, 1) on EVERY face.
+            if (t.face_mask != 0x3f) t.face_mask = 0;
         }
         t.dwords = host.size();
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_texels), t.dwords * 4));
@@ -1602,7 +1704,7 @@ int rtx_finish(rtx_context* ctx)
     for (rtx_context* p : ctx->peers) {
         if ((st = use_device(p)) != RTX_OK) return st;
         HIP_TRY(hipStreamSynchronize(p->stream));
-        HIP_TRY(hipStreamSynchronize(p->xfer_stream));
+        if ((st = wait_stream_bounded(p, p->xfer_stream, "gather (peer)")) != RTX_OK) return st;
     }
     return multi_sync(ctx);   // the root's (or this process' rank's) transfer stream
 }
@@ -1759,6 +1861,29 @@ RTX_API int rtx_sum_recent_draw_ms(rtx_context* ctx, int n, float* sum_ms)
         float v = 0.0f;
         if ((st = sum_recent_one(p, n, &v)) != RTX_OK) return st;
         if (v > *sum_ms) *sum_ms = v;
+    }
+    return use_device(ctx);
+}
+
+// The same durations one by one (most recent first), without retiring them: a bench that wants the spread of its K draws (min / median /
+// max) calls this BEFORE rtx_sum_recent_draw_ms. A multi-device context reports, per draw, the slowest rank.
+RTX_API int rtx_recent_draw_ms(rtx_context* ctx, int n, float* ms_each)
+{
+    if (!ctx || !ms_each || n <= 0) return fail(RTX_ERR_INVALID, "rtx_recent_draw_ms: bad arguments");
+    for (int k = 0; k < n; k++) ms_each[k] = 0.0f;
+    std::vector<rtx_context*> all{ctx};
+    all.insert(all.end(), ctx->peers.begin(), ctx->peers.end());
+    for (rtx_context* c : all) {
+        if (n > c->ev_pending) return fail(RTX_ERR_INVALID, "rtx_recent_draw_ms: %d draws requested, %d pending", n, c->ev_pending);
+        int st = use_device(c);
+        if (st) return st;
+        for (int k = 0; k < n; k++) {
+            const int idx = (c->ev_head - 1 - k + EVENT_RING * 2) % EVENT_RING;
+            HIP_TRY(hipEventSynchronize(c->ev_stop[idx]));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_start[idx], c->ev_stop[idx]));
+            if (ms > ms_each[k]) ms_each[k] = ms;
+        }
     }
     return use_device(ctx);
 }

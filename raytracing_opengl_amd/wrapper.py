@@ -224,6 +224,12 @@ class GLWrapper:
         _check(self._lib.rtx_get_rank_draw_ms(self._ctx, arr, n), "get_rank_draw_ms")
         return list(arr)
 
+    def recent_draw_ms(self, n: int):
+        """HIP-event durations (ms) of the n most recent draws, most recent first; does not retire them."""
+        arr = (ctypes.c_float * n)()
+        _check(self._lib.rtx_recent_draw_ms(self._ctx, n, arr), "recent_draw_ms")
+        return [float(v) for v in arr]
+
     def sum_recent_draw_ms(self, n: int) -> float:
         v = ctypes.c_float()
         _check(self._lib.rtx_sum_recent_draw_ms(self._ctx, n, ctypes.byref(v)), "sum_recent_draw_ms")

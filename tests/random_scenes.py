@@ -219,3 +219,23 @@ def pencil_scene(seed: int, w: int, h: int):
                 m = material(tuple(rng.random(3) * 0.9 + 0.1), int(rng.integers(0, 200)), float(rng.choice([0.1, 0.5, 1.0])))
             planes.append(plane(nrm, pos, m))
     return crowd_scene(seed, w, h, lights=(lights_point, lights_direct), camera=(cam_pos, cam_quat), planes_override=planes)
+
+
+def sized_torus_scene(seed: int, w: int, h: int):
+    """Tori of every SIZE (round 6: what the torus culls call a near or a far origin scales with the torus -- rt_device.h torus_near2): major radius
+    log-uniform over 0.04 .. 25, tube 4 % .. 140 % of it (ring, horn and spindle tori), random rotations, a floor, one light of each kind. The other
+    generators draw R in 0.3 .. 2 only. Used by tools/cull_audit.py (torus families) and the fuzz tests."""
+    rng = np.random.default_rng(seed ^ 0x51ced)
+    depth = int(rng.integers(1, 5))
+    toruses = []
+    for _ in range(int(rng.integers(3, 7))):
+        R = float(np.exp(rng.uniform(np.log(0.04), np.log(25.0))))
+        r = float(R * np.exp(rng.uniform(np.log(0.04), np.log(1.4))))
+        p = (float(rng.normal() * (4.0 + 2.0 * R)), float(rng.normal() * (2.0 + R)), float(8.0 + 3.0 * R + rng.normal() * 3.0))
+        toruses.append(torus(p, R, r, _mat(rng), quat=_quat(rng)))
+    spheres = [sphere(_pos(rng, 6.0, 9.0), float(rng.random() * 0.9 + 0.2), _mat(rng)) for _ in range(int(rng.integers(0, 3)))]
+    planes = [plane((0, 1, 0), (0, -30.0, 0), _mat(rng))] if rng.random() < 0.5 else []
+    lights_point = [light_point((3.0, 15.0, -2.0), 0.1, intensity=60.0)]
+    lights_direct = [light_direct((1.0, -2.0, 1.5))]
+    return make_scene(w, h, depth, spheres=spheres, planes=planes, toruses=toruses, lights_point=lights_point, lights_direct=lights_direct,
+                      cam_pos=(0.0, 0.0, -6.0), cam_quat=(0.0, 0.0, 0.0, 1.0))

@@ -149,6 +149,7 @@ def _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img):
         for uniform, levels in ref["gl_mips"].items():
             O.set_mip_levels(uniform, levels)
     ok = np.zeros((h, w), bool)
+    width = np.zeros((h, w))      # how wide the envelope is at each pixel (largest channel): a claim inside a WIDE envelope says little, so it is reported
     try:
         for y0 in sorted({int(y) & ~1 for y in np.argwhere(cand)[:, 0]}):
             y1 = min(y0 + 2, h)
@@ -160,10 +161,11 @@ def _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img):
                         lo, hi = np.fmin(lo, v), np.fmax(hi, v)
             r = ref["frame"][y0:y1, :, :3].astype(np.float64); c = img[y0:y1, :, :3].astype(np.float64)
             ok[y0:y1] = ((r >= lo - LOD_PAD) & (r <= hi + LOD_PAD)).all(-1) & ((c >= lo - LOD_PAD) & (c <= hi + LOD_PAD)).all(-1)
+            width[y0:y1] = (hi - lo).max(-1)
     finally:
         if gl_mips:
             oracle.OracleScene.drop_mips()
-    return ok
+    return ok, width
 
 
 def classify(ref: dict, candidate: np.ndarray | None = None, texture_lod: int = 1, tex_tol: float = 0.0, threads: int = 8, gl_mips: bool = False,
@@ -225,9 +227,13 @@ def classify(ref: dict, candidate: np.ndarray | None = None, texture_lod: int = 
     cand = left & ((tags & oracle.TAG_TEXTURE) != 0) & (((tags & oracle.TAG_QUAD_DIVERGENT) != 0) | quad_any)
     out["divergent_alpha"] = 0
     out["divergent_alpha_candidates"] = int(cand.sum())
+    out["divergent_alpha_envelope_width"] = 0.0      # the widest envelope a claim of this class was made in (a wide one excuses a lot)
     if cand.any() and int(cand.sum()) <= PAIR_MAX_PIXELS and lod_lo is not None and any(u == "texture_ring" for u, _n, _i in ref["textures"]):
-        pair_ok = _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img)
+        pair_ok, pair_width = _pair_envelope_ok(ref, texture_lod, gl_mips, threads, cand, img)
+        claimed = left & cand & pair_ok
         claim("divergent_alpha", cand & pair_ok)
+        if claimed.any():
+            out["divergent_alpha_envelope_width"] = float(pair_width[claimed].max())
     claim("texture", ((tags & oracle.TAG_TEXTURE) != 0) & (d <= tex_tol))
     if tex_level_envelope and lod_lo is not None:
         # texture_level: a mip-mapped fetch whose value differs by more than tex_tol although every quad neighbour was present: the two

@@ -558,8 +558,14 @@ def _far_rays():
 
 
 def far_ray_scene(name):
+    """The scene a recorded ray names: generator:seed of tests/random_scenes.py at 96 x 64, or bench:<recipe> as tools/cull_audit.py scene_list builds it."""
     import random_scenes as rs
+    from raytracing_opengl_amd import scenes as pkg_scenes
     gen, seed = name.split(":")
+    if gen == "bench":
+        if seed == "default t=7.5":
+            return pkg_scenes.build_scene("default", 640, 480, 4, time=7.5, delta=0.016)
+        return pkg_scenes.build_scene(seed, 640, 480, 6 if seed == "torus" else 4)
     return getattr(rs, gen)(int(seed), 96, 64)
 
 
@@ -610,7 +616,15 @@ def test_torus_culls_never_use_the_rays_own_limit(built):
             assert hit == ohit and (not hit or t == ot), (dist, limit, hit, t, ohit, ot)
             if dist <= 20.0:
                 assert hit == (limit > dist) and (not hit or abs(t - (dist - 0.3)) < 2e-3), (dist, limit, hit, t)
-        assert harness.kat(oracle.TYPE_TORUS, rec, ro, (0.0, 0.0, 1.0), 1e6)[2], "a torus behind the origin is culled"
+        # "behind" (round 6): a torus the ray points away from is culled from a NEAR origin (within (600 r R^2)^(1/4) = 3.66 of this torus' centre)
+        # and from beyond the backward reach; from a far origin whose backward extension goes through the tube the solver runs, as in the
+        # reference (rt.frag:462-487 never culls; tests/golden/torus_behind_rays.json is what it then sometimes reports) -- and what it says stands
+        bhit, bt, bculled = harness.kat(oracle.TYPE_TORUS, rec, ro, (0.0, 0.0, 1.0), 1e6)
+        assert bculled == (dist <= 3.6 or dist >= 150.0), dist
+        ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, ro, (0.0, 0.0, 1.0), 1e6)
+        assert bhit == ohit and (not bhit or bt == ot), (dist, bhit, bt, ohit, ot)
+        if dist <= 150.0:   # the line behind the origin passes 3 units beside the torus: culled from any distance
+            assert harness.kat(oracle.TYPE_TORUS, rec, (3.0, 1.0, dist), (0.0, 0.0, 1.0), 1e6)[2], "a torus behind the origin and beside the line is culled"
         if dist <= 150.0:   # (from 5 000 units out the discriminant's rounding doubt, 1e-5 |oc|^2, exceeds what the line misses the sphere by)
             assert harness.kat(oracle.TYPE_TORUS, rec, (3.0, 1.0, dist), rd, 1e6)[2], "a torus beside the ray's line is culled"
 
@@ -667,31 +681,32 @@ def _behind_rays():
 def test_the_behind_rays_are_what_the_fixture_says(built):
     """tests/golden/torus_behind_rays.json: the oracle's literal Durand-Kerner (rt.frag:462-487) reports the recorded phantom root on both rays,
     the device's literal solve reports the same root bit for bit, the torus lies BEHIND the origin (the line's closest approach to its centre
-    is at a negative t, more than 20 units back), and the product's cull rejects the ray -- the known residual, stated, not hidden."""
-    import random_scenes
+    is at a negative t), and -- since round 6 -- the product's culls let the ray through to the solver."""
     for r in _behind_rays():
-        gen, seed = r["scene"].split(":")
-        sc = getattr(random_scenes, gen)(int(seed), 96, 64)
+        sc = far_ray_scene(r["scene"])
         rec = sc.blocks["toruses_buf"][r["prim"] * 112:(r["prim"] + 1) * 112]
         ohit, ot, _ = _isect(oracle.TYPE_TORUS, rec, r["ro"], r["rd"], r["tmin"])
         dhit, dt, dcull = harness.kat(oracle.TYPE_TORUS, rec, r["ro"], r["rd"], r["tmin"])
         assert ohit and dhit and ot == dt == np.float32(r["t"])
         pos = np.array(struct.unpack_from("<3f", rec, 80))
         o, d = np.array(r["ro"]) - pos, np.array(r["rd"])
-        assert -(o @ d) < -20.0 and np.linalg.norm(o - (o @ d) * d) < 1.0       # the line goes through the torus, 20+ units behind the origin
-        assert dcull
+        assert -(o @ d) < -3.0 and np.linalg.norm(o - (o @ d) * d) < 2.0        # the line goes through the torus, behind the origin
+        assert not dcull                                                        # (round 6; rounds 2-5 culled it: the residual this fixture recorded)
 
 
-@pytest.mark.xfail(strict=True, reason="known residual of the torus culls (DESIGN.md section 3, 'behind' rays): the reference's solver has the four negative "
-                                       "roots 26 / 54 units back, cannot meet its stop criterion in float32, and its 60th sweep throws an iterate to a positive t; the product culls the ray unsolved. "
-                                       "2 rays in 4.2e11 culled ones (profiles/r05zz_cull_audit_torus_8e11_101_scenes.txt); remedy sized in DESIGN.md section 10")
 def test_the_product_reports_the_reference_phantom_hit_on_the_behind_rays(built):
-    """What parity with the reference would demand on those two rays: the product's composition (cull, then solve) reports the reference's hit.
-    It does not -- the day a cull rule exists that lets such rays through to the solver, this test starts passing and strict xfail flags it."""
-    import random_scenes
-    for r in _behind_rays():
-        gen, seed = r["scene"].split(":")
-        sc = getattr(random_scenes, gen)(int(seed), 96, 64)
-        rec = sc.blocks["toruses_buf"][r["prim"] * 112:(r["prim"] + 1) * 112]
-        _hit, _t, culled = harness.kat(oracle.TYPE_TORUS, rec, r["ro"], r["rd"], r["tmin"])
-        assert not culled
+    """What parity with the reference demands on those rays: the product's composition (cull, then solve) reports the reference's hit.
+    Rounds 2-5 culled them unsolved (a strict xfail recorded it); round 6's "behind" rule (rt_device.h torus_cull: a torus behind a FAR origin is
+    culled only where the ray's whole line clears it) lets them through to the solver, whose result is the oracle's bit for bit -- for the
+    torus on its own (kat) and through the product's scans over the whole scene, candidate tables and all, culls on against off (probe)."""
+    rays = _behind_rays()
+    assert len(rays) == 34
+    scenes = {}
+    for r in rays:
+        if r["scene"] not in scenes:
+            scenes[r["scene"]] = far_ray_scene(r["scene"])
+        rec = scenes[r["scene"]].blocks["toruses_buf"][r["prim"] * 112:(r["prim"] + 1) * 112]
+        hit, t, culled = harness.kat(oracle.TYPE_TORUS, rec, r["ro"], r["rd"], r["tmin"])
+        assert not culled and hit and t == np.float32(r["t"])
+        row = harness.probe(scenes[r["scene"]], np.array([r["ro"] + r["rd"] + [r["tmin"], r["prim"]]], dtype=np.float32))
+        check_far_ray_rows(row, [r], scenes, "host build of rt_device.h")

@@ -72,8 +72,9 @@ def test_the_flag_off_and_lod_off_sample_level_zero(small_textures):
 
 
 def test_missing_faces_odd_face_sizes_and_one_texel_faces(small_textures):
-    """A face that failed to load stays black at every level (GLWrapper.cpp:296-305 skips it); a face size that is not a power of two
-    (levels of max(1, n >> L) texels); 1 x 1 faces (a chain of one level)."""
+    """A face that failed to load (GLWrapper.cpp:296-305 skips it) leaves a mip-mapped cube map incomplete: glGenerateMipmap raises
+    GL_INVALID_OPERATION and every face samples (0, 0, 0, 1) -- the frame is the frame of six black faces; a face size that is
+    not a power of two (levels of max(1, n >> L) texels); 1 x 1 faces (a chain of one level)."""
     w, h = 200, 120
     sc = scenes.build_scene("default", w, h, 3, yaw=-120.0, pitch=35.0)
     rng = np.random.default_rng(5)
@@ -84,6 +85,13 @@ def test_missing_faces_odd_face_sizes_and_one_texel_faces(small_textures):
         img, st = _gpu(sc, w, h, tex)
         _judge(img, ref)
         assert st["rays_closest"] == cnt["rays_closest"]
+        if missing:
+            black = dict(textures=small_textures["textures"], cubemap=[np.zeros((n, n, 3), np.uint8) for _ in range(6)])
+            img_black, _ = _gpu(sc, w, h, black)
+            assert np.array_equal(img.view(np.uint32), img_black.view(np.uint32)), "an incomplete mip-mapped cube map samples black on every face"
+            # without mips the missing face alone is black (rounds 1-5): the other faces still show
+            img0, _ = _gpu(sc, w, h, tex, cube_mipmap=False)
+            assert not np.array_equal(img0.view(np.uint32), img_black.view(np.uint32))
 
 
 def test_row_bands_of_a_mip_mapped_sky_equal_the_full_frame(small_textures):

@@ -51,6 +51,11 @@ def _accept(name, r, textured):
     assert r["edge"] <= 3 and r["approx_math"] <= max(3, px // 2000) and r["unstable_between"] <= 8, (name, r)   # the last-resort categories stay marginal
     assert r["unstable_pixels_in_frame"] <= 0.12 * px, (name, r)                         # the envelope-bounded set is a small part of the frame
     assert r["box_nan"] <= allow["box_nan"], (name, r)                                   # the one class without a value bound is not needed by any quarter-size fixture
+    #  the ring-alpha class accepts a pixel anywhere inside an envelope over (top + 1)^3 forced-level renders, which is wide where the
+    # alpha steers the path: it stays a handful of pixels in EVERY fixture, and how wide the widest envelope of a claim was is part of the record
+    assert r.get("divergent_alpha", 0) <= 8, (name, r)
+    if r.get("divergent_alpha", 0):
+        print(f"{name}: {r['divergent_alpha']} pixel(s) claimed by divergent_alpha, widest envelope {r['divergent_alpha_envelope_width']:.3f}")
     if not textured:
         assert r["divergent"] == 0 and r["texture"] == 0 and r["quad_neighbour"] == 0 and r["texture_level"] == 0, (name, r)
     return r

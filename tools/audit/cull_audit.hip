@@ -26,7 +26,7 @@ using namespace rtdev;
 
 namespace {
 
-enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6, F_TORUS_BEHIND = 7 };
+enum { F_TORUS = 0, F_TORUS_MARGIN = 1, F_QUADRIC = 2, F_RING = 3, F_TABLES = 4, F_TORUS_LEAD = 5, F_TORUS_FAR = 6, F_TORUS_BEHIND = 7, F_TORUS_BEHIND_FAR = 8 };
 enum { N_COUNTERS = 128, BAD_FLOATS = 12 };
 
 struct AuditParams {
@@ -245,17 +245,23 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         const bool unit = unit_direction(dot3(d, d));
         const bool c_sphere = torus_cull(bound, ro, rd);
         const bool c_group = grouped && torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd);
-        const bool c_hull = unit && torus_hull_cull(T, o, d);
+        // the local culls as the product composes them (round 6: from a far origin the hull / puck / tube tests of the forward half-line only count
+        // together with the backward half's -- rt_device.h torus_local_cull, the "behind" rule), attributed to the forward test that fired
+        const bool c_local = unit && torus_local_cull<true>(T, o, d);
+        const bool f_hull = unit && torus_hull_cull(T, o, d);
         float pk0 = 0.0f, pk1 = 0.0f;
-        const bool c_puck = unit && torus_puck_cull(T, o, d, pk0, pk1);
-        // the Bernstein test of the inflated tube, behind the puck test: taken from the product's own composition (what the scans call), so that
-        // whatever conditions it puts in front of the test are the ones audited
-        const bool c_tube = unit && !c_hull && !c_puck && torus_local_cull<true>(T, o, d);
+        const bool f_puck = unit && torus_puck_cull(T, o, d, pk0, pk1);
         (void)pk0; (void)pk1;
+        const bool c_hull = c_local && f_hull, c_puck = c_local && !f_hull && f_puck, c_tube = c_local && !f_hull && !f_puck;
         // the premise in its strongest form: the ray's part up to the reference's own reach (t < 100: RT_TORUS_REACH, never the ray's limit --
         // rt_device.h torus_cull) stays 6 mm clear of the REAL tube (exact) -- every cull and every clear bit of a candidate table implies it
-        // (their margins are 1 % + 0.01 and more)
-        const bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01) >= 6.0e-3;
+        // (their margins are 1 % + 0.01 and more); from a far origin (the "behind" rule) the backward half up to RT_TORUS_REACH_BACK as well
+        // (round 6: "6 mm" was 0.6 of the smallest inflation any cull uses, 1 cm -- now 0.6 of the tube's own inflation T.cull.x - |r|, which is 1 cm + 1 %
+        // for r >= 0.3 and grows to RT_TORUS_IM_NOISE for thin tubes: rt_pack.h)
+        const double clear_min = 0.6 * ((double)T.cull.x - fabs((double)T.radii.y));
+        bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01) >= clear_min;
+        if (c_line && RT_TORUS_BEHIND_RULE && dot3(o, o) > 0.98f * T.k.y)       // (T.k.y: the near distance^2 the product's local culls use, rt_pack.h)
+            c_line = ray_tube_clearance(T, o, mk3(-d.x, -d.y, -d.z), (double)RT_TORUS_REACH_BACK * 1.001 + 0.01) >= clear_min;
         const bool any = c_sphere || c_group || c_hull || c_puck || c_tube || c_line;
         c[0]++; c[1] += any; c[2] += c_sphere; c[3] += c_group; c[4] += c_hull; c[5] += c_puck; c[6] += c_line; c[16] += scaled; c[17] += c_tube;
         // product's own composition must agree with the parts (intersect_torus_c<true> is what the scans call)
@@ -285,7 +291,7 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
 //           11: >= 10), 12 VIOLATIONS phantoms beyond the inflation, 13..18 |distance| of the hit point from the surface < 1e-5, < 1e-4, < 1e-3,
 //           < 1e-2, < 1e-1, >= 1e-1; 20 largest phantom clearance (float bits, atomicMax), 21 largest hit-point distance;
 //           22..27 hits by class of t, 28..33 of them reported earlier than 1e-3 t + 0.01 before the ray enters the inflated tube, 34..39 the largest lead
-__device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c, unsigned int& worst, unsigned int& worst_pt, unsigned int* lead_bits)
+__device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c, unsigned int& worst, unsigned int& worst_pt, unsigned int* lead_bits, unsigned int& worst_im)
 {
     const int n = S.h->n_torus;
     if (n == 0) return;
@@ -306,9 +312,13 @@ __device__ void audit_torus_margin(const AuditParams& p, const SceneView& S, uns
         const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
         const double tl = (double)RT_TORUS_REACH * 1.001 + 0.01;     // the reference's own reach: the culls never use the ray's limit
         const double clr = ray_tube_clearance(T, o, d, tl);
-        const double infl = 0.01 * (fabs((double)T.radii.x) + fabs((double)T.radii.y)) + 0.01;
+        const double infl = (double)T.cull.x - fabs((double)T.radii.y);      // the smallest inflation any cull of this torus uses (the puck's half height)
         if (clr <= 0.0) c[2]++;
         else {
+            // |Im| of the complex root pair of a ray that clears a tube of radius r by clr (locally a cylinder): what the solver took for real
+            const double rt_ = fabs((double)T.radii.y);
+            const unsigned ib = __builtin_bit_cast(unsigned, (float)sqrt(clr * (2.0 * rt_ + clr)));
+            worst_im = ib > worst_im ? ib : worst_im;
             int k = 3;
             for (double lim = 1.0e-6; k < 11 && clr >= lim; lim *= 10.0) k++;
             c[k]++;
@@ -384,7 +394,7 @@ __device__ void audit_torus_lead(const AuditParams& p, const SceneView& S, unsig
         const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
         const int b = lead_bin(sqrtf(dot3(o, o)));
         c[10 + b]++;
-        const double infl = 0.01 * ((double)Rm + (double)rt) + 0.01;
+        const double infl = (double)T.cull.x - (double)rt;       // the tube's own inflation (rt_pack.h rinf - r): 1 cm + 1 % for r >= 0.3, up to RT_TORUS_IM_NOISE for thin tubes
         const double tin = ray_tube_first_entry(T, o, d, infl);
         if (tin < 0.0) { c[90 + b]++; record_bad(p, 90, i, ro, rd, RT_MAXDIST, t, 0.0f); }
         else {
@@ -406,8 +416,9 @@ __device__ void audit_torus_lead(const AuditParams& p, const SceneView& S, unsig
 // roots, occasionally ends its 60 sweeps with an iterate thrown to a positive t on the real axis: a phantom hit. The rate where it lives: every ray
 // of this family is such a ray (a point of the tube's surface, jittered; an origin 1.5 ... 100 units from the centre aimed at it, half of them
 // grazing; then the direction REVERSED), every one is solved. bins b = 0..9 of the origin's distance as in the lead family.
-// counters: 0 rays, 1 culled by the product's composition (torus_cull or the local culls), 2 hits reported, 20+b rays per bin, 30+b VIOLATIONS
-//           phantom hits per bin (hit reported, the half-line clears the real tube by more than 1 mm in double arithmetic), 40+b of those: culled
+// counters: 0 rays, 1 culled by the product's composition (torus_cull or the local culls), 2 hits reported, 20+b rays per bin, 30+b phantom hits
+//           per bin (hit reported, the half-line clears the real tube by more than 1 mm in double arithmetic), 40+b VIOLATIONS of those: culled by the
+//           product (round 6: the "behind" rule of rt_device.h torus_cull lets far origins through to the solver -- a phantom that is SOLVED is reproduced)
 __device__ void audit_torus_behind(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
 {
     const int n = S.h->n_torus;
@@ -444,7 +455,49 @@ __device__ void audit_torus_behind(const AuditParams& p, const SceneView& S, uns
         float t = 0.0f;
         if (!intersect_torus(T, ro, rd, tmin, t)) continue;
         c[2]++;
-        if (ray_tube_clearance(T, o, d, 100.11) > 1.0e-3) { c[30 + b]++; c[40 + b] += culled; record_bad(p, 30 + b, i, ro, rd, tmin, t, sqrtf(dot3(o, o))); }
+        if (ray_tube_clearance(T, o, d, 100.11) > 1.0e-3) { c[30 + b]++; c[40 + b] += culled; if (culled) record_bad(p, 40 + b, i, ro, rd, tmin, t, sqrtf(dot3(o, o))); }
+    }
+}
+
+// The backward reach (RT_TORUS_REACH_BACK): the same rays from 104 ... 3000 units out -- the quartic's real roots lie more than 100 units BEHIND the
+// origin. Every ray is solved; a hit is a phantom by construction. bins as in torus_far: < 120, 150, 200, 400, 1000, beyond.
+// counters: 0 rays, 1 culled by the product's composition, 20+b rays per bin, 30+b hits reported per bin, 40+b VIOLATIONS of those: culled
+__device__ void audit_torus_behind_far(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
+{
+    const int n = S.h->n_torus;
+    if (n == 0) return;
+    for (int it = 0; it < p.iters; it++) {
+        const unsigned long long ray = gid * (unsigned long long)p.iters + (unsigned long long)it;
+        Rng R{p.seed * 0x2545f4914f6cdd1dull + ray * 0xd1342543de82ef95ull};
+        const int i = (int)(R.next() % (unsigned long long)n);
+        const DevTorus T = S.tori()[i];
+        if (!(T.cull.y < RT_FLT_MAX)) continue;
+        const float Rm = fabsf(T.radii.x), rt = fabsf(T.radii.y);
+        const float phi = 6.2831853f * R.u01(), th = 6.2831853f * R.u01();
+        const float cp = __cosf(phi), sp = __sinf(phi), ct = __cosf(th), st = __sinf(th);
+        const f3 nl = mk3(ct * cp, ct * sp, st);
+        const f3 sl = mk3((Rm + rt * ct) * cp, (Rm + rt * ct) * sp, rt * st) + mk3(R.gauss(), R.gauss(), R.gauss()) * (R.u01() < 0.5f ? 1.0e-3f : 0.05f * (Rm + rt));
+        const float dist = (100.0f + 1.5f + Rm + rt) * R.logu(1.0f, 30.0f);
+        f3 ol = R.unit() * dist;
+        if (R.u01() < 0.5f) {
+            f3 dl = normalize3(sl - ol);
+            dl = normalize3(dl - nl * (dot3(dl, nl) * (1.0f - 0.1f * R.u01())));
+            ol = sl - dl * dist;
+        }
+        const f3 ro = quat_rotate(T.qinv, ol) + xyz(T.pos);
+        const f3 rd = -normalize3(quat_rotate(T.qinv, normalize3(sl - ol)));       // away from the torus
+        const float tmin = ray_tmin(R);
+        bool culled = torus_cull(S.torus_bound()[i], ro, rd);
+        float t2 = 0.0f;
+        bool solved = false;
+        if (!culled) { intersect_torus_c<true, true>(T, ro, rd, tmin, t2, solved); culled = !solved; }
+        const float dd = length3(ro - xyz(T.pos));
+        const int b = dd < 120.0f ? 0 : dd < 150.0f ? 1 : dd < 200.0f ? 2 : dd < 400.0f ? 3 : dd < 1000.0f ? 4 : 5;
+        c[0]++; c[1] += culled; c[20 + b]++;
+        float t = 0.0f;
+        if (!intersect_torus(T, ro, rd, tmin, t)) continue;
+        c[30 + b]++;
+        if (culled) { c[40 + b]++; record_bad(p, 40 + b, i, ro, rd, tmin, t, dd); }
     }
 }
 
@@ -740,7 +793,14 @@ __device__ void audit_tables(const AuditParams& p, const SceneView& S, unsigned 
                 const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), d = quat_rotate_id(T.quat, ident, rd);
                 // up to the reference's own reach, whatever the ray's limit: no torus cull uses that, so a clear bit must not depend on it either
                 const double clr = ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01);
-                if (!(clr >= 5.0e-3)) { c[11]++; record_bad(p, 11 + kind * 100, i - ns, ro, rd, tlimit, 0.0f, (float)clr); }
+                const double clear_min = T.cull.y < RT_FLT_MAX ? 0.5 * ((double)T.cull.x - fabs((double)T.radii.y)) : 5.0e-3;    // half the tube's own inflation (5 mm for r >= 0.3)
+                if (!(clr >= clear_min)) { c[11]++; record_bad(p, 11 + kind * 100, i - ns, ro, rd, tlimit, 0.0f, (float)clr); }
+                // the "behind" rule (rt_device.h torus_cull): from a far origin the LINE's part behind the origin, up to the backward reach, as well
+                if (RT_TORUS_BEHIND_RULE && T.cull.y < RT_FLT_MAX && dot3(o, o) > T.k.y) {
+                    c[8]++;
+                    const double back = ray_tube_clearance(T, o, mk3(-d.x, -d.y, -d.z), (double)RT_TORUS_REACH_BACK * 1.001 + 0.01);
+                    if (!(back >= clear_min)) { c[12]++; record_bad(p, 12 + kind * 100, i - ns, ro, rd, tlimit, -1.0f, (float)back); }
+                }
             }
         }
     }
@@ -752,9 +812,9 @@ __global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
     const unsigned long long gid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
     unsigned int c[N_COUNTERS];                     // per thread: at most iters x 160 each
     for (int k = 0; k < N_COUNTERS; k++) c[k] = 0u;
-    unsigned int worst = 0u, worst_pt = 0u, lead_bits[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned int worst = 0u, worst_pt = 0u, worst_im = 0u, lead_bits[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     if (p.family == F_TORUS) audit_torus(p, S, gid, c);
-    else if (p.family == F_TORUS_MARGIN) audit_torus_margin(p, S, gid, c, worst, worst_pt, lead_bits);
+    else if (p.family == F_TORUS_MARGIN) audit_torus_margin(p, S, gid, c, worst, worst_pt, lead_bits, worst_im);
     else if (p.family == F_QUADRIC) audit_quadric(p, S, gid, c);
     else if (p.family == F_RING) audit_ring(p, S, gid, c);
     else if (p.family == F_TORUS_LEAD) {
@@ -768,10 +828,12 @@ __global__ __launch_bounds__(256) void audit_kernel(const AuditParams p)
     }
     else if (p.family == F_TORUS_FAR) audit_torus_far(p, S, gid, c);
     else if (p.family == F_TORUS_BEHIND) audit_torus_behind(p, S, gid, c);
+    else if (p.family == F_TORUS_BEHIND_FAR) audit_torus_behind_far(p, S, gid, c);
     else audit_tables(p, S, gid, c);
     flush(p, c);
     if (p.family == F_TORUS_MARGIN && worst) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 20), worst);
     if (p.family == F_TORUS_MARGIN && worst_pt) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 21), worst_pt);
+    if (p.family == F_TORUS_MARGIN && worst_im) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 43), worst_im);
     if (p.family == F_TORUS_MARGIN)
         for (int b = 0; b < 6; b++) if (lead_bits[b]) atomicMax(reinterpret_cast<unsigned int*>(p.counters + 34 + b), lead_bits[b]);
 }
@@ -933,7 +995,7 @@ __attribute__((visibility("default"))) int cull_audit_run(const rtpack::Defines*
     unsigned long long host_cnt[N_COUNTERS];
     TRY(hipMemcpy(host_cnt, d_cnt, sizeof host_cnt, hipMemcpyDeviceToHost));
     for (int k = 0; k < N_COUNTERS; k++) {
-        if ((family == F_TORUS_MARGIN && (k == 20 || k == 21 || (k >= 34 && k < 40))) || (family == F_TORUS_LEAD && ((k >= 60 && k < 70) || (k >= 80 && k < 90)))) counters[k] = counters[k] > host_cnt[k] ? counters[k] : host_cnt[k];
+        if ((family == F_TORUS_MARGIN && (k == 20 || k == 21 || k == 43 || (k >= 34 && k < 40))) || (family == F_TORUS_LEAD && ((k >= 60 && k < 70) || (k >= 80 && k < 90)))) counters[k] = counters[k] > host_cnt[k] ? counters[k] : host_cnt[k];
         else counters[k] += host_cnt[k];
     }
     unsigned int nb = 0;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Static facts about the product kernel <CULL=1,COUNT=0,LDS=0>: instruction mix, registers, spills.
-# usage: [ISA_WPE=7] tools/isa_stats.sh [extra hipcc flags]     (ISA_WPE: which waves-per-SIMD instantiation; default 6 = the light one, 7 = the many-primitive variant)
+# usage: [ISA_HEAVY=1] tools/isa_stats.sh [extra hipcc flags]     (ISA_HEAVY=1: the many-primitive variant <..., HEAVY = true>; default the light one; SKYLOD = false)
 cd "$(dirname "$0")/.."
 OUT=${ISA_OUT:-/tmp/rt_kernel_isa.s}
 cfg() { sed -n "s/^$1[ \t]*?=[ \t]*//p" raytracing_opengl_amd/kernel_build.cfg; }   # the product's own configuration
@@ -9,7 +9,7 @@ python3 - "$OUT" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
 import os
-m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi(\d+)ELb[01]EEEv14RtLaunchParams:', txt) if x.group(1) == os.environ.get('ISA_WPE', '6')]
+m=[x for x in re.finditer(r'rt_trace_kernelILb1ELb0ELb0ELi\d+ELb([01])ELb0EEEv14RtLaunchParams:', txt) if x.group(1) == os.environ.get('ISA_HEAVY', '0')]
 i=m[0].start()
 j=txt.find('.end_amdhsa_kernel',i)
 body=txt[i:j]
