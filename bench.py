@@ -605,7 +605,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=args.lod)
-            cores = os.cpu_count() or 1
+            cores, cpu_quota = oracle.effective_cpus()
             cpu_s, reps = 0.0, 0
             while cpu_s < 10.0 and reps < 20:   # bounded sample: whole frames until >= 10 s of wall time
                 c0 = time.perf_counter()
@@ -614,11 +614,12 @@ def main():
                 reps += 1
             cpu_s /= reps
             # one thread, on a thin slice of rows spread over the frame (SURVEY section 8(d) asks for both figures)
-            rows = sorted({min(H - 1, (H * (2 * j + 1)) // 32) for j in range(16)})
+            # (pairs of rows that make whole 2x2 quads: a single row would run -- and discard -- its quads' other halves)
+            rows = sorted({min(H - 2, ((H * (2 * j + 1)) // 32) & ~1) for j in range(16)})
             c0 = time.perf_counter()
             one_rays = 0
             for y in rows:
-                _r, c1 = o.render(y, y + 1, threads=1)
+                _r, c1 = o.render(y, y + 2, threads=1)
                 one_rays += c1["rays_closest"] + c1["rays_shadow"]
             one_s = time.perf_counter() - c0
             # The oracle applies the quad-derivative texture rule by running every 2x2 quad as four ucontext coroutines -- a checker's
@@ -634,8 +635,11 @@ def main():
                 cpu_model = "unknown"
             out["cpu_baseline"] = {"value": round((cnt["rays_closest"] + cnt["rays_shadow"]) / cpu_s / 1e6, 3), "unit": "Mray/s",
                                    "cores": cores, "kind": "port", "cpu": cpu_model,
+                                   "cores_note": (f"threads used = the CPUs this container may use: {os.cpu_count()} hardware threads visible, cgroup CPU quota "
+                                                  f"{cpu_quota:g}" if cpu_quota else f"threads used = the affinity mask ({os.cpu_count()} hardware threads visible, no cgroup quota)"),
                                    "one_thread": {"value": round(one_rays / one_s / 1e6, 4), "unit": "Mray/s",
-                                                  "sample": f"{len(rows)} rows spread over the frame, {one_s:.2f} s"},
+                                                  "sample": f"{len(rows)} pairs of rows spread over the frame, {one_s:.2f} s"},
+                                   "parallel_efficiency": round((cnt["rays_closest"] + cnt["rays_shadow"]) / cpu_s / (one_rays / one_s) / cores, 3),
                                    "without_quad_coroutines": {"value": round((cnt0["rays_closest"] + cnt0["rays_shadow"]) / plain_s / 1e6, 3), "unit": "Mray/s",
                                                                "sample": f"one full frame with level-0 textures (plain loops, no 2x2-quad coroutines), {plain_s:.2f} s"},
                                    "note": "the oracle is the CHECKER (scalar, contraction-free, quads as coroutines): a baseline for orientation, not a tuned CPU renderer",

@@ -103,7 +103,12 @@ typedef enum rtx_option {
                                 pixel. At N = 2 ... 4 the frame rate of the float target is the rate of the root's links.
                                 The contiguous layouts receive in place and always move whole pixels. A per-process group (rtx_create_rank) must
                                 set the same value on every rank, like RTX_OPT_BAND_LAYOUT and rtx_set_band_split: each process sizes its own
-                                side of the paired ncclSend / ncclRecv from them, and nothing cross-checks the ranks. */
+                                side of the paired ncclSend / ncclRecv from them. Since round 6 the ranks cross-check: whenever a rank's frame
+                                configuration (size, rank count, layout, split, targets, this option) differs from the one last confirmed, the
+                                next rtx_draw first compares 16-byte digests across the ranks and fails with RTX_ERR_INVALID, naming the rank
+                                that differs, before a band travels; waits on the transfer stream are bounded by the environment variable
+                                RTX_GATHER_TIMEOUT_MS (default 30 000; 0 = wait for ever) and end with RTX_ERR_DEVICE naming a rank that
+                                never answered. */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which build of the trace kernel runs: 0 = the default one, 1 = the many-primitive one (group culls, ray
                                 pencils and slab tables compiled in; its own register budget -- 7 waves/SIMD in round 1, hence the
                                 name, 6 now), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */

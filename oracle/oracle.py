@@ -64,6 +64,29 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def effective_cpus():
+    """(n, quota): the CPUs this process may actually use -- the affinity mask capped by the cgroup's CPU quota -- and that quota (None if
+    there is none). The GPU boxes show 256 hardware threads and grant a container 16 CPUs of time (/sys/fs/cgroup/cpu.max = "1600000 100000");
+    256 OpenMP threads inside that quota are SLOWER than 16 (tools/time_oracle_threads.py: 8.3 Mray/s against 13.8 on 32)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 _lib = None
 
 
@@ -188,6 +211,8 @@ class OracleScene:
         lod_force: diagnostic, >= 0: every mip-mapped fetch is sampled at this level of detail (orc_set_lod_force).
         lod_force_site: diagnostic, up to two (sampler uniform, site 0 = hit / 1 = shadow, level): the fetches of those sites at levels of their own."""
         y1 = self.height if y1 is None else y1
+        if threads <= 0:
+            threads = effective_cpus()[0]      # "all cores" = the CPUs this container may use, not the hardware threads it can see
         out = np.empty((y1 - y0, self.width, 4), dtype=np.float32)
         cnt = Counters()
         l = lib()

@@ -9,6 +9,23 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _cpu_budget():
+    """OpenMP's default team is one thread per VISIBLE hardware thread; the GPU boxes show 256 and grant a container 16 CPUs of time (cgroup
+    quota), where 256 threads are slower than 16 (tools/time_oracle_threads.py). The checkers' OpenMP loops (oracle/*.c, tests/host_harness)
+    get the CPUs this container may actually use, unless the caller has set OMP_NUM_THREADS."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.999)))
+    except Exception:
+        pass
+    return n
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))     # before any OpenMP library is loaded
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -133,3 +133,45 @@ def test_rebalanced_frames_still_assemble(lib):
         used = (ctypes.c_int * n)()
         assert lib.bands_sim_contiguous(h, 8, n, None, (ctypes.c_double * n)(*ms), int(rng.integers(2)), used) == 0
         assert sum(used) == h and all(u >= 1 for u in used)
+
+
+def _handshake(lib, cfgs, splits=None, present=None, timeout=50):
+    n = len(cfgs)
+    flat = (ctypes.c_int * (8 * n))(*[v for c in cfgs for v in c])
+    n_split = len(splits[0]) if splits else 0
+    sp = (ctypes.c_int * max(1, n * n_split))(*([v for s in splits for v in s] if splits else [0]))
+    pr = (ctypes.c_int * n)(*(present or [1] * n))
+    lib.bands_sim_handshake.restype = ctypes.c_int
+    return lib.bands_sim_handshake(n, flat, sp, n_split, pr, timeout)
+
+
+def test_first_contact_ranks_that_disagree_about_the_frame_are_told_so(lib):
+    """VERDICT r5 item 6 (rtx_capi.cpp config_handshake; include/rtx.h: RTX_OPT_GATHER_RGB / band layout / split / targets decide the byte counts
+    of the paired ncclSend / ncclRecv on every rank independently): ranks in separate processes compare a 16-byte digest of the frame
+    configuration before a band travels. Same configuration -> 0; any single field changed on one rank -> that rank is named."""
+    base = [3840, 2160, 4, 8, 0, 3, 1, 0]           # width, height, n_ranks, band_rows, band_layout, gather_targets, gather_rgb, loopback
+    assert _handshake(lib, [base] * 4) == 0
+    for field in range(8):
+        for rank in (1, 2, 3):
+            cfgs = [list(base) for _ in range(4)]
+            cfgs[rank][field] += 1
+            assert _handshake(lib, cfgs) == 1 + rank, (field, rank)
+    # the contiguous layouts: the split is part of it (it decides how many rows each rank sends); the interleaved one ignores a stale split
+    cont = [3840, 2160, 4, 8, 1, 3, 1, 0]
+    even, skew = [544, 544, 536, 536], [544, 552, 528, 536]
+    assert _handshake(lib, [cont] * 4, [even] * 4) == 0
+    assert _handshake(lib, [cont] * 4, [even, even, skew, even]) == 3
+    assert _handshake(lib, [base] * 4, [even, even, skew, even]) == 0
+
+
+def test_first_contact_a_rank_that_never_calls_is_named_not_waited_for(lib):
+    """The waits on the transfer stream are bounded (RTX_GATHER_TIMEOUT_MS; band_math.h bounded_wait, here on a fake clock): rank 0 receives the
+    peers' digests one at a time, so the rank that never issued its send is the one the error names -- not a hung process."""
+    base = [1920, 1080, 8, 8, 0, 1, 1, 0]
+    assert _handshake(lib, [base] * 8, present=[1] * 8) == 0
+    for missing in (1, 4, 7):
+        present = [1] * 8
+        present[missing] = 0
+        assert _handshake(lib, [base] * 8, present=present, timeout=50) == -(100 + missing)
+    # a timeout of 0 means "wait for ever" (rounds 1-5): not exercised with a missing rank, but a present one still completes at once
+    assert _handshake(lib, [base] * 2, present=[1, 1], timeout=0) == 0

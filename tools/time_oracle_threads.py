@@ -16,7 +16,7 @@ ts = textures.default_texture_set()
 for lod in (1, 0):
     o = oracle.OracleScene(sc, W, H, ts["textures"], ts["cubemap"], texture_lod=lod)
     o.render(0, 16, threads=8)      # mip chains, thread pool
-    for n in [t for t in (1, 8, 32, 64, 128, 256) if t <= (os.cpu_count() or 1)]:
+    for n in [t for t in (1, 8, 16, 32, 64, 128, 256) if t <= (os.cpu_count() or 1)]:
         rows = (0, H) if n > 1 else (H // 2 - 32, H // 2 + 32)
         t0 = time.perf_counter()
         _img, cnt = o.render(rows[0], rows[1], threads=n)
