@@ -865,23 +865,26 @@ RT_HD bool sphere_entry_beyond(float a, float b, float hp, float d2, float tlimi
 {
     const float L = fmaf(tlimit, 1.001f, fmaf(1e-5f, d2, 0.01001f));
     const float s = fmaf(-a, L, -b);
-    return s > 0.0f && s * s > hp;
+    return (s > 0.0f) & (s * s > hp);
 }
+// (round 6: straight-line. With early returns the compiler built six nested exec-mask regions per test -- s_and_saveexec / s_cbranch_execz
+// pairs around two or three VALU instructions each, four tests per scan step; every operation here is cheap and has no side effect, so all
+// of it is evaluated and the conditions are combined bitwise: the same predicate, NaNs still compare false -> "not culled".)
 RT_HD bool sphere_cull(f3 c, float r2, f3 ro, f3 rd, float tlimit)
 {
     const f3 oc = ro - c;
     const float d2 = dot3_fma(oc, oc);
     const float cc = d2 - r2;                 // > 0: origin outside
-    if (!(cc > 0.0f)) return false;
     const float a = dot3_fma(rd, rd);
-    if (!(a > 0.25f && a < 4.0f)) return false;  // degenerate direction (refract() yields the zero vector on a total
-                                                 // reflection it disagrees about with the Fresnel test): never cull
     const float b = dot3_fma(oc, rd);
-    if (b >= 0.0f) return true;               // sphere behind the origin
     const float h = fmaf(b, b, -(a * cc));
     const float err = 1e-5f * a * d2;
-    if (h < -err) return true;                // line misses the sphere, beyond rounding doubt
-    return sphere_entry_beyond(a, b, h + err, d2, tlimit);
+    // origin outside; not a degenerate direction (refract() yields the zero vector on a total reflection it disagrees about with the
+    // Fresnel test: never cull)
+    const bool may = (cc > 0.0f) & (a > 0.25f) & (a < 4.0f);
+    // sphere behind the origin | the line misses the sphere, beyond rounding doubt | entered beyond the limit
+    const bool out = (b >= 0.0f) | (h < -err) | sphere_entry_beyond(a, b, h + err, d2, tlimit);
+    return may & out;
 }
 // The premise above holds for UNIT directions only. The shader's Durand-Kerner update divides by the product of root
 // differences but not by the quartic's leading coefficient dot(rd,rd)^2, so for a direction of length L its steps are L^4
@@ -943,20 +946,18 @@ RT_HD float torus_near2(float rb2) { return gl_max(gl_min(9.0f, 4.0f * rb2), 1.5
 RT_HD bool torus_sphere_cull(f3 c, float r2, float near2, f3 ro, f3 rd)
 {
     const float a = dot3_fma(rd, rd);
-    if (!unit_direction(a)) return false;
     const f3 oc = ro - c;
     const float d2 = dot3_fma(oc, oc);
-    const float cc = d2 - r2;                 // > 0: origin outside
-    if (!(cc > 0.0f)) return false;           // (also: a torus that is never culled, r2 = +inf; NaN)
+    const float cc = d2 - r2;                 // > 0: origin outside (false also for a torus that is never culled, r2 = +inf, and for NaN)
     const float b = dot3_fma(oc, rd);
     const float h = fmaf(b, b, -(a * cc));
     const float err = 1e-5f * a * d2;
-    if (h < -err) return true;                // the LINE misses the sphere, beyond rounding doubt
-    if (b >= 0.0f) {                          // sphere behind the origin
-        if (!RT_TORUS_BEHIND_RULE || !(d2 > near2)) return true;
-        return sphere_entry_beyond(a, -b, h + err, d2, RT_TORUS_REACH_BACK);     // far origin: only if the reversed ray enters it beyond the reach
-    }
-    return sphere_entry_beyond(a, b, h + err, d2, RT_TORUS_REACH);
+    const bool may = unit_direction(a) & (cc > 0.0f);
+    const bool behind = b >= 0.0f;            // sphere behind the origin: what follows looks at the REVERSED ray (-|b|), with the backward reach
+    const float reach = RT_TORUS_REACH_BACK == RT_TORUS_REACH ? RT_TORUS_REACH : (behind ? RT_TORUS_REACH_BACK : RT_TORUS_REACH);
+    // the LINE misses the sphere, beyond rounding doubt | behind a NEAR origin | the (reversed) ray enters it beyond the reach
+    const bool out = (h < -err) | (behind & !(RT_TORUS_BEHIND_RULE && d2 > near2)) | sphere_entry_beyond(a, -fabsf(b), h + err, d2, reach);
+    return may & out;
 }
 RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd)
 {
@@ -1180,6 +1181,116 @@ RT_HD bool intersect_torus(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t
     return intersect_torus_c<false>(T, ro, rd, tmin, t, solved);
 }
 
+RT_HD int lane_pop(unsigned long long& m)
+{
+    const int j = __builtin_ctzll(m);
+    m &= m - 1ull;
+    return j;
+}
+
+// ---- a lane's candidate tori in ONE solver loop (round 6; SURVEY section 7 step 5, "ray regeneration", inside the wave) ----
+// The lane-divergent scans (calc_inter / in_shadow of the many-primitive variant) used to run one pass per candidate: every lane takes its
+// next candidate, the wave solves, and the pass lasts as long as its slowest lane -- 0.57 of the lanes of a solver sweep did work on the
+// 64-torus frame. The solve does not depend on the ray's limit (rt.frag:486 applies it afterwards), so a lane whose solve has ended can take
+// its NEXT candidate -- rotation, culls, torus_ray_setup -- and re-enter the sweeps while the other lanes are still in theirs: no barrier, no
+// LDS, no other wave. Per lane the sequence of operations is exactly the sequential one (candidates in index order, each tested against
+// the limit as it stands when its solve ends, a converged lane stops updating its roots: trap T14), so results are bit-identical. Lanes are
+// refilled in batches: sweeps run in bursts of RT_DK_BURST, and only between bursts do waiting lanes fetch their next candidate (a refill
+// is ~350 instructions for however few lanes take part; convergence clusters at 10-15 sweeps, so most lanes of a run wait at the same burst).
+// ANYHIT (in_shadow): the first accepted root ends the lane's list.
+#ifndef RT_DK_BURST
+#define RT_DK_BURST 2        /* (2 / 4 / 8 on the 64-torus 4K frame: 2 081 / 2 089 / 2 093 us; one pass per candidate: 2 164 -- profiles/r06b_dk_restart_ab.txt) */
+#endif
+#ifndef RT_DK_RESTART
+#define RT_DK_RESTART 1      /* A/B switch: 0 = one solver pass per candidate (rounds 2-5) */
+#endif
+template <bool CULL, bool TUBE, bool COUNT, bool ANYHIT>
+RT_HD void torus_run_candidates(const SceneView& S, int base, unsigned long long cand, f3 ro, f3 rd, float& tmin, int& num, bool& hit, LaneCounters& cnt)
+{
+    const float eps = 0.001f;
+    // Phase A: the culls of every candidate, before any solver state exists (their temporaries -- the Bernstein test alone holds ~30 values --
+    // must not share the registers with four complex iterates and seven ray terms): what is left is the list of tori this lane SOLVES.
+    unsigned long long todo = 0ull;
+    if (CULL) {
+        while (RT_ANY(cand != 0ull)) {
+            if (cand != 0ull) {
+                const int j = lane_pop(cand);
+                const DevTorus& T = S.tori()[base + j];
+                const bool ident = ident_flag(T.pos.w);
+                const f3 o = quat_rotate_id(T.quat, ident, ro - xyz(T.pos));
+                const f3 d = quat_rotate_id(T.quat, ident, rd);
+                if (!torus_local_cull<TUBE>(T, o, d)) todo |= 1ull << j;
+            }
+        }
+    } else {
+        todo = cand;
+    }
+    // Phase B: one solver loop over the lane's list. A refill is the rotation and the seven dot products of torus_ray_setup only.
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    bool _dk_run_counted = false;
+#endif
+    bool active = false;
+    int sweeps = 0, cur = 0;
+    TorusRay w;
+    w.a = w.b = w.c = w.axy = w.bxy = w.cxy = w.k = 0.0f;
+    v2f c0 = mk2v(0.0f, 0.0f), c1 = c0, c2 = c0, c3 = c0;
+    for (;;) {
+        if (RT_ANY(!active && todo != 0ull)) {
+            if (!active && todo != 0ull) {
+                cur = base + lane_pop(todo);
+                const DevTorus& T = S.tori()[cur];
+                const bool ident = ident_flag(T.pos.w);
+                w = torus_ray_setup(T, quat_rotate_id(T.quat, ident, ro - xyz(T.pos)), quat_rotate_id(T.quat, ident, rd));
+                c0 = mk2v(1.0f, 0.0f);                              // rt.frag:463-466
+                c1 = mk2v(0.4f, 0.9f);
+                c2 = cmul(c1, mk2v(0.4f, 0.9f));
+                c3 = cmul(c2, mk2v(0.4f, 0.9f));
+                sweeps = 0;
+                active = true;
+                if (COUNT) cnt.torus_solves++;
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+                atomicAdd(&g_dk[1], 1ull);                          // lane solves
+#endif
+            }
+        }
+        if (!RT_ANY(active)) break;
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+        if (!_dk_run_counted) { _dk_run_counted = true; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_dk[0], 1ull); }   // solver runs (one per scan now)
+#endif
+#pragma unroll 1
+        for (int k = 0; k < RT_DK_BURST; k++) {
+#if defined(RT_DK_STATS) && defined(__HIP_DEVICE_COMPILE__)
+            {   // wave sweeps, lane sweeps
+                const unsigned long long am = __ballot(active), all = __ballot(1);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)all) - 1) { atomicAdd(&g_dk[2], 1ull); atomicAdd(&g_dk[3], (unsigned long long)__builtin_popcountll(am)); }
+            }
+#endif
+            if (active) {
+                float e = dk_step(c0, c1, c2, c3, w);              // one sweep, rt.frag:468-477
+                e = gl_max(e, dk_step(c1, c2, c3, c0, w));
+                e = gl_max(e, dk_step(c2, c3, c0, c1, w));
+                e = gl_max(e, dk_step(c3, c0, c1, c2, w));
+                sweeps++;
+                if (e < eps || sweeps >= 60) {                      // this lane's solve has ended (rt.frag:478, the cap of rt.frag:467)
+                    float r0 = c0[0], r1 = c1[0], r2 = c2[0], r3 = c3[0];
+                    if (fabsf(c0[1]) > eps || r0 < 0.0f) r0 = 10000.0f;
+                    if (fabsf(c1[1]) > eps || r1 < 0.0f) r1 = 10000.0f;
+                    if (fabsf(c2[1]) > eps || r2 < 0.0f) r2 = 10000.0f;
+                    if (fabsf(c3[1]) > eps || r3 < 0.0f) r3 = 10000.0f;
+                    const float t = gl_min(gl_min(r0, r1), gl_min(r2, r3));
+                    if (torus_root_accepted(t, tmin)) {
+                        hit = true;
+                        if (ANYHIT) todo = 0ull;
+                        else { num = cur; tmin = t; }
+                    }
+                    active = false;
+                }
+            }
+            if (!RT_ANY(active)) break;
+        }
+    }
+}
+
 // ---- general quadric (rt.frag:499-572) ----
 RT_HD bool is_between(f3 v, f3 lo, f3 hi) { return (v.x > lo.x && v.y > lo.y && v.z > lo.z) && (v.x < hi.x && v.y < hi.y && v.z < hi.z); }
 // WAVE = false (tools/audit only): the early exits below are taken by each lane on its own condition, so that an audit whose lanes hold
@@ -1243,16 +1354,14 @@ RT_HD bool intersect_surface(const DevSurface& Q, f3 ro_w, f3 rd_w, float tmin, 
 // inside the clip box -- what surface_box_miss may then use.
 RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit, bool& safe)
 {
-    safe = false;
-    if (!(Q.bound.w >= 0.0f)) return false;
+    // (round 6: straight-line like sphere_cull -- every early return was an exec-mask region of its own; same predicate)
     // p2 ~ d^T M d from the six direction products (ray-invariant) and the symmetric M of this quadric
     const float dxx = rd.x * rd.x, dyy = rd.y * rd.y, dzz = rd.z * rd.z;
     const float dxy = 2.0f * (rd.x * rd.y), dxz = 2.0f * (rd.x * rd.z), dyz = 2.0f * (rd.y * rd.z);
     const float p2 = fmaf(Q.sym1.x, dyz, fmaf(Q.sym0.z, dxz, fmaf(Q.sym0.y, dxy, fmaf(Q.sym1.y, dzz, fmaf(Q.sym0.w, dyy, Q.sym0.x * dxx)))));
-    if (!(fabsf(p2) > Q.sym1.z)) return false;  // too close to the degenerate branch: run the full test
     const float a = dot3_fma(rd, rd);
-    if (!(a > 0.25f && a < 4.0f)) return false;  // degenerate direction: never cull
-    safe = true;
+    // a bound exists; not too close to the degenerate branch (else: run the full test); not a degenerate direction (never cull)
+    safe = (Q.bound.w >= 0.0f) & (fabsf(p2) > Q.sym1.z) & (a > 0.25f) & (a < 4.0f);
     const f3 oc = ro - xyz(Q.bound);
     const float b = dot3_fma(oc, rd);
     const float d2 = dot3_fma(oc, oc);
@@ -1260,10 +1369,10 @@ RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit, boo
     // far ones: the bound of the closed clip box, if there is one (NaN: none -- the comparisons below then never cull)
     const float cc = d2 - (d2 <= (float)(RT_QUADRIC_FAR * RT_QUADRIC_FAR) ? Q.bound.w : Q.sym1.w);
     const float h = fmaf(b, b, -(a * cc)), err = 1e-5f * a * d2;
-    if (h < -err) return true;                  // the line misses: rounding-safe (see sphere_cull); NaN -> false -> not culled
-    if (!(cc > 0.0f)) return false;             // origin inside the bound
-    if (b >= 0.0f) return true;                 // the bound lies behind the origin
-    return sphere_entry_beyond(a, b, h + err, d2, tlimit);
+    // the line misses (rounding-safe, see sphere_cull; NaN -> false -> not culled) | origin outside the bound, and the bound behind the origin
+    // or entered beyond the limit
+    const bool out = (h < -err) | ((cc > 0.0f) & ((b >= 0.0f) | sphere_entry_beyond(a, b, h + err, d2, tlimit)));
+    return safe & out;
 }
 RT_HD bool surface_cull(const DevSurfaceCull& Q, f3 ro, f3 rd, float tlimit)
 {
@@ -1589,15 +1698,12 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
 // primitives at once. The number of solver passes per scan drops from "distinct primitives any lane
 // of the wave needs" to "most candidates of a single lane". Per lane the tests still run in index
 // order with the live tmin, so the closest-hit semantics (strict <, first wins) are unchanged.
+#ifndef RT_SURF_PREFETCH
+#define RT_SURF_PREFETCH 0   /* 1: the quadric mask walk loads the NEXT candidate's cull record while the current one is tested (A/B: profiles/r06c_*) */
+#endif
 #ifndef RT_LANE_DIVERGENT_MIN
 #define RT_LANE_DIVERGENT_MIN 3   /* classes with fewer primitives keep the wave-uniform path */
 #endif
-RT_HD int lane_pop(unsigned long long& m)
-{
-    const int j = __builtin_ctzll(m);
-    m &= m - 1ull;
-    return j;
-}
 
 #define RT_UNROLL4(BODY) { { constexpr int k = 0; BODY } { constexpr int k = 1; BODY } { constexpr int k = 2; BODY } { constexpr int k = 3; BODY } }
 
@@ -1753,10 +1859,18 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             const uint32_t own_w = ps.next(S, slabw);
             uint32_t u = wave_or(own_w, true);
             scan_stats_word(ps.mem ? 0 : 1, own_w, true, u);
+#if RT_SURF_PREFETCH
+            DevSurfaceCull nxt = cullrec[(w << 5) + (u ? __builtin_ctz(u) : 0)];
+#endif
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
+#if RT_SURF_PREFETCH
+                const DevSurfaceCull c0 = nxt;
+                nxt = cullrec[(w << 5) + (u ? __builtin_ctz(u) : b)];      // the next candidate's record travels while this one is tested
+#else
                 const DevSurfaceCull c0 = cullrec[i];
+#endif
                 // (round 4) behind the sphere: the clip box itself, for the lanes it governs -- quadric-heavy 4K frame 1 015 -> 981 us
                 bool safe;
                 bool need = !surface_cull(c0, ro, rd, tmin, safe);
@@ -1828,6 +1942,11 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 RT_UNROLL4(if (i + k < end && !torus_cull(b[k], ro, rd)) cand |= 1ull << (i + k - base);)
             }
             dk_stats_scan(cand);
+            if (GROUPS && RT_DK_RESTART) {      // (the many-primitive variant only: in the default variant this path never runs, and its code costs)
+                bool th = false;
+                torus_run_candidates<CULL, GROUPS, COUNT, false>(S, base, cand, ro, rd, tmin, num, th, cnt);
+                if (th) type = TYPE_TORUS;
+            } else
             while (RT_ANY(cand != 0ull)) {
                 if (cand != 0ull) {
                     const int i = base + lane_pop(cand);          // differs from lane to lane
@@ -1929,10 +2048,18 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             const uint32_t own_w = ps.next(S, slabw);
             uint32_t u = wave_or(own_w, on);
             scan_stats_word(ps.mem ? 2 : 3, own_w, on, u);
+#if RT_SURF_PREFETCH
+            DevSurfaceCull nxt = cullrec[(w << 5) + (u ? __builtin_ctz(u) : 0)];
+#endif
             while (u != 0u) {
                 const int b = __builtin_ctz(u), i = (w << 5) + b;
                 u &= u - 1u;
+#if RT_SURF_PREFETCH
+                const DevSurfaceCull c0 = nxt;
+                nxt = cullrec[(w << 5) + (u ? __builtin_ctz(u) : b)];
+#else
                 const DevSurfaceCull c0 = cullrec[i];
+#endif
                 bool safe;
                 bool need = on && !surface_cull(c0, ro, rd, dist, safe);
                 if (RT_ANY(need)) need = need && !(safe && surface_box_miss(S.surfaces()[i], ro, rd, dist));
@@ -1995,6 +2122,13 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                     RT_UNROLL4(if (on && i + k < end && !torus_cull(b[k], ro, rd)) cand |= 1ull << (i + k - base);)
                 }
                 dk_stats_scan(cand);
+                if (GROUPS && RT_DK_RESTART) {
+                    bool th = false;
+                    float lim = dist;
+                    int unused = 0;
+                    torus_run_candidates<CULL, GROUPS, COUNT, true>(S, base, cand, ro, rd, lim, unused, th, cnt);
+                    if (th) { shadow = 1.0f; on = false; }
+                } else
                 while (RT_ANY(cand != 0ull)) {
                     if (cand != 0ull) {
                         const int i = base + lane_pop(cand);

@@ -33,6 +33,7 @@ def main():
         print(f"{name}: kernel {ms:.3f} ms (instrumented)")
         print(f"  wave-level solver runs {v[0]}, lane-level solves {v[1]}, mean lanes/run {v[1]/max(v[0],1):.1f}")
         print(f"  wave sweeps {v[2]} (mean {v[2]/max(v[0],1):.1f}/run), lane sweeps {v[3]} (mean {v[3]/max(v[1],1):.1f}/solve)")
+        print(f"  lane-sweep utilisation (lane sweeps / 64 x wave sweeps): {v[3] / max(64 * v[2], 1):.3f}")
         print(f"  wave cycles in solver {v[4]} (mean {v[4]/max(v[0],1):.0f}/run, {v[4]/max(v[2],1):.0f}/sweep)")
         print(f"  lane solves: accepted hit {v[7]}, real root beyond the limit {v[5]}, no usable root {v[1]-v[7]-v[5]}; hitting 60 sweeps {v[6]}")
         print(f"  torus scans with a candidate {v[8]}: passes (busiest lane's candidates) {v[9]} = {v[9]/max(v[8],1):.2f}/scan, candidates {v[10]} = "
