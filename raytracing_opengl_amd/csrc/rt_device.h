@@ -919,31 +919,27 @@ RT_HD bool unit_direction(float dd) { return fabsf(dd - 1.0f) <= 1e-3f; }   // f
 #define RT_TORUS_REACH 102.5f      /* 100 + 2.5 % (round 4's widening at t = 100); sphere_cull and the puck test add their own slack */
 #endif
 // "BEHIND" RAYS (round 6). A ray that points AWAY from a torus its backward extension goes through has four real NEGATIVE roots, and the
-// reference still solves it (rt.frag:462-487 never culls). From a near origin the iteration converges on them and reports nothing. From a far
-// origin the quartic's coefficients (~ |o|^4) put the float noise of a Durand-Kerner step above the 1e-3 stop criterion: the solve runs all 60
-// sweeps with its iterates jittering around the roots, and when two of them nearly coincide in the last sweep one is thrown along the real
-// axis -- now and then to a positive t below the limit: a hit where there is no torus, which the reference shows. Measured
-// (tools/cull_audit.py family torus_behind, profiles/r05zz_cull_audit_torus_behind_6e10.txt: every ray of that kind solved): no phantom among
-// 1.4e10 such rays from within 4 units of the torus' centre, 1 in 5.7e9 at 4..6, 862 in 9.7e9 at 24..48. Rule: "the torus lies behind the
-// origin" is a reason to cull it only for a NEAR origin; for a far one every test looks at the ray's whole LINE -- the backward half is culled
-// only where it clears the inflated torus (then the roots are two complex pairs, the lateral premise of the comment above) or enters it
-// beyond RT_TORUS_REACH_BACK. Near = closer to the centre than torus_near2(bound radius^2): 3 units at most (a margin below the 4 the
-// measurement supports), two bound radii for a small torus (the noise grows as |o|^4 / (r R^2): what "far" means scales with the torus),
-// and never less than 1.25 bound radii, so that a torus' own shadow and mirror rays (|o| <= R + r) keep their culls whatever its size.
+// reference still solves it (rt.frag:462-487 never culls). Mostly the iteration converges on them and reports nothing. But the quartic's
+// coefficients grow as |o|^4, and once the float noise of a Durand-Kerner step exceeds the 1e-3 stop criterion the solve runs all 60 sweeps with
+// its iterates jittering around the roots; when two of them nearly coincide in the last sweep one is thrown along the real axis -- now and then
+// to a positive t below the limit: a hit where there is no torus, which the reference shows. Measured (tools/cull_audit.py family torus_behind,
+// every ray of that kind solved; profiles/r06d_cull_audit_torus_behind_1e12.txt, 7.8e11 rays over 125 scenes): 66 phantoms from 2..4 units, 223
+// from 4..6, 13 667 from 24..48 -- the rate falls towards the torus but there is NO distance from which on it is zero (round 5's "none within 4
+// units" was 1.4e10 rays; two of the 66 come from 3.2 and 3.3 units of tori of R = 1 .. 1.3). Rule: "the torus lies behind the origin" is no
+// reason to cull it. For an origin OUTSIDE the torus' inflated bounding sphere every test looks at the ray's whole LINE -- the backward half is
+// culled only where it clears the inflated torus (then the roots are two complex pairs: the lateral premise of the comment above) or enters
+// it beyond RT_TORUS_REACH_BACK (measured like the forward reach: family torus_behind_far, 1.1e11 rays from 104 .. 3000 units, no hit). An
+// origin INSIDE the bounding sphere (a torus' own shadow and mirror rays: |o| <= R + r) keeps the half-line culls -- hull, puck, tube --
+// whose premises were measured on exactly those rays.
 #ifndef RT_TORUS_BEHIND_RULE
 #define RT_TORUS_BEHIND_RULE 1      /* A/B switch: 0 = the culls of round 5 (a torus behind the origin is culled from any distance) */
 #endif
 #ifndef RT_TORUS_REACH_BACK
 #define RT_TORUS_REACH_BACK 102.5f  /* how far back along the line a torus still has to be looked at (measured: tools/cull_audit.py family torus_behind_far) */
 #endif
-#if defined(RT_AB_NEAR_INF)     /* measurement only: the rule compiled in, never taken (what its CODE costs) */
-RT_HD float torus_near2(float rb2) { return rb2 * 0.0f + 3.0e38f; }
-#else
-RT_HD float torus_near2(float rb2) { return gl_max(gl_min(9.0f, 4.0f * rb2), 1.5625f * rb2); }
-#endif
-// sphere_cull(c, r2, ro, rd, RT_TORUS_REACH) with the "behind" rule in its `b >= 0` branch; near2: squared distance up to which "the sphere
-// lies behind the origin" is still a reason to cull (0 = from nowhere: a group's sphere, whose members each have their own)
-RT_HD bool torus_sphere_cull(f3 c, float r2, float near2, f3 ro, f3 rd)
+// sphere_cull(c, r2, ro, rd, RT_TORUS_REACH) with the "behind" rule: the origin is outside the sphere here, so a sphere behind it is judged by
+// the REVERSED ray (-|b|) against the backward reach. Straight-line (see sphere_cull).
+RT_HD bool torus_sphere_cull(f3 c, float r2, f3 ro, f3 rd)
 {
     const float a = dot3_fma(rd, rd);
     const f3 oc = ro - c;
@@ -953,15 +949,15 @@ RT_HD bool torus_sphere_cull(f3 c, float r2, float near2, f3 ro, f3 rd)
     const float h = fmaf(b, b, -(a * cc));
     const float err = 1e-5f * a * d2;
     const bool may = unit_direction(a) & (cc > 0.0f);
-    const bool behind = b >= 0.0f;            // sphere behind the origin: what follows looks at the REVERSED ray (-|b|), with the backward reach
+    const bool behind = b >= 0.0f;
     const float reach = RT_TORUS_REACH_BACK == RT_TORUS_REACH ? RT_TORUS_REACH : (behind ? RT_TORUS_REACH_BACK : RT_TORUS_REACH);
-    // the LINE misses the sphere, beyond rounding doubt | behind a NEAR origin | the (reversed) ray enters it beyond the reach
-    const bool out = (h < -err) | (behind & !(RT_TORUS_BEHIND_RULE && d2 > near2)) | sphere_entry_beyond(a, -fabsf(b), h + err, d2, reach);
+    // the LINE misses the sphere, beyond rounding doubt | round 5: behind the origin | the (reversed) ray enters it beyond the reach
+    const bool out = (h < -err) | (behind & !RT_TORUS_BEHIND_RULE) | sphere_entry_beyond(a, RT_TORUS_BEHIND_RULE ? -fabsf(b) : b, h + err, d2, reach);
     return may & out;
 }
 RT_HD bool torus_cull(f4 bound, f3 ro, f3 rd)
 {
-    return torus_sphere_cull(xyz(bound), bound.w, torus_near2(bound.w), ro, rd);
+    return torus_sphere_cull(xyz(bound), bound.w, ro, rd);
 }
 // A ring hit lies within sqrt(r2) of the ring centre (p < r2, rt.frag:384) and needs 0 < t < tmin;
 // intersect_ring has no NaN-accepting path (all four comparisons must hold), so missing the
@@ -1141,7 +1137,7 @@ RT_HD bool torus_forward_cull(const DevTorus& T, f3 o, f3 d)
     // measured and not compiled in, profiles/r05u_start_cull_ab.txt.)
     return TUBE && T.k.w > 0.0f && torus_tube_cull(T, o, d, t0, t1);
 }
-// The "behind" rule (torus_cull): from a far origin the part of the LINE behind the origin has to clear the inflated torus too -- the same puck
+// The "behind" rule (torus_cull): from an origin outside the bounding sphere the part of the LINE behind the origin has to clear the inflated torus too -- the same puck
 // and tube tests on the reversed ray (the hull test is a statement about half-lines that move away from the disc; a reversed ray of this
 // kind moves towards it).
 RT_HD bool torus_backward_cull(const DevTorus& T, f3 o, f3 d)
@@ -1157,11 +1153,7 @@ RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
     const float dd = dot3(d, d);
     if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
     if (!torus_forward_cull<TUBE>(T, o, d)) return false;
-#if defined(RT_AB_EXPECT)
-    if (!RT_TORUS_BEHIND_RULE || __builtin_expect(!(dot3(o, o) > T.k.y), 1)) return true;
-#else
-    if (!RT_TORUS_BEHIND_RULE || !(dot3(o, o) > T.k.y)) return true;     // near origin (the common case; T.k.y: rt_pack.h): the forward half-line decides
-#endif
+    if (!RT_TORUS_BEHIND_RULE || !(dot3(o, o) > T.k.z)) return true;     // origin inside the inflated bounding sphere (T.k.z = its radius^2): the half-line decides
     return torus_backward_cull(T, o, d);
 }
 template <bool CULL, bool TUBE = true>
@@ -1417,7 +1409,7 @@ RT_HD bool surface_box_miss(const DevSurface& Q, f3 ro, f3 rd, float tlimit)
 RT_HD bool torus_group_cull(f4 g, f3 ro, f3 rd)
 {
     if (!(g.w >= 0.0f)) return false;   // a member that is never culled (zero tube, non-unit quaternion): neither is the group
-    return torus_sphere_cull(xyz(g), g.w, 0.0f, ro, rd);    // (no "near" for a group: each member has its own)
+    return torus_sphere_cull(xyz(g), g.w, ro, rd);
 }
 RT_HD bool surface_group_cull(f4 g, f3 ro, f3 rd)
 {
@@ -1581,9 +1573,9 @@ RT_HD PencilPrim pencil_prim(const DevPencil& P, f4 bound, const DevSurfaceCull*
         const float D = sqrtf(D2), sa = rad / D;                        // sin(alpha) < 0.996: alpha is well-conditioned
         r.a = mk4(v.x / D, v.y / D, v.z / D, sa);
         r.b.x = sqrtf(1.0f - sa * sa);
-        // tori: the apex is a FAR origin in the sense of torus_cull's "behind" rule (with 2 % to spare) -- a ray that STARTS at the apex keeps
-        // this torus as a candidate in the cells its bound's antipodal cone meets as well
-        if (!Q && RT_TORUS_BEHIND_RULE && D2 > 0.98f * torus_near2(bound.w)) r.b.z = 1.0f;
+        // tori: the apex is outside the bound (it is, here), so torus_cull's "behind" rule looks at the whole line of a ray that STARTS at the
+        // apex -- the torus stays a candidate in the cells its bound's antipodal cone meets as well
+        if (!Q && RT_TORUS_BEHIND_RULE) r.b.z = 1.0f;
     } else {
         const float cu = dot3(c, xyz(P.e1)), cv = dot3(c, xyz(P.e2));
         const float rr = rad + 1.0e-3f * gl_max(P.grid.z, P.grid.w);

@@ -78,14 +78,16 @@ struct alignas(16) DevBox {
 #define RT_TORUS_IM_NOISE 0.1         /* the largest |Im| of a complex root pair the reference's solver may take for real: measured 0.057 from 30 .. 60 units out
                                          (tools/cull_audit.py torus_margin on the sized-torus scenes, profiles/r06*); every torus bound is inflated for it (rt_pack.h) */
 #endif
-#ifndef RT_TORUS_NEAR_K
-#define RT_TORUS_NEAR_K 600.0         /* near^4 = K r R^2 (rt_pack.h; the "behind" rule of rt_device.h torus_cull) */
-#endif
+/* the torus sizes the cull premises were audited on (tools/cull_audit.py; rt_pack.h): others are never culled */
+#define RT_TORUS_CULL_R_MIN 0.25f
+#define RT_TORUS_CULL_R_MAX 2.5f
+#define RT_TORUS_CULL_TUBE_MIN 0.08f
+#define RT_TORUS_CULL_TUBE_MAX 2.0f
 struct alignas(16) DevTorus {
     f4 quat;
     f4 pos;            // xyz, w = int bits: 1 if quat is the identity
     f4 radii;          // R, r, R*R, r*r
-    f4 k;              // x = 4*R*R, y = "behind" rule: near distance^2 of the local culls, z = puck radius^2 = world cull-sphere radius^2 ((R+r) inflated), w = hole radius^2 ((R-r) deflated, 0 = none)
+    f4 k;              // x = 4*R*R, y = z = puck radius^2 = world cull-sphere radius^2 ((R+r) inflated), w = hole radius^2 ((R-r) deflated, 0 = none)
     f4 qinv;
     f4 cull;           // x = puck half height (r inflated), y = (r + RT_TORUS_HULL_MARGIN)^2, z = |R| (convex-hull cull), w = r + RT_TORUS_HULL_MARGIN (start cull)
 };

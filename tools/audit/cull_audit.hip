@@ -260,7 +260,7 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         // for r >= 0.3 and grows to RT_TORUS_IM_NOISE for thin tubes: rt_pack.h)
         const double clear_min = 0.6 * ((double)T.cull.x - fabs((double)T.radii.y));
         bool c_line = unit && isfinite(bound.w) && ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01) >= clear_min;
-        if (c_line && RT_TORUS_BEHIND_RULE && dot3(o, o) > 0.98f * T.k.y)       // (T.k.y: the near distance^2 the product's local culls use, rt_pack.h)
+        if (c_line && RT_TORUS_BEHIND_RULE && dot3(o, o) > 0.98f * T.k.z)       // (T.k.z: the bounding sphere's radius^2 -- outside it the product's culls look at the whole line)
             c_line = ray_tube_clearance(T, o, mk3(-d.x, -d.y, -d.z), (double)RT_TORUS_REACH_BACK * 1.001 + 0.01) >= clear_min;
         const bool any = c_sphere || c_group || c_hull || c_puck || c_tube || c_line;
         c[0]++; c[1] += any; c[2] += c_sphere; c[3] += c_group; c[4] += c_hull; c[5] += c_puck; c[6] += c_line; c[16] += scaled; c[17] += c_tube;
@@ -796,7 +796,7 @@ __device__ void audit_tables(const AuditParams& p, const SceneView& S, unsigned 
                 const double clear_min = T.cull.y < RT_FLT_MAX ? 0.5 * ((double)T.cull.x - fabs((double)T.radii.y)) : 5.0e-3;    // half the tube's own inflation (5 mm for r >= 0.3)
                 if (!(clr >= clear_min)) { c[11]++; record_bad(p, 11 + kind * 100, i - ns, ro, rd, tlimit, 0.0f, (float)clr); }
                 // the "behind" rule (rt_device.h torus_cull): from a far origin the LINE's part behind the origin, up to the backward reach, as well
-                if (RT_TORUS_BEHIND_RULE && T.cull.y < RT_FLT_MAX && dot3(o, o) > T.k.y) {
+                if (RT_TORUS_BEHIND_RULE && T.cull.y < RT_FLT_MAX && dot3(o, o) > T.k.z) {
                     c[8]++;
                     const double back = ray_tube_clearance(T, o, mk3(-d.x, -d.y, -d.z), (double)RT_TORUS_REACH_BACK * 1.001 + 0.01);
                     if (!(back >= clear_min)) { c[12]++; record_bad(p, 12 + kind * 100, i - ns, ro, rd, tlimit, -1.0f, (float)back); }
