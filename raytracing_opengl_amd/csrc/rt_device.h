@@ -1690,6 +1690,21 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
 // primitives at once. The number of solver passes per scan drops from "distinct primitives any lane
 // of the wave needs" to "most candidates of a single lane". Per lane the tests still run in index
 // order with the live tmin, so the closest-hit semantics (strict <, first wins) are unchanged.
+// Round 6: an exact test takes its primitive record BY VALUE. Through a reference the compiler loaded every field where it was first used --
+// the quadric walk's exact test fetched its 96-byte record in seven scalar loads, each behind a branch and each waited for at once
+// (profiles/r06_quadric_walk_isa.txt): seven scalar-cache round trips per test where one does. A by-value copy in front of the test is one
+// batch of loads (fields the test never reads are dropped again by the compiler). Quadric-heavy 4K frame 920 -> 859 us (profiles/r06e_*).
+#ifndef RT_SURF_RECORD_BY_VALUE
+#define RT_SURF_RECORD_BY_VALUE 1   /* the candidate walks of the many-primitive variant */
+#endif
+#ifndef RT_RECORDS_BY_VALUE
+#define RT_RECORDS_BY_VALUE 1       /* the short tables' uniform scans (surfaces, boxes, tori, rings) */
+#endif
+#if RT_RECORDS_BY_VALUE
+#define RT_REC(T) T
+#else
+#define RT_REC(T) T&
+#endif
 #ifndef RT_SURF_PREFETCH
 #define RT_SURF_PREFETCH 0   /* 1: the quadric mask walk loads the NEXT candidate's cull record while the current one is tested (A/B: profiles/r06c_*) */
 #endif
@@ -1866,11 +1881,22 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                 // (round 4) behind the sphere: the clip box itself, for the lanes it governs -- quadric-heavy 4K frame 1 015 -> 981 us
                 bool safe;
                 bool need = !surface_cull(c0, ro, rd, tmin, safe);
+#if RT_SURF_RECORD_BY_VALUE
+                if (RT_ANY(need)) {
+                    const DevSurface Qv = S.surfaces()[i];     // the whole 96-byte record in ONE scalar round trip (the walk's ISA had it in seven: profiles/r06_quadric_walk_isa.txt)
+                    need = need && !(safe && surface_box_miss(Qv, ro, rd, tmin));
+                    if (RT_ANY(need)) {
+                        scan_stats_level2(ps.mem ? 0 : 1, need);
+                        if (need && intersect_surface(Qv, ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; scan_stats_hit(ps.mem ? 0 : 1); }
+                    }
+                }
+#else
                 if (RT_ANY(need)) need = need && !(safe && surface_box_miss(S.surfaces()[i], ro, rd, tmin));
                 if (RT_ANY(need)) {
                     scan_stats_level2(ps.mem ? 0 : 1, need);
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, tmin, t)) { num = i; tmin = t; type = TYPE_SURFACE; scan_stats_hit(ps.mem ? 0 : 1); }
                 }
+#endif
             }
         }
     } else {
@@ -1895,7 +1921,8 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             }
             for (int k = 0; k < 2; k++) {
                 if (RT_ANY(need[k])) {
-                    if (need[k] && intersect_surface(S.surfaces()[i + k], ro, rd, tmin, t)) { num = i + k; tmin = t; type = TYPE_SURFACE; }
+                    const RT_REC(DevSurface) Qv = S.surfaces()[i + k];
+                    if (need[k] && intersect_surface(Qv, ro, rd, tmin, t)) { num = i + k; tmin = t; type = TYPE_SURFACE; }
                 }
             }
         }
@@ -1905,7 +1932,8 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
         RayBoxCtx bctx;
         for (int i = 0; i < S.h->n_box; i++) {
             f3 nor;
-            if (intersect_box(S.boxes()[i], ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
+            const RT_REC(DevBox) Bv = S.boxes()[i];
+            if (intersect_box(Bv, ro, rd, tmin, t, nor, bctx)) { num = i; tmin = t; type = TYPE_BOX; }
         }
     }
     RT_PH_LAP(cnt, PH_C_BOX);
@@ -1963,7 +1991,8 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
                     if (need[k]) {
                         bool solved;
                         RT_PH_BEGIN(_dk0);
-                        const bool th = intersect_torus_c<CULL, GROUPS>(S.tori()[i + k], ro, rd, tmin, t, solved);
+                        const RT_REC(DevTorus) Tv = S.tori()[i + k];
+                        const bool th = intersect_torus_c<CULL, GROUPS>(Tv, ro, rd, tmin, t, solved);
                         RT_PH_END(cnt, PH_DK, _dk0);
                         if (COUNT && solved) cnt.torus_solves++;
                         if (th) { num = i + k; tmin = t; type = TYPE_TORUS; }
@@ -1985,7 +2014,8 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             for (int k = 0; k < 4; k++) {
                 if (RT_ANY(need[k])) {
                     f2 uv;
-                    if (need[k] && intersect_ring(S.rings()[i + k], ro, rd, tmin, t, uv)) { num = i + k; tmin = t; type = TYPE_RING; }
+                    const RT_REC(DevRing) Rv = S.rings()[i + k];
+                    if (need[k] && intersect_ring(Rv, ro, rd, tmin, t, uv)) { num = i + k; tmin = t; type = TYPE_RING; }
                 }
             }
         }
@@ -2022,7 +2052,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
         RayBoxCtx bctx;
         for (int i = 0; i < S.h->n_box; i++) {
             f3 nor;
-            if (on && intersect_box(S.boxes()[i], ro, rd, dist, t, nor, bctx)) { shadow = 1.0f; on = false; }
+            const RT_REC(DevBox) Bv = S.boxes()[i];
+            if (on && intersect_box(Bv, ro, rd, dist, t, nor, bctx)) { shadow = 1.0f; on = false; }
             if (!RT_ANY(on)) break;
         }
     }
@@ -2054,12 +2085,24 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
 #endif
                 bool safe;
                 bool need = on && !surface_cull(c0, ro, rd, dist, safe);
+#if RT_SURF_RECORD_BY_VALUE
+                if (RT_ANY(need)) {
+                    const DevSurface Qv = S.surfaces()[i];
+                    need = need && !(safe && surface_box_miss(Qv, ro, rd, dist));
+                    if (RT_ANY(need)) {
+                        scan_stats_level2(ps.mem ? 2 : 3, need);
+                        if (need && intersect_surface(Qv, ro, rd, dist, t)) { shadow = 1.0f; on = false; scan_stats_hit(ps.mem ? 2 : 3); }
+                        if (!RT_ANY(on)) u = 0u;
+                    }
+                }
+#else
                 if (RT_ANY(need)) need = need && !(safe && surface_box_miss(S.surfaces()[i], ro, rd, dist));
                 if (RT_ANY(need)) {
                     scan_stats_level2(ps.mem ? 2 : 3, need);
                     if (need && intersect_surface(S.surfaces()[i], ro, rd, dist, t)) { shadow = 1.0f; on = false; scan_stats_hit(ps.mem ? 2 : 3); }
                     if (!RT_ANY(on)) u = 0u;
                 }
+#endif
             }
         }
     } else if (RT_ANY(on)) {
@@ -2082,7 +2125,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             }
             for (int k = 0; k < 2; k++) {
                 if (RT_ANY(need[k])) {
-                    if (need[k] && on && intersect_surface(S.surfaces()[i + k], ro, rd, dist, t)) { shadow = 1.0f; on = false; }
+                    const RT_REC(DevSurface) Qv = S.surfaces()[i + k];
+                    if (need[k] && on && intersect_surface(Qv, ro, rd, dist, t)) { shadow = 1.0f; on = false; }
                 }
             }
             if (!RT_ANY(on)) break;
@@ -2150,7 +2194,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                     if (need[k] && on) {
                         bool solved;
                         RT_PH_BEGIN(_dk0);
-                        const bool th = intersect_torus_c<CULL, GROUPS>(S.tori()[i + k], ro, rd, dist, t, solved);
+                        const RT_REC(DevTorus) Tv = S.tori()[i + k];
+                        const bool th = intersect_torus_c<CULL, GROUPS>(Tv, ro, rd, dist, t, solved);
                         RT_PH_END(cnt, PH_DK, _dk0);
                         if (COUNT && solved) cnt.torus_solves++;
                         if (th) { shadow = 1.0f; on = false; }
@@ -2179,7 +2224,8 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
             for (int k = 0; k < 4; k++) {
                 if (RT_ANY(need[k])) {
                     f2 uv = mk2(0.0f, 0.0f);
-                    const bool geom_hit = need[k] && intersect_ring(S.rings()[i + k], ro, rd, dist, t, uv);
+                    const RT_REC(DevRing) Rv = S.rings()[i + k];
+                    const bool geom_hit = need[k] && intersect_ring(Rv, ro, rd, dist, t, uv);
                     const bool hit = geom_hit && on;
                     const int texnum = __builtin_bit_cast(int, S.rings()[i + k].pos_tex.w);
                     if (texnum > 0) {

@@ -9,7 +9,8 @@
 #   dk       tools/dk_stats.py over counting builds <variant names>
 #   sized    torus / torus_margin / torus_lead audits over the sized-torus scenes only, violations by scene
 #   gpu      the -m gpu suite
-#   bench    bench.py at N = 1 (the driver's line) + the per-config lines
+#   final    the round's final measurements (profiles of the three bench scenes, every configuration's bench line, SMAA split)
+#   bench    bench.py at N = 1 (the driver's line)
 step=$1; shift
 O=gpurun_out/r06_$step; mkdir -p $O
 export PYTHONUNBUFFERED=1
@@ -36,6 +37,26 @@ sized)  # the torus premises on tori of every size: per-scene violations (tests/
   ;;
 gpu)
   timeout 1500 python -m pytest tests -m gpu -x -q "$@" > $O/pytest_gpu.txt 2>&1; tail -15 $O/pytest_gpu.txt
+  ;;
+final)  # the round's final measurements: kernel-trace + PMC passes of the three bench scenes (-> profiles/valu*.json, traffic*.json through
+        # tools/prof_to_json.py), the bench line of every configuration, the driver's line under rocprofv3 (kernel-trace), the SMAA split
+  bash tools/profile_configs.sh r06 > $O/profile_configs.log 2>&1; tail -5 $O/profile_configs.log
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/bench_trace -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/$O/bench_n1_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_n1_under_rocprof.err )
+  python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+  python bench.py --scene quadric --no-cpu-baseline > $O/bench_n1_quadric.json 2>/dev/null
+  python bench.py --scene torus --depth 6 --no-cpu-baseline > $O/bench_n1_torus.json 2>/dev/null
+  python bench.py --width 1920 --height 1080 --no-cpu-baseline > $O/bench_config1_1080p.json 2>/dev/null
+  python bench.py --width 7680 --height 4320 --no-cpu-baseline > $O/bench_config4_8k_1gpu.json 2>/dev/null
+  python bench.py --gpus 1 --transport loopback --no-cpu-baseline --also-bands > $O/bench_loopback_multi.json 2>/dev/null
+  for f in $O/bench_*.json; do python - $f <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d['kernel_ms'], d['roofline']['frac'], (d.get('smaa') or {}).get('ms_per_resolve'), (d.get('cpu_baseline') or {}).get('value'))
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+  done
+  find $O/bench_trace -name "*kernel_stats.csv" | head -2
+  REPS=20 bash tools/ab_smaa.sh > $O/smaa_split.txt 2>&1; cat $O/smaa_split.txt
   ;;
 bench)
   timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.err; tail -c 3000 $O/bench.json
