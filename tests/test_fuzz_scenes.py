@@ -142,8 +142,23 @@ SWEEP = 150   # seeds per generator in the -m gpu suite (0.18 s each, nearly all
               # suite's 495, against a 1 200 s budget for everything the driver runs; tools/fuzz_gpu.py runs the 10^4-scale sweeps)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_sized_torus_scene_bit_exact_on_host(built, small_textures, seed):
+    """Tori of every size (tests/random_scenes.py::sized_torus_scene: R 0.04 .. 25, tubes of 4 % .. 140 % of it -- round 6): most of them lie
+    outside the size range the cull premises were audited on and are never culled (rt_pack.h); those inside it take the noise-aware
+    inflation. Culls on == culls off == oracle, bit for bit, ray counts included."""
+    W, H = [(112, 64), (97, 65)][seed % 2]
+    sc = random_scenes.sized_torus_scene(seed, W, H)
+    ref, cnt = oracle.OracleScene(sc, W, H, small_textures["textures"], small_textures["cubemap"], texture_lod=0).render()
+    for cull in (True, False):
+        img, hc = harness.render(sc, W, H, small_textures["textures"], small_textures["cubemap"], cull=cull)
+        same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), (seed, cull, int((~same).sum()))
+        assert hc["closest"] == cnt["rays_closest"] and hc["shadow_ref"] == cnt["rays_shadow"], (seed, cull)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("gen", ["random_scene", "nasty_scene", "scaled_quat_scene", "crowd_scene", "pencil_scene"])
+@pytest.mark.parametrize("gen", ["random_scene", "nasty_scene", "scaled_quat_scene", "crowd_scene", "pencil_scene", "sized_torus_scene"])
 def test_fuzz_sweep_on_gpu(built, small_textures, gen):
     """150 seeds of each generator (80 of the long-table ones) through ONE context per frame size (re-specialised per scene, as a program that swaps scenes
     would): culls on against the un-culled oracle -- max 1e-4, NaN/inf in the same places, identical ray counts (counting variant of the

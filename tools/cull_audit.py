@@ -187,15 +187,16 @@ def main():
     ap.add_argument("--margin-rays", type=float, default=None, help="rays of the torus_margin family (every ray is solved: default rays / 20)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="keep the scenes whose name starts with this (e.g. sized_torus_scene)")
+    ap.add_argument("--seed0", type=int, default=1000, help="first ray-stream seed (scene k of a family draws from seed0 + k): another value = other rays")
     args = ap.parse_args()
     lib = load()
     scs = scene_list(args.scenes)
     if args.only:
         scs = [(n, s) for n, s in scs if n.startswith(args.only)]
-    report = {"rays_per_family": args.rays, "families": {}, "scenes": [n for n, _ in scs]}
+    report = {"rays_per_family": args.rays, "seed0": args.seed0, "families": {}, "scenes": [n for n, _ in scs]}
     for fam in args.families.split(","):
         want = args.rays if fam != "torus_margin" else (args.margin_rays or args.rays / 20)
-        entry = run_family(lib, scs, fam, want)
+        entry = run_family(lib, scs, fam, want, seed0=args.seed0)
         c, gpu_s, viol, bad_rows = entry.pop("raw"), entry["gpu_seconds"], entry["violations"], entry["first_violations"]
         report["families"][fam] = entry
         print(f"== {fam}: {c[0]:.3e} rays over {entry['scenes']} scenes in {gpu_s:.1f} s of kernels: {viol} violations", flush=True)

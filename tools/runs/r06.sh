@@ -4,7 +4,7 @@
 # steps:
 #   behind   the "behind" rule of the torus culls: audits (behind, behind_far, torus, tables) + what it costs (A/B against variants built by
 #            tools/ab_build.sh: r5rule = -DRT_TORUS_BEHIND_RULE=0, notube = -DRT_TORUS_BACK_TUBE=0, backinf = no backward reach)
-#   audit    tools/cull_audit.py <families> <rays> <scenes>                      e.g. r06.sh audit torus_behind 1e12 24
+#   audit    tools/cull_audit.py <families> <rays> <scenes> [timeout] [seed0]    e.g. r06.sh audit torus_behind 1e12 24
 #   ab       tools/ab_run.py <scenes...> over every library under raytracing_opengl_amd/variants/   (AB_SIZE, AB_STEPS from the environment)
 #   dk       tools/dk_stats.py over counting builds <variant names>
 #   sized    torus / torus_margin / torus_lead audits over the sized-torus scenes only, violations by scene
@@ -22,8 +22,8 @@ behind)
   AB_SIZE=1920x1080 AB_STEPS=40 timeout 600 python tools/ab_run.py default > $O/ab_1080p.txt 2>&1; cat $O/ab_1080p.txt
   ;;
 audit)
-  timeout ${4:-3000} python tools/cull_audit.py --families $1 --rays $2 --scenes ${3:-12} --out $O/$1_$2.json 2>&1 | grep -v amdgpu.ids | cut -c1-420 > $O/$1_$2.txt
-  grep "==\|VIOLATION\|phantom\|hits reported" $O/$1_$2.txt | cut -c1-200
+  timeout ${4:-3000} python tools/cull_audit.py --families $1 --rays $2 --scenes ${3:-12} --seed0 ${5:-1000} --out $O/$1_$2_s${5:-1000}.json 2>&1 | grep -v amdgpu.ids | cut -c1-420 > $O/$1_$2_s${5:-1000}.txt
+  grep "==\|VIOLATION\|phantom\|hits reported" $O/$1_$2_s${5:-1000}.txt | cut -c1-200
   ;;
 ab)
   timeout 1500 python tools/ab_run.py "$@" > $O/ab_${AB_SIZE:-4k}.txt 2>&1; cat $O/ab_${AB_SIZE:-4k}.txt
