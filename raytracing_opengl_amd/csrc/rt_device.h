@@ -1705,9 +1705,6 @@ RT_HD uint32_t pencil_cell_word(const SceneView& S, const DevPencil& P, const Pe
 #else
 #define RT_REC(T) T&
 #endif
-#ifndef RT_TORUS_LANE_PHASE1
-#define RT_TORUS_LANE_PHASE1 0   /* A/B: the first-level torus tests of a table-driven scan per lane over the lane's own candidate word instead of wave-uniform over the union */
-#endif
 #ifndef RT_SURF_PREFETCH
 #define RT_SURF_PREFETCH 0   /* 1: the quadric mask walk loads the NEXT candidate's cull record while the current one is tested (A/B: profiles/r06c_*) */
 #endif
@@ -1950,23 +1947,12 @@ RT_HD float calc_inter(const SceneView& S, f3 ro, f3 rd, int& num, int& type, La
             bool group_live = true;
             if (ps.use) {   // phase 1 over the wave's pencil candidates only
                 for (int w = base >> 5; w << 5 < end; w++) {
-#if RT_TORUS_LANE_PHASE1
-                    uint32_t own = ps.next(S, slabw);          // every lane walks ITS OWN word (vector loads of the bounds): max popcount trips, not the union's
-                    while (RT_ANY(own != 0u)) {
-                        if (own != 0u) {
-                            const int b = __builtin_ctz(own), i = (w << 5) + b;
-                            own &= own - 1u;
-                            if (!torus_cull(bound[i], ro, rd)) cand |= 1ull << (i - base);
-                        }
-                    }
-#else
                     uint32_t u = wave_or(ps.next(S, slabw), true);
                     while (u != 0u) {
                         const int b = __builtin_ctz(u), i = (w << 5) + b;
                         u &= u - 1u;
                         if (!torus_cull(bound[i], ro, rd)) cand |= 1ull << (i - base);
                     }
-#endif
                 }
             } else
             for (int i = base; i < end; i += 4) {
@@ -2157,24 +2143,12 @@ RT_HD float in_shadow(const SceneView& S, const TexTable& T, bool on, bool ref_o
                 bool group_live = true;
                 if (ps.use) {
                     for (int w = base >> 5; w << 5 < end; w++) {
-#if RT_TORUS_LANE_PHASE1
-                        uint32_t own = ps.next(S, slabw);
-                        own = on ? own : 0u;
-                        while (RT_ANY(own != 0u)) {
-                            if (own != 0u) {
-                                const int b = __builtin_ctz(own), i = (w << 5) + b;
-                                own &= own - 1u;
-                                if (!torus_cull(bound[i], ro, rd)) cand |= 1ull << (i - base);
-                            }
-                        }
-#else
                         uint32_t u = wave_or(ps.next(S, slabw), on);
                         while (u != 0u) {
                             const int b = __builtin_ctz(u), i = (w << 5) + b;
                             u &= u - 1u;
                             if (on && !torus_cull(bound[i], ro, rd)) cand |= 1ull << (i - base);
                         }
-#endif
                     }
                 } else
                 for (int i = base; i < end; i += 4) {
