@@ -1118,9 +1118,7 @@ RT_HD bool torus_puck_cull(const DevTorus& T, f3 o, f3 d)
 // TUBE: the Bernstein test of the inflated tube behind the puck test (round 4). Compiled into the many-primitive kernel variant (and the host
 // build): 64 tori, 4K, depth 6: 5.25 M -> 4.47 M solves, 141 k -> 128 k solver runs, 1 904 -> 1 794 us; in the default variant its one torus gains
 // a tenth fewer runs and loses as much to the 90 instructions per candidate pass (472 -> 477 us: not compiled in there).
-#ifndef RT_TORUS_BACK_TUBE
-#define RT_TORUS_BACK_TUBE 1     /* the tube test on the backward half-line in every kernel variant (a ray it does not remove is a 60-sweep solve) */
-#endif
+// (the half-line o + t d, t >= 0, whichever way it points along the ray's line: torus_local_cull)
 template <bool TUBE = true>
 RT_HD bool torus_forward_cull(const DevTorus& T, f3 o, f3 d)
 {
@@ -1137,24 +1135,22 @@ RT_HD bool torus_forward_cull(const DevTorus& T, f3 o, f3 d)
     // measured and not compiled in, profiles/r05u_start_cull_ab.txt.)
     return TUBE && T.k.w > 0.0f && torus_tube_cull(T, o, d, t0, t1);
 }
-// The "behind" rule (torus_cull): from an origin outside the bounding sphere the part of the LINE behind the origin has to clear the inflated torus too -- the same puck
-// and tube tests on the reversed ray (the hull test is a statement about half-lines that move away from the disc; a reversed ray of this
-// kind moves towards it).
-RT_HD bool torus_backward_cull(const DevTorus& T, f3 o, f3 d)
-{
-    const f3 nd = mk3(-d.x, -d.y, -d.z);
-    float t0, t1;
-    if (torus_puck_cull(T, o, nd, t0, t1, RT_TORUS_REACH_BACK)) return true;
-    return RT_TORUS_BACK_TUBE && T.k.w > 0.0f && torus_tube_cull(T, o, nd, t0, t1);
-}
+// The "behind" rule (torus_cull) in the torus' own frame. From an origin OUTSIDE the inflated bounding sphere exactly one half of the ray's line
+// can meet the torus: with the centre ahead (o.d < 0) the backward half only moves away from the sphere it already is outside of, with the
+// centre behind (o.d >= 0) the forward half does. So the one set of tests -- hull, puck, tube -- runs on the half-line that matters: the ray
+// itself, or the REVERSED ray (whose roots are the negative ones the reference's solver may throw to the positive side). A sign error of
+// o.d next to 0 lets the other half dip into the sphere by ~1e-14 |o|^2, nowhere near the torus inside it (the sphere is 1 % + 0.01 larger).
+// An origin inside the sphere (a torus' own shadow and mirror rays) is judged on its forward half-line, as the premises were measured.
+// (First form of round 6: forward tests, then the backward ones for every forward-culled far ray -- twice the work on most rays that reach
+// this point, default 4K frame 474 us; this form: profiles/r06h_*.)
 template <bool TUBE = true>
 RT_HD bool torus_local_cull(const DevTorus& T, f3 o, f3 d)
 {
     const float dd = dot3(d, d);
     if (!unit_direction(dd)) return false;  // not a unit direction: the solver's result is not geometric (see torus_cull)
-    if (!torus_forward_cull<TUBE>(T, o, d)) return false;
-    if (!RT_TORUS_BEHIND_RULE || !(dot3(o, o) > T.k.z)) return true;     // origin inside the inflated bounding sphere (T.k.z = its radius^2): the half-line decides
-    return torus_backward_cull(T, o, d);
+    const bool back = RT_TORUS_BEHIND_RULE && (dot3(o, o) > T.k.z) & (dot3(o, d) >= 0.0f);     // T.k.z: the bounding sphere's radius^2
+    static_assert(RT_TORUS_REACH_BACK == RT_TORUS_REACH, "torus_puck_cull takes one reach for both halves of the line");
+    return torus_forward_cull<TUBE>(T, o, back ? mk3(-d.x, -d.y, -d.z) : d);
 }
 template <bool CULL, bool TUBE = true>
 RT_HD bool intersect_torus_c(const DevTorus& T, f3 ro, f3 rd, float tmin, float& t, bool& solved)

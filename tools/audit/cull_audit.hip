@@ -248,9 +248,12 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         // the local culls as the product composes them (round 6: from a far origin the hull / puck / tube tests of the forward half-line only count
         // together with the backward half's -- rt_device.h torus_local_cull, the "behind" rule), attributed to the forward test that fired
         const bool c_local = unit && torus_local_cull<true>(T, o, d);
-        const bool f_hull = unit && torus_hull_cull(T, o, d);
+        // (the half-line the product judges: the reversed ray from an origin outside the bounding sphere with the centre behind it)
+        const bool back_half = RT_TORUS_BEHIND_RULE && dot3(o, o) > T.k.z && dot3(o, d) >= 0.0f;
+        const f3 dj = back_half ? mk3(-d.x, -d.y, -d.z) : d;
+        const bool f_hull = unit && torus_hull_cull(T, o, dj);
         float pk0 = 0.0f, pk1 = 0.0f;
-        const bool f_puck = unit && torus_puck_cull(T, o, d, pk0, pk1);
+        const bool f_puck = unit && torus_puck_cull(T, o, dj, pk0, pk1);
         (void)pk0; (void)pk1;
         const bool c_hull = c_local && f_hull, c_puck = c_local && !f_hull && f_puck, c_tube = c_local && !f_hull && !f_puck;
         // the premise in its strongest form: the ray's part up to the reference's own reach (t < 100: RT_TORUS_REACH, never the ray's limit --
