@@ -505,18 +505,15 @@ RT_COLD f4 sample_cube_lod(const DevCubemap& c, f3 d, float lambda)
         f = lambda - fl;
         two = l0 + 1 <= c.levels - 1;
     }
-    int w = c.size;
-    uint32_t first = 0;
-    for (int l = 0; l < l0; l++) {   // dword offset of level l0 (per lane; a handful of integer operations per level)
-        first += 6u * (uint32_t)w * (uint32_t)w;
-        w = w > 1 ? w >> 1 : 1;
-    }
+    int w = c.size >> l0;            // level l0: faces of max(1, size >> l0) texels, at c.level_off[l0] (the host's table, as for the 2-D textures)
+    w = w > 1 ? w : 1;
+    uint32_t first = c.level_off[l0];
     f4 c0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
         if (pass == 1 && !RT_ANY(two)) break;
         if (pass == 1 && two) {
-            first += 6u * (uint32_t)w * (uint32_t)w;
+            first = c.level_off[l0 + 1];
             w = w > 1 ? w >> 1 : 1;
         }
         int i0, i1, j0, j1;

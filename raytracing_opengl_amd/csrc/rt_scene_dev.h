@@ -204,6 +204,7 @@ struct DevCubemap {
     int32_t face_mask;       // bit f set = face present (a missing face samples black)
     float fsize;             // (float)size
     int32_t levels;          // 1 = no mip chain (the reference's default genMipmap = false, or RTX_OPT_TEXTURE_LOD = 0)
+    uint32_t level_off[MAX_MIPS];  // dword offset of each level's six faces (round 6, ADVICE r5: the fetch used to add the levels up per lane)
 };
 
 }  // namespace rtdev

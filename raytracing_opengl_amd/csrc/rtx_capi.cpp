@@ -305,6 +305,15 @@ void fill_tex_table(rtx_context* ctx, TexTable& T)
             T.sky.fsize = static_cast<float>(it->second.width);
             T.sky.face_mask = it->second.face_mask;
             T.sky.levels = ctx->opt_lod ? it->second.levels : 1;   // RTX_OPT_TEXTURE_LOD = 0: level 0 everywhere, as for the 2-D textures
+            {   // level L of the cube = six faces of max(1, size >> L)^2 dwords behind level L - 1 (rtx_cubemap_create)
+                uint32_t off = 0;
+                int wl = it->second.width;
+                for (int l = 0; l < MAX_MIPS; l++) {
+                    T.sky.level_off[l] = off;
+                    off += 6u * static_cast<uint32_t>(wl) * static_cast<uint32_t>(wl);
+                    wl = wl > 1 ? wl >> 1 : 1;
+                }
+            }
         }
     }
 }

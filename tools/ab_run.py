@@ -43,7 +43,7 @@ if __name__ == "__main__":
     scene_names = sys.argv[1:] or ["default", "quadric", "torus"]
     vdir = os.path.join(ROOT, "raytracing_opengl_amd", "variants")
     libs = [("product", os.path.join(ROOT, "raytracing_opengl_amd", "librtx_hip.so"))]
-    libs += [(f[len("librtx_hip_"):-3], os.path.join(vdir, f)) for f in sorted(os.listdir(vdir)) if f.endswith(".so") and "_dk" not in f and "_prof" not in f]
+    libs += [(f[len("librtx_hip_"):-3], os.path.join(vdir, f)) for f in (sorted(os.listdir(vdir)) if os.path.isdir(vdir) else []) if f.endswith(".so") and "_dk" not in f and "_prof" not in f]
     for rep in range(2):
         for tag, path in libs:
             env = dict(os.environ, RTX_HIP_LIB=path)
