@@ -105,10 +105,10 @@ typedef enum rtx_option {
                                 set the same value on every rank, like RTX_OPT_BAND_LAYOUT and rtx_set_band_split: each process sizes its own
                                 side of the paired ncclSend / ncclRecv from them. Since round 6 the ranks cross-check: whenever a rank's frame
                                 configuration (size, rank count, layout, split, targets, this option) differs from the one last confirmed, the
-                                next rtx_draw first compares 16-byte digests across the ranks and fails with RTX_ERR_INVALID, naming the rank
-                                that differs, before a band travels; waits on the transfer stream are bounded by the environment variable
-                                RTX_GATHER_TIMEOUT_MS (default 30 000; 0 = wait for ever) and end with RTX_ERR_DEVICE naming a rank that
-                                never answered. */
+                                next rtx_draw first all-gathers 16-byte digests across the ranks and fails ON EVERY RANK with RTX_ERR_INVALID,
+                                naming the rank that differs, before a band travels; waits on the transfer stream are bounded by the
+                                environment variable RTX_GATHER_TIMEOUT_MS (default 30 000; 0 = wait for ever) and end with RTX_ERR_DEVICE
+                                instead of a hung process when a rank never takes part. */
     RTX_OPT_HIGH_OCCUPANCY = 5 /* which build of the trace kernel runs: 0 = the default one, 1 = the many-primitive one (group culls, ray
                                 pencils and slab tables compiled in; its own register budget -- 7 waves/SIMD in round 1, hence the
                                 name, 6 now), -1 (default) = choose by primitive count (>= 32 -> 1). Same results. */

@@ -22,6 +22,7 @@ ncclResult_t ncclCommInitAll(ncclComm_t*, int, const int*);
 ncclResult_t ncclCommDestroy(ncclComm_t);
 ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclAllGather(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
 ncclResult_t ncclGroupStart(void);
 ncclResult_t ncclGroupEnd(void);
 const char* ncclGetErrorString(ncclResult_t);
@@ -580,6 +581,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;   // the ranks' first contact only (config_handshake); absent in a library: the check is skipped
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -597,6 +599,7 @@ struct Rccl {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
@@ -673,53 +676,35 @@ rtbands::FrameConfig frame_config(const rtx_context* me)
     return fc;
 }
 // Ranks in separate processes: before a band travels under a configuration this rank has not had confirmed, the ranks compare 16-byte
-// digests of it (band_math.h): peer -> rank 0, rank 0 -> verdict to every peer. Fixed-size messages that pair whatever the configurations
-// are; a rank that does not take part shows up as a timeout that names it. Costs two small messages, only when something changed.
+// digests of it (band_math.h). ONE ncclAllGather of 16 bytes per rank on the transfer stream: a collective runs on the rings the communicator
+// built at ncclCommInitRank, so it needs no connection of its own (a send / receive pair in each direction would: RCCL connects peers
+// lazily, both directions of a pair in one blocking exchange, and a root that first receives and then answers never gets there), every rank
+// sees every digest and fails by itself with the same message, and the message sizes are fixed whatever the configurations are. A rank that
+// does not take part shows up as the bounded wait's timeout on the others. Costs one small collective, only when something changed.
 int config_handshake(rtx_context* me)
 {
-    if (!me->per_process || !me->banded || me->loopback || me->n_total < 2 || !uses_rccl(me)) return RTX_OK;
+    if (!me->per_process || !me->banded || !uses_rccl(me) || !g_rccl.AllGather) return RTX_OK;
     const rtbands::ConfigDigest mine = rtbands::config_digest(frame_config(me));
     if (mine == me->cfg_confirmed) return RTX_OK;
     int st = use_device(me);
     if (st) return st;
     const int N = me->n_total;
     const size_t slot = 16;
-    if (!me->d_cfg) HIP_TRY(hipMalloc(&me->d_cfg, slot * static_cast<size_t>(2 * N + 2)));
+    if (!me->d_cfg) HIP_TRY(hipMalloc(&me->d_cfg, slot * static_cast<size_t>(N + 1)));
     auto at = [&](int k) { return static_cast<void*>(static_cast<char*>(me->d_cfg) + slot * static_cast<size_t>(k)); };
     unsigned long long msg[2] = {mine.a, mine.b};
-    HIP_TRY(hipMemcpyAsync(at(0), msg, slot, hipMemcpyHostToDevice, me->xfer_stream));
-    if (me->rank != 0) {
-        NCCL_TRY(g_rccl.GroupStart());
-        NCCL_TRY_IN_GROUP(g_rccl.Send(at(0), slot, ncclUint8, 0, me->comm, me->xfer_stream));
-        NCCL_TRY_IN_GROUP(g_rccl.Recv(at(1), slot, ncclUint8, 0, me->comm, me->xfer_stream));
-        NCCL_TRY(g_rccl.GroupEnd());
-        if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check", 0)) != RTX_OK) return st;
-        unsigned long long verdict[2] = {0, 0};
-        HIP_TRY(hipMemcpy(verdict, at(1), slot, hipMemcpyDeviceToHost));
-        if (verdict[0] != 0)
-            return fail(RTX_ERR_INVALID, "frame configuration of rank %d differs from rank 0's (this is rank %d): frame size, rank count, RTX_OPT_BAND_LAYOUT, the band split, "
-                        "RTX_OPT_GATHER_TARGETS and RTX_OPT_GATHER_RGB must be the same on every rank", static_cast<int>(verdict[0]) - 1, me->rank);
-    } else {
-        for (int r = 1; r < N; r++) {      // one peer at a time: a rank that never calls is named by the timeout
-            NCCL_TRY(g_rccl.Recv(at(r), slot, ncclUint8, r, me->comm, me->xfer_stream));
-            if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check", r)) != RTX_OK) return st;
-        }
-        std::vector<rtbands::ConfigDigest> all(static_cast<size_t>(N));
-        std::vector<unsigned long long> host(static_cast<size_t>(2 * N));
-        HIP_TRY(hipMemcpy(host.data(), me->d_cfg, slot * static_cast<size_t>(N), hipMemcpyDeviceToHost));
-        for (int r = 0; r < N; r++) { all[r].a = host[2 * r]; all[r].b = host[2 * r + 1]; }
-        all[0] = mine;
-        const int wrong = rtbands::config_first_mismatch(all);
-        unsigned long long verdict[2] = {wrong < 0 ? 0ull : static_cast<unsigned long long>(wrong) + 1ull, 0ull};
-        HIP_TRY(hipMemcpyAsync(at(N), verdict, slot, hipMemcpyHostToDevice, me->xfer_stream));
-        NCCL_TRY(g_rccl.GroupStart());
-        for (int r = 1; r < N; r++) NCCL_TRY_IN_GROUP(g_rccl.Send(at(N), slot, ncclUint8, r, me->comm, me->xfer_stream));
-        NCCL_TRY(g_rccl.GroupEnd());
-        if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check (verdicts)")) != RTX_OK) return st;
-        if (wrong >= 0)
-            return fail(RTX_ERR_INVALID, "frame configuration of rank %d differs from rank 0's: frame size, rank count, RTX_OPT_BAND_LAYOUT, the band split, "
-                        "RTX_OPT_GATHER_TARGETS and RTX_OPT_GATHER_RGB must be the same on every rank", wrong);
-    }
+    HIP_TRY(hipMemcpyAsync(at(N), msg, slot, hipMemcpyHostToDevice, me->xfer_stream));            // own digest behind the N gathered slots
+    NCCL_TRY(g_rccl.AllGather(at(N), at(0), slot, ncclUint8, me->comm, me->xfer_stream));
+    if ((st = wait_stream_bounded(me, me->xfer_stream, "frame-configuration check (is every rank drawing, with the same calls in the same order?)")) != RTX_OK) return st;
+    std::vector<unsigned long long> host(static_cast<size_t>(2 * N));
+    HIP_TRY(hipMemcpy(host.data(), me->d_cfg, slot * static_cast<size_t>(N), hipMemcpyDeviceToHost));
+    std::vector<rtbands::ConfigDigest> all(static_cast<size_t>(N));
+    for (int r = 0; r < N; r++) { all[r].a = host[2 * r]; all[r].b = host[2 * r + 1]; }
+    if (all[me->rank] != mine) return fail(RTX_ERR_DEVICE, "frame-configuration check: rank %d did not get its own digest back from the all-gather", me->rank);
+    const int wrong = rtbands::config_first_mismatch(all);
+    if (wrong >= 0)
+        return fail(RTX_ERR_INVALID, "frame configuration of rank %d differs from rank 0's (this is rank %d): frame size, rank count, RTX_OPT_BAND_LAYOUT, the band split, "
+                    "RTX_OPT_GATHER_TARGETS and RTX_OPT_GATHER_RGB must be the same on every rank", wrong, me->rank);
     me->cfg_confirmed = mine;
     return RTX_OK;
 }

@@ -136,24 +136,25 @@ int bands_rebalance(int height, int n_ranks, const int* rows_now, const double* 
 }
 // ---- first contact (band_math.h FrameConfig / config_digest / config_first_mismatch / bounded_wait; rtx_capi.cpp config_handshake) ----
 // cfg = n_ranks rows of 8 ints (width, height, n_ranks, band_rows, band_layout, gather_targets, gather_rgb, loopback) + split rows per rank
-// (n_split ints each, used when band_layout != 0). The fake transport: every "peer" hands its 16-byte digest to "rank 0", which answers with
-// the verdict the product sends (0 = agreed, 1 + r = rank r differs). present[r] == 0: that rank never calls -- rank 0's wait for it runs
-// on a fake clock (one tick per poll) against `timeout_ticks` and the function returns -(100 + r), the rank the product's message would name.
+// (n_split ints each, used when band_layout != 0). The fake transport is an all-gather: every rank contributes its 16-byte digest and sees
+// all of them; the return value is what EVERY rank of the product concludes (0 = agreed, 1 + r = rank r differs from rank 0). present[r] == 0:
+// that rank never calls, the collective cannot complete -- the others' wait runs on a fake clock (one tick per poll) against
+// `timeout_ticks` and the function returns -100 (the product's RTX_ERR_DEVICE: "did not finish within ...").
 int bands_sim_handshake(int n_ranks, const int* cfg, const int* split, int n_split, const int* present, int timeout_ticks)
 {
     std::vector<rtbands::ConfigDigest> digests(static_cast<size_t>(n_ranks));
+    bool all_present = true;
     for (int r = 0; r < n_ranks; r++) {
         rtbands::FrameConfig fc;
         const int* c = cfg + 8 * r;
         fc.width = c[0]; fc.height = c[1]; fc.n_ranks = c[2]; fc.band_rows = c[3]; fc.band_layout = c[4]; fc.gather_targets = c[5]; fc.gather_rgb = c[6]; fc.loopback = c[7];
         if (split && n_split > 0) fc.split_rows.assign(split + static_cast<size_t>(r) * n_split, split + static_cast<size_t>(r + 1) * n_split);
         digests[r] = rtbands::config_digest(fc);
+        all_present = all_present && present[r] != 0;
     }
-    for (int r = 1; r < n_ranks; r++) {          // rank 0 receives one peer at a time (config_handshake), each wait bounded
-        double clock = 0.0;
-        const bool arrived = rtbands::bounded_wait([&] { return present[r] != 0; }, [&] { return clock; }, [&] { clock += 1.0; }, static_cast<double>(timeout_ticks));
-        if (!arrived) return -(100 + r);
-    }
+    double clock = 0.0;
+    const bool done = rtbands::bounded_wait([&] { return all_present; }, [&] { return clock; }, [&] { clock += 1.0; }, static_cast<double>(timeout_ticks));
+    if (!done) return -100;
     const int wrong = rtbands::config_first_mismatch(digests);
     return wrong < 0 ? 0 : 1 + wrong;
 }

@@ -147,8 +147,8 @@ def _handshake(lib, cfgs, splits=None, present=None, timeout=50):
 
 def test_first_contact_ranks_that_disagree_about_the_frame_are_told_so(lib):
     """VERDICT r5 item 6 (rtx_capi.cpp config_handshake; include/rtx.h: RTX_OPT_GATHER_RGB / band layout / split / targets decide the byte counts
-    of the paired ncclSend / ncclRecv on every rank independently): ranks in separate processes compare a 16-byte digest of the frame
-    configuration before a band travels. Same configuration -> 0; any single field changed on one rank -> that rank is named."""
+    of the paired ncclSend / ncclRecv on every rank independently): ranks in separate processes all-gather a 16-byte digest of the frame
+    configuration before a band travels. Same configuration -> 0; any single field changed on one rank -> every rank names that rank."""
     base = [3840, 2160, 4, 8, 0, 3, 1, 0]           # width, height, n_ranks, band_rows, band_layout, gather_targets, gather_rgb, loopback
     assert _handshake(lib, [base] * 4) == 0
     for field in range(8):
@@ -164,14 +164,14 @@ def test_first_contact_ranks_that_disagree_about_the_frame_are_told_so(lib):
     assert _handshake(lib, [base] * 4, [even, even, skew, even]) == 0
 
 
-def test_first_contact_a_rank_that_never_calls_is_named_not_waited_for(lib):
-    """The waits on the transfer stream are bounded (RTX_GATHER_TIMEOUT_MS; band_math.h bounded_wait, here on a fake clock): rank 0 receives the
-    peers' digests one at a time, so the rank that never issued its send is the one the error names -- not a hung process."""
+def test_first_contact_a_rank_that_never_calls_is_a_timeout_not_a_hang(lib):
+    """The waits on the transfer stream are bounded (RTX_GATHER_TIMEOUT_MS; band_math.h bounded_wait, here on a fake clock): the all-gather of the
+    digests cannot complete without every rank, and the ranks that did call get RTX_ERR_DEVICE instead of a hung process."""
     base = [1920, 1080, 8, 8, 0, 1, 1, 0]
     assert _handshake(lib, [base] * 8, present=[1] * 8) == 0
     for missing in (1, 4, 7):
         present = [1] * 8
         present[missing] = 0
-        assert _handshake(lib, [base] * 8, present=present, timeout=50) == -(100 + missing)
-    # a timeout of 0 means "wait for ever" (rounds 1-5): not exercised with a missing rank, but a present one still completes at once
+        assert _handshake(lib, [base] * 8, present=present, timeout=50) == -100
+    # a timeout of 0 means "wait for ever" (rounds 1-5): not exercised with a missing rank, but a complete group still finishes at once
     assert _handshake(lib, [base] * 2, present=[1, 1], timeout=0) == 0

@@ -284,7 +284,7 @@ def test_rank_context_of_a_one_process_per_gpu_split(small_textures):
 
 def test_first_contact_between_ranks_in_separate_processes():
     """ranks that disagree about the frame configuration are told so (RTX_ERR_INVALID naming the rank) and a rank that never
-    calls is named by a bounded wait (RTX_ERR_DEVICE) -- on real devices, two processes (tools/first_contact_check.py). Needs two GPUs; the
+    calls is a bounded wait's timeout (RTX_ERR_DEVICE), not a hang -- on real devices, two processes (tools/first_contact_check.py). Needs two GPUs; the
     protocol itself runs on the CPU against a fake transport in tests/test_band_math.py."""
     import os, subprocess, sys
     if _n_devices() < 2:
@@ -294,7 +294,7 @@ def test_first_contact_between_ranks_in_separate_processes():
            os.path.join(root, "tools", "first_contact_check.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    assert "1. 2 ranks agree" in r.stdout and "3. rank 0: the silent rank is named" in r.stdout, r.stdout[-2000:]
+    assert "1. 2 ranks agree" in r.stdout and "3. rank 0: a silent rank is a timeout" in r.stdout, r.stdout[-2000:]
 
 
 def _run_bench(extra, torchrun=False, timeout=600):
