@@ -222,7 +222,7 @@ def pencil_scene(seed: int, w: int, h: int):
 
 
 def sized_torus_scene(seed: int, w: int, h: int):
-    """Tori of every SIZE (round 6: what the torus culls call a near or a far origin scales with the torus -- rt_device.h torus_near2): major radius
+    """Tori of every SIZE (round 6: the torus cull premises are statements about a float iteration whose behaviour depends on the torus' size -- rt_pack.h RT_TORUS_CULL_*): major radius
     log-uniform over 0.04 .. 25, tube 4 % .. 140 % of it (ring, horn and spindle tori), random rotations, a floor, one light of each kind. The other
     generators draw R in 0.3 .. 2 only. Used by tools/cull_audit.py (torus families) and the fuzz tests."""
     rng = np.random.default_rng(seed ^ 0x51ced)

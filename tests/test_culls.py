@@ -696,7 +696,7 @@ def test_the_behind_rays_are_what_the_fixture_says(built):
 
 def test_the_product_reports_the_reference_phantom_hit_on_the_behind_rays(built):
     """What parity with the reference demands on those rays: the product's composition (cull, then solve) reports the reference's hit.
-    Rounds 2-5 culled them unsolved (a strict xfail recorded it); round 6's "behind" rule (rt_device.h torus_cull: a torus behind a FAR origin is
+    Rounds 2-5 culled them unsolved (a strict xfail recorded it); round 6's "behind" rule (rt_device.h torus_cull: from an origin outside its bounding sphere a torus is
     culled only where the ray's whole line clears it) lets them through to the solver, whose result is the oracle's bit for bit -- for the
     torus on its own (kat) and through the product's scans over the whole scene, candidate tables and all, culls on against off (probe)."""
     rays = _behind_rays()

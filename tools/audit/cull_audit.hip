@@ -245,8 +245,8 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         const bool unit = unit_direction(dot3(d, d));
         const bool c_sphere = torus_cull(bound, ro, rd);
         const bool c_group = grouped && torus_group_cull(S.torus_group()[i / RT_GROUP], ro, rd);
-        // the local culls as the product composes them (round 6: from a far origin the hull / puck / tube tests of the forward half-line only count
-        // together with the backward half's -- rt_device.h torus_local_cull, the "behind" rule), attributed to the forward test that fired
+        // the local culls as the product composes them (round 6: from an origin outside the bounding sphere the hull / puck / tube tests run on the ONE half of the line that can meet the torus
+        // -- rt_device.h torus_local_cull, the "behind" rule), attributed to the test that fired
         const bool c_local = unit && torus_local_cull<true>(T, o, d);
         // (the half-line the product judges: the reversed ray from an origin outside the bounding sphere with the centre behind it)
         const bool back_half = RT_TORUS_BEHIND_RULE && dot3(o, o) > T.k.z && dot3(o, d) >= 0.0f;
@@ -258,7 +258,7 @@ __device__ void audit_torus(const AuditParams& p, const SceneView& S, unsigned l
         const bool c_hull = c_local && f_hull, c_puck = c_local && !f_hull && f_puck, c_tube = c_local && !f_hull && !f_puck;
         // the premise in its strongest form: the ray's part up to the reference's own reach (t < 100: RT_TORUS_REACH, never the ray's limit --
         // rt_device.h torus_cull) stays 6 mm clear of the REAL tube (exact) -- every cull and every clear bit of a candidate table implies it
-        // (their margins are 1 % + 0.01 and more); from a far origin (the "behind" rule) the backward half up to RT_TORUS_REACH_BACK as well
+        // (their margins are 1 % + 0.01 and more); from an origin outside the bounding sphere (the "behind" rule) the backward half up to RT_TORUS_REACH_BACK as well
         // (round 6: "6 mm" was 0.6 of the smallest inflation any cull uses, 1 cm -- now 0.6 of the tube's own inflation T.cull.x - |r|, which is 1 cm + 1 %
         // for r >= 0.3 and grows to RT_TORUS_IM_NOISE for thin tubes: rt_pack.h)
         const double clear_min = 0.6 * ((double)T.cull.x - fabs((double)T.radii.y));
@@ -421,7 +421,7 @@ __device__ void audit_torus_lead(const AuditParams& p, const SceneView& S, unsig
 // grazing; then the direction REVERSED), every one is solved. bins b = 0..9 of the origin's distance as in the lead family.
 // counters: 0 rays, 1 culled by the product's composition (torus_cull or the local culls), 2 hits reported, 20+b rays per bin, 30+b phantom hits
 //           per bin (hit reported, the half-line clears the real tube by more than 1 mm in double arithmetic), 40+b VIOLATIONS of those: culled by the
-//           product (round 6: the "behind" rule of rt_device.h torus_cull lets far origins through to the solver -- a phantom that is SOLVED is reproduced)
+//           product (round 6: the "behind" rule of rt_device.h torus_cull lets origins outside the bounding sphere through to the solver -- a phantom that is SOLVED is reproduced)
 __device__ void audit_torus_behind(const AuditParams& p, const SceneView& S, unsigned long long gid, unsigned int* c)
 {
     const int n = S.h->n_torus;
@@ -798,7 +798,7 @@ __device__ void audit_tables(const AuditParams& p, const SceneView& S, unsigned 
                 const double clr = ray_tube_clearance(T, o, d, (double)RT_TORUS_REACH * 1.001 + 0.01);
                 const double clear_min = T.cull.y < RT_FLT_MAX ? 0.5 * ((double)T.cull.x - fabs((double)T.radii.y)) : 5.0e-3;    // half the tube's own inflation (5 mm for r >= 0.3)
                 if (!(clr >= clear_min)) { c[11]++; record_bad(p, 11 + kind * 100, i - ns, ro, rd, tlimit, 0.0f, (float)clr); }
-                // the "behind" rule (rt_device.h torus_cull): from a far origin the LINE's part behind the origin, up to the backward reach, as well
+                // the "behind" rule (rt_device.h torus_cull): from an origin outside the bounding sphere the LINE's part behind the origin, up to the backward reach, as well
                 if (RT_TORUS_BEHIND_RULE && T.cull.y < RT_FLT_MAX && dot3(o, o) > T.k.z) {
                     c[8]++;
                     const double back = ray_tube_clearance(T, o, mk3(-d.x, -d.y, -d.z), (double)RT_TORUS_REACH_BACK * 1.001 + 0.01);
