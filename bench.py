@@ -22,8 +22,10 @@ Extra objects on the JSON line:
   roofline     HBM-write roofline of the trace kernel: W*H*16 B of RGBA32F per launch / mean kernel
                time from HIP events on the launch stream, against 8 TB/s; .valu = the ceiling that actually binds
                (VALU instructions per launch from profiles/valu.json / live duration vs the chip's issue rate).
-  cpu_baseline the oracle (scalar C restatement of the shader, all host cores) timed on one full
-               frame of the same workload, rank 0, N = 1 only.
+  cpu_baseline the oracle (scalar C restatement of the shader) on the CPUs this container may use (affinity mask capped by the cgroup
+               quota: 16 of the 256 hardware threads a GPU box shows), whole frames of the same workload for >= 10 s, rank 0, N = 1 only;
+               with the one-thread rate and the parallel efficiency beside it.
+  kernel_ms_stats  min / median / max of the timed draws' own HIP-event durations.
   smaa         the SMAA post-process on the traced frame: time of one resolve and its HBM roofline (untimed addition).
 """
 from __future__ import annotations
