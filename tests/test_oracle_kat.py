@@ -247,3 +247,15 @@ def test_mip_chain_and_trilinear_rule():
     lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.3, 0.6, 99.0, c0)
     lib.orc_kat_sample2d_lod(ctypes.byref(t), 0.9, 0.1, 3.0, c1)
     assert list(c0) == list(c1)                       # clamped to the 1x1 top level
+
+
+def test_effective_cpus_respects_affinity_and_cgroup_quota():
+    """oracle.effective_cpus(): the thread count every checker uses -- the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256
+    hardware threads and grant 16 CPUs of time: 256 OpenMP threads inside that quota ran the oracle at 8 Mray/s where 16 run it at 13)."""
+    import os
+    n, quota = oracle.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
+    if quota is not None:
+        assert quota > 0 and n <= int(quota + 0.999)
